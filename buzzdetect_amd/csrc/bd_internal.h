@@ -1,0 +1,48 @@
+// Internal declarations shared by the gfx950 kernels and the C-ABI host layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/buzzdetect_hip.h"
+
+namespace bd {
+
+constexpr int kMelMaxLen = 32;   // longest run of non-zero bins a mel band may have
+
+// Constant tables of the front end, built on the host at bd_create (engine.hip) and kept in
+// device memory; every workgroup stages them into LDS once.
+struct FeTables {
+    float  hann[BD_STFT_WINDOW];          // periodic Hann, evaluated in float32 like tf.signal.hann_window
+    float2 tw256[256];                    // exp(-2*pi*i*k/256)
+    float2 tw512[BD_SPECTRUM_BINS + 1];   // exp(-2*pi*i*k/512), k = 0..256 (+1 pad)
+    int    band_start[BD_MEL_BANDS];      // first non-zero bin of each mel band
+    int    band_len[BD_MEL_BANDS];        // number of consecutive non-zero bins
+    int    max_len;
+    int    pad_[3];
+    float  band_w[kMelMaxLen][BD_MEL_BANDS];  // band_w[j][m] = mel[band_start[m] + j][m]
+};
+
+// One separable layer (yamnet.py:52-74) after BatchNorm folding.
+struct SepLayer {
+    int cin, cout, stride;
+    int h_in, w_in, h_out, w_out;
+    const float* dw_w;   // [9][cin]   depthwise taps * bn scale
+    const float* dw_b;   // [cin]      beta - mean * scale
+    const float* pw_wt;  // [cout][cin] pointwise kernel transposed * bn scale (K contiguous)
+    const float* pw_b;   // [cout]
+};
+
+// ---- launchers (each enqueues exactly one kernel on `stream`) ----
+void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
+                   const FeTables* tables, hipStream_t stream);
+void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
+                    hipStream_t stream);
+void launch_conv1(const float* logmel, int patch_step, int windows, const float* w9x32,
+                  const float* b32, float* out, hipStream_t stream);
+void launch_depthwise(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream);
+void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream);
+void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
+                      int n_classes, float* emb, float* logits, hipStream_t stream);
+
+}  // namespace bd

@@ -1,0 +1,560 @@
+// C-ABI host layer of libbuzzdetect_hip.so (include/buzzdetect_hip.h): weight folding, the
+// per-chunk launch plan, index arithmetic and per-stage event timing.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bd_internal.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define BD_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(BD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+// (stride, filters): embedders/yamnet/yamnet.py:77-93
+const int kLayerDefs[14][2] = {{2, 32},  {1, 64},  {2, 128}, {1, 128}, {2, 256}, {1, 256},  {2, 512},
+                               {1, 512}, {1, 512}, {1, 512}, {1, 512}, {1, 512}, {2, 1024}, {1, 1024}};
+
+constexpr int64_t kFloatsA = 98304;   // largest activation per window held in buffer A (layer 2 output 48x32x64)
+constexpr int64_t kFloatsB = 49152;   // largest per window in buffer B (layer-2 depthwise output 48x32x32)
+constexpr int kDefaultGroup = 1024;
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Event2 {
+    hipEvent_t a, b;
+    int slot;
+};
+
+}  // namespace
+
+struct bd_engine {
+    int device = 0;
+    int n_classes = 0;
+    int group_windows = kDefaultGroup;
+    float* d_pool = nullptr;          // one allocation for every folded tensor
+    bd::FeTables* d_tables = nullptr;
+    const float* conv1_w = nullptr;   // [9][32]
+    const float* conv1_b = nullptr;   // [32]
+    bd::SepLayer sep[13];
+    const float* head_wt = nullptr;   // [n_classes][1024]
+    const float* head_b = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<Event2> pending;
+    std::vector<Event2> free_events;
+    double ms[BD_PROFILE_SLOTS] = {0};
+    int64_t launches[BD_PROFILE_SLOTS] = {0};
+};
+
+namespace {
+
+// Time one launch with a pair of events on the caller's stream when profiling is on.
+struct Scope {
+    bd_engine* e;
+    hipStream_t s;
+    Event2 ev;
+    bool on;
+    Scope(bd_engine* e_, hipStream_t s_, int slot) : e(e_), s(s_), on(e_->profiling) {
+        if (!on) return;
+        if (!e->free_events.empty()) {
+            ev = e->free_events.back();
+            e->free_events.pop_back();
+        } else {
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+                on = false;
+                return;
+            }
+        }
+        ev.slot = slot;
+        (void)hipEventRecord(ev.a, s);
+    }
+    ~Scope() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, s);
+        e->pending.push_back(ev);
+    }
+};
+
+// ---- index arithmetic: embedders/yamnet/features.py:82-108, :42-46, :65-76 ----
+int64_t padded_length(int64_t n, int32_t hop) {
+    const int64_t min_samples = BD_MIN_SAMPLES;
+    int64_t pad = min_samples - n > 0 ? min_samples - n : 0;
+    const int64_t num = n > min_samples ? n : min_samples;
+    const int64_t after = num - min_samples;
+    // tf.cast(tf.math.ceil(tf.cast(after, f32) / tf.cast(hop, f32)), int32): float32 on purpose
+    const volatile float q = (float)after / (float)hop;
+    const int64_t hops = (int64_t)ceilf(q);
+    pad += (int64_t)hop * hops - after;
+    return n + pad;
+}
+
+struct Geometry {
+    int64_t n_padded, n_frames, n_windows;
+};
+
+int geometry(int64_t n, int32_t hop, int32_t step, Geometry* g) {
+    if (n < 0) return fail(BD_EINVAL, "n_samples must be >= 0");
+    if (hop <= 0) return fail(BD_EINVAL, "hop_samples must be > 0");
+    if (n >= (1LL << 24))
+        return fail(BD_ERANGE,
+                    "chunk of 2^24 samples or more: the float32 ceil in pad_waveform (features.py:100-102) is "
+                    "no longer exact; split the chunk");
+    g->n_padded = padded_length(n, hop);
+    if (g->n_padded < n) return fail(BD_ERANGE, "pad_waveform would need negative padding");
+    g->n_frames = g->n_padded >= BD_STFT_WINDOW ? 1 + (g->n_padded - BD_STFT_WINDOW) / BD_STFT_HOP : 0;
+    if (step > 0)
+        g->n_windows = g->n_frames >= BD_PATCH_FRAMES ? 1 + (g->n_frames - BD_PATCH_FRAMES) / step : 0;
+    else
+        g->n_windows = 0;
+    return BD_OK;
+}
+
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+// ---- weight preparation ----
+struct BnFold {
+    std::vector<double> scale, shift;
+};
+
+BnFold fold_bn(const float* beta, const float* mean, const float* var, int c) {
+    // keras BatchNormalization inference with scale=False: (x - mean) * rsqrt(var + eps) + beta
+    BnFold f;
+    f.scale.resize(c);
+    f.shift.resize(c);
+    for (int i = 0; i < c; ++i) {
+        const double s = 1.0 / std::sqrt((double)var[i] + 1e-4);
+        f.scale[i] = s;
+        f.shift[i] = (double)beta[i] - (double)mean[i] * s;
+    }
+    return f;
+}
+
+int build_tables(const float* mel, bd::FeTables* t) {
+    std::memset(t, 0, sizeof(*t));
+    // tf.signal.hann_window(400, periodic=True, dtype=float32): float32 arithmetic throughout
+    for (int k = 0; k < BD_STFT_WINDOW; ++k) {
+        const float arg = (float)(2.0 * M_PI) * (float)k / (float)BD_STFT_WINDOW;
+        t->hann[k] = 0.5f - 0.5f * (float)std::cos((double)arg);
+    }
+    for (int k = 0; k < 256; ++k) {
+        const double a = -2.0 * M_PI * k / 256.0;
+        t->tw256[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int k = 0; k <= BD_SPECTRUM_BINS; ++k) {
+        const double a = -2.0 * M_PI * k / 512.0;
+        t->tw512[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    int max_len = 1;
+    for (int m = 0; m < BD_MEL_BANDS; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < BD_SPECTRUM_BINS; ++k) {
+            const float w = mel[k * BD_MEL_BANDS + m];
+            if (!std::isfinite(w)) return fail(BD_EWEIGHTS, "mel matrix has a non-finite entry");
+            if (w != 0.0f) {
+                if (first < 0) first = k;
+                last = k;
+            }
+        }
+        if (first < 0) {
+            t->band_start[m] = 0;
+            t->band_len[m] = 0;
+            continue;
+        }
+        const int len = last - first + 1;
+        if (len > bd::kMelMaxLen)
+            return fail(BD_EWEIGHTS, "mel band spans more than 32 spectrum bins; not a triangular filterbank?");
+        t->band_start[m] = first;
+        t->band_len[m] = len;
+        if (len > max_len) max_len = len;
+        for (int j = 0; j < len; ++j) t->band_w[j][m] = mel[(first + j) * BD_MEL_BANDS + m];
+    }
+    t->max_len = max_len;
+    return BD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bd_abi_version(void) { return BD_ABI_VERSION; }
+
+const char* bd_last_error(void) { return g_error.c_str(); }
+
+int64_t bd_padded_length(int64_t n_samples, int32_t hop_samples) {
+    Geometry g;
+    const int rc = geometry(n_samples, hop_samples, 0, &g);
+    return rc < 0 ? rc : g.n_padded;
+}
+
+int64_t bd_num_frames(int64_t n_samples, int32_t hop_samples) {
+    Geometry g;
+    const int rc = geometry(n_samples, hop_samples, 0, &g);
+    return rc < 0 ? rc : g.n_frames;
+}
+
+int64_t bd_num_windows(int64_t n_samples, int32_t hop_samples, int32_t patch_step) {
+    if (patch_step <= 0) return fail(BD_EINVAL, "patch_step must be > 0");
+    Geometry g;
+    const int rc = geometry(n_samples, hop_samples, patch_step, &g);
+    return rc < 0 ? rc : g.n_windows;
+}
+
+int bd_stage_shape(int32_t stage, int32_t* h, int32_t* w, int32_t* c) {
+    if (stage < 0 || stage >= BD_NUM_STAGES || !h || !w || !c) return fail(BD_EINVAL, "bad stage");
+    int hh = 96, ww = 64, cc = 1;
+    // stage 0 = conv1; stage 2k-1 = depthwise of layer k+1, stage 2k = its pointwise
+    hh = 48, ww = 32, cc = 32;
+    for (int s = 1; s <= stage; ++s) {
+        const int layer = (s + 1) / 2;   // index into kLayerDefs (1..13)
+        if (s & 1) {                     // depthwise
+            if (kLayerDefs[layer][0] == 2) {
+                hh /= 2;
+                ww /= 2;
+            }
+        } else {
+            cc = kLayerDefs[layer][1];
+        }
+    }
+    *h = hh;
+    *w = ww;
+    *c = cc;
+    return BD_OK;
+}
+
+int bd_create(bd_handle* out, int device, const bd_weights* w) {
+    if (!out || !w) return fail(BD_EINVAL, "bd_create: null argument");
+    *out = nullptr;
+    if (!w->embedder_blob || !w->mel) return fail(BD_EINVAL, "bd_create: embedder_blob and mel are required");
+    if (w->embedder_floats != BD_EMBEDDER_BLOB_FLOATS)
+        return fail(BD_EWEIGHTS, "bd_create: embedder blob must hold exactly 3217344 floats "
+                                 "(payload of variables.data-00000-of-00001)");
+    if (w->n_classes < 0 || w->n_classes > BD_MAX_CLASSES) return fail(BD_EINVAL, "bd_create: n_classes out of range");
+    if (w->n_classes > 0 && (!w->head_kernel || !w->head_bias))
+        return fail(BD_EINVAL, "bd_create: head_kernel/head_bias missing");
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(BD_ENODEVICE, "bd_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= count) return fail(BD_ENODEVICE, "bd_create: device index out of range");
+    hipDeviceProp_t prop;
+    BD_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BD_ENODEVICE, std::string("bd_create: kernels are built for gfx950 only, device is ") +
+                                      prop.gcnArchName);
+    BD_HIP(hipSetDevice(device));
+
+    // ---- fold + lay out every tensor in one host staging buffer ----
+    std::vector<float> host;
+    host.reserve(BD_EMBEDDER_BLOB_FLOATS + 64 * 1024);
+    auto reserve = [&](size_t n) {
+        const size_t off = align_up((int64_t)host.size(), 64);
+        host.resize(off + n, 0.0f);
+        return off;
+    };
+    const float* p = w->embedder_blob;
+    size_t off_conv1_w, off_conv1_b;
+    size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13];
+    {
+        const int c = kLayerDefs[0][1];
+        const float* kern = p;   // [3][3][1][32]
+        const BnFold f = fold_bn(p + 9 * c, p + 10 * c, p + 11 * c, c);
+        p += 12 * c;
+        off_conv1_w = reserve(9 * c);
+        off_conv1_b = reserve(c);
+        for (int t = 0; t < 9; ++t)
+            for (int i = 0; i < c; ++i) host[off_conv1_w + t * c + i] = (float)((double)kern[t * c + i] * f.scale[i]);
+        for (int i = 0; i < c; ++i) host[off_conv1_b + i] = (float)f.shift[i];
+    }
+    int cin = kLayerDefs[0][1];
+    for (int l = 0; l < 13; ++l) {
+        const int cout = kLayerDefs[l + 1][1];
+        const float* dw = p;   // [3][3][cin][1]
+        const BnFold fd = fold_bn(p + 9 * cin, p + 10 * cin, p + 11 * cin, cin);
+        p += 12 * (size_t)cin;
+        const float* pw = p;   // [1][1][cin][cout]
+        p += (size_t)cin * cout;
+        const BnFold fp = fold_bn(p, p + cout, p + 2 * cout, cout);
+        p += 3 * (size_t)cout;
+        off_dw_w[l] = reserve(9 * (size_t)cin);
+        off_dw_b[l] = reserve(cin);
+        off_pw_w[l] = reserve((size_t)cin * cout);
+        off_pw_b[l] = reserve(cout);
+        for (int t = 0; t < 9; ++t)
+            for (int i = 0; i < cin; ++i)
+                host[off_dw_w[l] + (size_t)t * cin + i] = (float)((double)dw[(size_t)t * cin + i] * fd.scale[i]);
+        for (int i = 0; i < cin; ++i) host[off_dw_b[l] + i] = (float)fd.shift[i];
+        for (int n = 0; n < cout; ++n)
+            for (int k = 0; k < cin; ++k)
+                host[off_pw_w[l] + (size_t)n * cin + k] = (float)((double)pw[(size_t)k * cout + n] * fp.scale[n]);
+        for (int n = 0; n < cout; ++n) host[off_pw_b[l] + n] = (float)fp.shift[n];
+        cin = cout;
+    }
+    if (p - w->embedder_blob != BD_EMBEDDER_BLOB_FLOATS) return fail(BD_EWEIGHTS, "internal: blob walk mismatch");
+    size_t off_head_w = 0, off_head_b = 0;
+    if (w->n_classes > 0) {
+        off_head_w = reserve((size_t)w->n_classes * BD_EMBEDDING_SIZE);
+        off_head_b = reserve(BD_MAX_CLASSES);
+        for (int c = 0; c < w->n_classes; ++c)
+            for (int k = 0; k < BD_EMBEDDING_SIZE; ++k)
+                host[off_head_w + (size_t)c * BD_EMBEDDING_SIZE + k] = w->head_kernel[(size_t)k * w->n_classes + c];
+        for (int c = 0; c < w->n_classes; ++c) host[off_head_b + c] = w->head_bias[c];
+    }
+    for (float v : host)
+        if (!std::isfinite(v)) return fail(BD_EWEIGHTS, "bd_create: non-finite value after BatchNorm folding");
+
+    bd::FeTables tables;
+    int rc = build_tables(w->mel, &tables);
+    if (rc < 0) return rc;
+
+    bd_engine* e = new bd_engine();
+    e->device = device;
+    e->n_classes = w->n_classes;
+    hipError_t err = hipMalloc(&e->d_pool, host.size() * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&e->d_tables, sizeof(bd::FeTables));
+    if (err == hipSuccess) err = hipMemcpy(e->d_pool, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(e->d_tables, &tables, sizeof(tables), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        if (e->d_pool) (void)hipFree(e->d_pool);
+        if (e->d_tables) (void)hipFree(e->d_tables);
+        delete e;
+        return fail(BD_EHIP, std::string("bd_create: ") + hipGetErrorString(err));
+    }
+    e->conv1_w = e->d_pool + off_conv1_w;
+    e->conv1_b = e->d_pool + off_conv1_b;
+    int h = 48, wd = 32;
+    cin = kLayerDefs[0][1];
+    for (int l = 0; l < 13; ++l) {
+        bd::SepLayer& L = e->sep[l];
+        L.cin = cin;
+        L.cout = kLayerDefs[l + 1][1];
+        L.stride = kLayerDefs[l + 1][0];
+        L.h_in = h;
+        L.w_in = wd;
+        L.h_out = (h + L.stride - 1) / L.stride;
+        L.w_out = (wd + L.stride - 1) / L.stride;
+        L.dw_w = e->d_pool + off_dw_w[l];
+        L.dw_b = e->d_pool + off_dw_b[l];
+        L.pw_wt = e->d_pool + off_pw_w[l];
+        L.pw_b = e->d_pool + off_pw_b[l];
+        h = L.h_out;
+        wd = L.w_out;
+        cin = L.cout;
+    }
+    if (w->n_classes > 0) {
+        e->head_wt = e->d_pool + off_head_w;
+        e->head_b = e->d_pool + off_head_b;
+    }
+    *out = e;
+    return BD_OK;
+}
+
+int bd_destroy(bd_handle h) {
+    if (!h) return BD_OK;
+    (void)hipSetDevice(h->device);
+    for (auto& ev : h->pending) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    for (auto& ev : h->free_events) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    if (h->d_pool) (void)hipFree(h->d_pool);
+    if (h->d_tables) (void)hipFree(h->d_tables);
+    delete h;
+    return BD_OK;
+}
+
+int bd_set_group_windows(bd_handle h, int32_t windows) {
+    if (!h || windows < 0) return fail(BD_EINVAL, "bd_set_group_windows: bad argument");
+    h->group_windows = windows == 0 ? kDefaultGroup : windows;
+    return BD_OK;
+}
+
+int64_t bd_workspace_bytes(bd_handle h, int64_t n_samples, int32_t hop_samples, int32_t patch_step) {
+    if (!h) return fail(BD_EINVAL, "bd_workspace_bytes: null handle");
+    if (patch_step <= 0) return fail(BD_EINVAL, "patch_step must be > 0");
+    Geometry g;
+    const int rc = geometry(n_samples, hop_samples, patch_step, &g);
+    if (rc < 0) return rc;
+    const int64_t group = g.n_windows < h->group_windows ? g.n_windows : h->group_windows;
+    return align_up(g.n_frames * BD_MEL_BANDS * 4, 256) + align_up(group * kFloatsA * 4, 256) +
+           align_up(group * kFloatsB * 4, 256) + 256;
+}
+
+int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, float* logmel_dev,
+                void* stream) {
+    if (!h || !logmel_dev || (!pcm_dev && n_samples > 0)) return fail(BD_EINVAL, "bd_frontend: null argument");
+    if (misaligned(pcm_dev) || misaligned(logmel_dev)) return fail(BD_EINVAL, "bd_frontend: pointers need 16-byte alignment");
+    Geometry g;
+    const int rc = geometry(n_samples, hop_samples, 0, &g);
+    if (rc < 0) return rc;
+    BD_HIP(hipSetDevice(h->device));
+    {
+        Scope sc(h, (hipStream_t)stream, 0);
+        bd::launch_logmel(pcm_dev, n_samples, g.n_frames, logmel_dev, h->d_tables, (hipStream_t)stream);
+    }
+    BD_HIP(hipGetLastError());
+    return BD_OK;
+}
+
+int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t patch_step, float* patches_dev,
+               void* stream) {
+    if (!h || !logmel_dev || !patches_dev) return fail(BD_EINVAL, "bd_patches: null argument");
+    if (patch_step <= 0 || n_frames < 0) return fail(BD_EINVAL, "bd_patches: bad size");
+    if (misaligned(logmel_dev) || misaligned(patches_dev)) return fail(BD_EINVAL, "bd_patches: pointers need 16-byte alignment");
+    const int64_t w = n_frames >= BD_PATCH_FRAMES ? 1 + (n_frames - BD_PATCH_FRAMES) / patch_step : 0;
+    BD_HIP(hipSetDevice(h->device));
+    bd::launch_patches(logmel_dev, w, patch_step, patches_dev, (hipStream_t)stream);
+    BD_HIP(hipGetLastError());
+    return BD_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// The launch plan of one chunk.  stop_stage < 0: run everything; otherwise stop after that CNN
+// stage of the first group and copy it to tap_out.
+int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t step, void* ws, int64_t ws_bytes,
+              float* emb, float* logits, int stop_stage, int tap_windows, float* tap_out, hipStream_t stream) {
+    if (!e) return fail(BD_EINVAL, "null handle");
+    if (!pcm && n > 0) return fail(BD_EINVAL, "null pcm pointer");
+    if (step <= 0) return fail(BD_EINVAL, "patch_step must be > 0");
+    if (misaligned(pcm) || misaligned(ws) || misaligned(emb) || misaligned(logits) || misaligned(tap_out))
+        return fail(BD_EINVAL, "device pointers need 16-byte alignment");
+    if (logits && e->n_classes == 0) return fail(BD_EINVAL, "engine was created without a head");
+    Geometry g;
+    int rc = geometry(n, hop, step, &g);
+    if (rc < 0) return rc;
+    const int64_t need = bd_workspace_bytes(e, n, hop, step);
+    if (need < 0) return (int)need;
+    if (!ws || ws_bytes < need) return fail(BD_EWORKSPACE, "workspace smaller than bd_workspace_bytes()");
+    if (stop_stage >= 0 && (tap_windows <= 0 || tap_windows > g.n_windows || tap_windows > e->group_windows))
+        return fail(BD_EINVAL, "bd_stage_tap: windows must be in 1..min(n_windows, group)");
+    BD_HIP(hipSetDevice(e->device));
+
+    const int64_t group = g.n_windows < e->group_windows ? g.n_windows : e->group_windows;
+    char* base = static_cast<char*>(ws);
+    float* logmel = reinterpret_cast<float*>(base);
+    float* buf_a = reinterpret_cast<float*>(base + align_up(g.n_frames * BD_MEL_BANDS * 4, 256));
+    float* buf_b = reinterpret_cast<float*>(reinterpret_cast<char*>(buf_a) + align_up(group * kFloatsA * 4, 256));
+
+    {
+        Scope sc(e, stream, 0);
+        bd::launch_logmel(pcm, n, g.n_frames, logmel, e->d_tables, stream);
+    }
+    for (int64_t w0 = 0; w0 < g.n_windows; w0 += group) {
+        const int gw = stop_stage >= 0 ? tap_windows : (int)(g.n_windows - w0 < group ? g.n_windows - w0 : group);
+        const float* lm = logmel + w0 * step * BD_MEL_BANDS;
+        {
+            Scope sc(e, stream, 1);
+            bd::launch_conv1(lm, step, gw, e->conv1_w, e->conv1_b, buf_a, stream);
+        }
+        const float* last = buf_a;
+        int64_t last_floats = (int64_t)gw * 48 * 32 * 32;
+        bool stopped = stop_stage == 0;
+        for (int l = 0; l < 13 && !stopped; ++l) {
+            const bd::SepLayer& L = e->sep[l];
+            {
+                Scope sc(e, stream, 2 + 2 * l);
+                bd::launch_depthwise(buf_a, buf_b, gw, L, stream);
+            }
+            last = buf_b;
+            last_floats = (int64_t)gw * L.h_out * L.w_out * L.cin;
+            if (stop_stage == 2 * l + 1) {
+                stopped = true;
+                break;
+            }
+            {
+                Scope sc(e, stream, 3 + 2 * l);
+                bd::launch_pointwise(buf_b, buf_a, (int64_t)gw * L.h_out * L.w_out, L, stream);
+            }
+            last = buf_a;
+            last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
+            if (stop_stage == 2 * l + 2) stopped = true;
+        }
+        if (stop_stage >= 0) {
+            BD_HIP(hipMemcpyAsync(tap_out, last, last_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            break;
+        }
+        {
+            Scope sc(e, stream, 28);
+            bd::launch_pool_head(buf_a, gw, e->head_wt, e->head_b, e->n_classes,
+                                 emb ? emb + w0 * BD_EMBEDDING_SIZE : nullptr,
+                                 logits ? logits + w0 * e->n_classes : nullptr, stream);
+        }
+    }
+    BD_HIP(hipGetLastError());
+    return BD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bd_embed(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
+             void* workspace_dev, int64_t workspace_bytes, float* emb_dev, void* stream) {
+    if (!emb_dev) return fail(BD_EINVAL, "bd_embed: null output");
+    return run_chunk(h, pcm_dev, n_samples, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
+                     nullptr, -1, 0, nullptr, (hipStream_t)stream);
+}
+
+int bd_predict(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
+               void* workspace_dev, int64_t workspace_bytes, float* emb_dev, float* logits_dev, void* stream) {
+    if (!logits_dev) return fail(BD_EINVAL, "bd_predict: null output");
+    return run_chunk(h, pcm_dev, n_samples, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
+                     logits_dev, -1, 0, nullptr, (hipStream_t)stream);
+}
+
+int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
+                 void* workspace_dev, int64_t workspace_bytes, int32_t stage, int32_t windows, float* out_dev,
+                 void* stream) {
+    if (!out_dev) return fail(BD_EINVAL, "bd_stage_tap: null output");
+    if (stage < 0 || stage >= BD_NUM_STAGES) return fail(BD_EINVAL, "bd_stage_tap: stage out of range");
+    return run_chunk(h, pcm_dev, n_samples, hop_samples, patch_step, workspace_dev, workspace_bytes, nullptr,
+                     nullptr, stage, windows, out_dev, (hipStream_t)stream);
+}
+
+int bd_profile_enable(bd_handle h, int32_t on) {
+    if (!h) return fail(BD_EINVAL, "null handle");
+    h->profiling = on != 0;
+    return BD_OK;
+}
+
+int bd_profile_read(bd_handle h, double* ms, int64_t* launches, int32_t slots) {
+    if (!h || !ms || !launches || slots < BD_PROFILE_SLOTS) return fail(BD_EINVAL, "bd_profile_read: bad argument");
+    BD_HIP(hipSetDevice(h->device));
+    for (auto& ev : h->pending) {
+        BD_HIP(hipEventSynchronize(ev.b));
+        float t = 0.f;
+        BD_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
+        h->ms[ev.slot] += t;
+        h->launches[ev.slot] += 1;
+        h->free_events.push_back(ev);
+    }
+    h->pending.clear();
+    for (int i = 0; i < BD_PROFILE_SLOTS; ++i) {
+        ms[i] = h->ms[i];
+        launches[i] = h->launches[i];
+        h->ms[i] = 0;
+        h->launches[i] = 0;
+    }
+    return BD_PROFILE_SLOTS;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+// Front end of the analyze hot path on gfx950: PCM -> log-mel spectrogram, one kernel.
+//
+// Restates embedders/yamnet/features.py:22-58 (tf.signal.stft 400/160/512 -> tf.abs ->
+// matmul with the [257,64] mel matrix -> log(x + 0.001)) with pad_waveform (features.py:82-108)
+// folded in as "samples past n_valid read as zero".  Nothing of [T,400] / [T,257] is ever
+// written to HBM: a workgroup stages a run of PCM into LDS, each 64-lane wavefront owns one
+// STFT frame at a time and carries it through
+//   Hann window -> 256-point complex FFT of the even/odd-packed frame (radix-4 Stockham,
+//   4 passes through the wave's own LDS tile) -> real-FFT split -> |X[k]| -> banded mel
+//   reduction (lane m owns band m; every band is a short run of bins) -> logf
+// and writes one coalesced 256-byte row of the [T,64] output.
+//
+// Algorithmic HBM traffic: 640 B read (160 new samples) + 256 B written per frame.
+#include "bd_internal.h"
+
+namespace bd {
+
+namespace {
+
+constexpr int kWaves = 4;
+constexpr int kFramesPerWave = 4;
+constexpr int kGroupFrames = kWaves * kFramesPerWave;                         // 16 frames per pass
+constexpr int kGroupSamples = (kGroupFrames - 1) * BD_STFT_HOP + BD_STFT_WINDOW;  // 2800
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// forward DFT-4 of (u0..u3) -> (X0..X3) in place
+__device__ __forceinline__ void dft4(float2& u0, float2& u1, float2& u2, float2& u3) {
+    const float2 a = make_float2(u0.x + u2.x, u0.y + u2.y);
+    const float2 b = make_float2(u0.x - u2.x, u0.y - u2.y);
+    const float2 c = make_float2(u1.x + u3.x, u1.y + u3.y);
+    const float2 d = make_float2(u1.y - u3.y, -(u1.x - u3.x));   // -i * (u1 - u3)
+    u0 = make_float2(a.x + c.x, a.y + c.y);
+    u1 = make_float2(b.x + d.x, b.y + d.y);
+    u2 = make_float2(a.x - c.x, a.y - c.y);
+    u3 = make_float2(b.x - d.x, b.y - d.y);
+}
+
+__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ pcm, long long n_valid,
+                                                     long long n_frames, float* __restrict__ out,
+                                                     const FeTables* __restrict__ tab) {
+    __shared__ __attribute__((aligned(16))) float s_pcm[kGroupSamples];
+    __shared__ __attribute__((aligned(16))) float s_hann[BD_STFT_WINDOW];
+    __shared__ __attribute__((aligned(16))) float2 s_tw256[256];
+    __shared__ __attribute__((aligned(16))) float2 s_tw512[BD_SPECTRUM_BINS + 1];
+    __shared__ __attribute__((aligned(16))) float2 s_z[kWaves][256];
+    __shared__ __attribute__((aligned(16))) float s_mag[kWaves][BD_SPECTRUM_BINS + 7];
+    __shared__ __attribute__((aligned(16))) float s_bw[kMelMaxLen * BD_MEL_BANDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    for (int i = tid; i < BD_STFT_WINDOW; i += 256) s_hann[i] = tab->hann[i];
+    s_tw256[tid] = tab->tw256[tid];
+    for (int i = tid; i < BD_SPECTRUM_BINS + 1; i += 256) s_tw512[i] = tab->tw512[i];
+    const int max_len = tab->max_len;
+    for (int i = tid; i < max_len * BD_MEL_BANDS; i += 256) s_bw[i] = (&tab->band_w[0][0])[i];
+    const int band_start = tab->band_start[lane];
+    const int band_len = tab->band_len[lane];
+
+    float2* z = s_z[wave];
+    float* mag = s_mag[wave];
+
+    const long long n_groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
+    for (long long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        __syncthreads();   // tables visible / previous pass done with s_pcm
+        const long long base = group * (long long)(kGroupFrames * BD_STFT_HOP);
+        for (int i = tid; i < kGroupSamples; i += 256) {
+            const long long idx = base + i;
+            s_pcm[i] = idx < n_valid ? pcm[idx] : 0.0f;
+        }
+        __syncthreads();
+
+        for (int fi = 0; fi < kFramesPerWave; ++fi) {
+            const int fl = wave + kWaves * fi;
+            const long long frame = group * kGroupFrames + fl;
+            const float* x = s_pcm + fl * BD_STFT_HOP;
+
+            // ---- pass 1 (p = 1): windowed samples straight from the PCM tile, no twiddles ----
+            float2 u[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n2 = 2 * (lane + 64 * r);   // z[n] = x[2n] + i x[2n+1]; zero past 400
+                if (n2 < BD_STFT_WINDOW) {
+                    const float2 xv = *reinterpret_cast<const float2*>(x + n2);
+                    const float2 hv = *reinterpret_cast<const float2*>(s_hann + n2);
+                    u[r] = make_float2(xv.x * hv.x, xv.y * hv.y);
+                } else {
+                    u[r] = make_float2(0.0f, 0.0f);
+                }
+            }
+            dft4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[4 * lane + r] = u[r];
+            __syncthreads();
+
+            // ---- passes 2..4 (p = 4, 16, 64) ----
+#pragma unroll
+            for (int p = 4; p <= 64; p *= 4) {
+                const int k = lane & (p - 1);
+                const int tstep = k * (64 / p);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = z[lane + 64 * r];
+                u[1] = cmul(u[1], s_tw256[tstep & 255]);
+                u[2] = cmul(u[2], s_tw256[(2 * tstep) & 255]);
+                u[3] = cmul(u[3], s_tw256[(3 * tstep) & 255]);
+                dft4(u[0], u[1], u[2], u[3]);
+                const int j0 = ((lane - k) << 2) + k;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[j0 + p * r] = u[r];
+                __syncthreads();
+            }
+
+            // ---- split the packed transform into the real spectrum, take magnitudes ----
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = lane + 64 * r;
+                const float2 zk = z[k];
+                const float2 zm = z[(256 - k) & 255];
+                const float ex = 0.5f * (zk.x + zm.x);
+                const float ey = 0.5f * (zk.y - zm.y);
+                const float ox = 0.5f * (zk.y + zm.y);    // O = -i/2 * (Zk - conj(Zm))
+                const float oy = -0.5f * (zk.x - zm.x);
+                const float2 t = s_tw512[k];
+                const float xr = ex + (t.x * ox - t.y * oy);
+                const float xi = ey + (t.x * oy + t.y * ox);
+                mag[k] = sqrtf(xr * xr + xi * xi);
+            }
+            if (lane == 0) mag[256] = fabsf(z[0].x - z[0].y);
+            __syncthreads();
+
+            // ---- banded mel reduction + log ----
+            float acc = 0.0f;
+            for (int j = 0; j < max_len; ++j) {
+                if (j < band_len) acc = fmaf(mag[band_start + j], s_bw[j * BD_MEL_BANDS + lane], acc);
+            }
+            if (frame < n_frames) out[frame * BD_MEL_BANDS + lane] = logf(acc + 0.001f);
+            // the next frame's first write to z / mag happens after its own first barrier
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ logmel, long long n_windows,
+                                                      int patch_step, float* __restrict__ patches) {
+    // tf.signal.frame(axis=0) (features.py:72-76): patch w = frames [w*step, w*step + 96)
+    const long long per = BD_PATCH_FRAMES * BD_MEL_BANDS / 4;   // float4 per patch
+    const long long total = n_windows * per;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+        const long long w = i / per;
+        const long long r = i - w * per;
+        const float4 v = reinterpret_cast<const float4*>(logmel + w * patch_step * BD_MEL_BANDS)[r];
+        reinterpret_cast<float4*>(patches)[i] = v;
+    }
+}
+
+}  // namespace
+
+void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
+                   const FeTables* tables, hipStream_t stream) {
+    if (n_frames <= 0) return;
+    const int64_t groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
+    const int grid = (int)(groups < 4096 ? groups : 4096);
+    hipLaunchKernelGGL(logmel_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
+                       (long long)n_frames, logmel, tables);
+}
+
+void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
+                    hipStream_t stream) {
+    if (n_windows <= 0) return;
+    const int64_t total = n_windows * (BD_PATCH_FRAMES * BD_MEL_BANDS / 4);
+    const int64_t blocks = (total + 255) / 256;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(patches_kernel, dim3(grid), dim3(256), 0, stream, logmel, (long long)n_windows,
+                       patch_step, patches);
+}
+
+}  // namespace bd

@@ -1,0 +1,229 @@
+"""Host side of the MI355X analyze hot path: owns the C-ABI handle, the device workspace and
+the hop arithmetic; PyTorch is used only for device memory and streams.
+
+Replaces, behind the reference's plugin surface (see ``buzzdetect_amd/dropin``):
+``YamnetK2.embed`` (embedders/yamnet_k2/embedder.py:27-37), ``EmbedderYamnet.embed``
+(embedders/yamnet/embedder.py:33-44) and ``ModelGeneralV3.predict``
+(models/model_general_v3/model.py:18-31).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+SAMPLE_RATE = 16000
+STFT_HOP = 160
+
+
+def hop_samples(framehop_s: float) -> int:
+    """``tf.cast(patch_hop_seconds * sample_rate, tf.int32)`` (features.py:99): truncation."""
+    return int(framehop_s * 16000.0)
+
+
+def patch_step(framehop_s: float) -> int:
+    """``int(round(spectrogram_sample_rate * patch_hop_seconds))`` (features.py:66-71)."""
+    spectrogram_sample_rate = 16000.0 / STFT_HOP
+    return int(round(spectrogram_sample_rate * framehop_s))
+
+
+class DeviceResult:
+    """What ``predict``/``embed`` hand back: a device tensor that also answers ``.numpy()``,
+    the one method the reference's writer calls on results (src/write/worker.py:69)."""
+
+    def __init__(self, tensor: torch.Tensor, stream: torch.cuda.Stream):
+        self.tensor = tensor
+        self._stream = stream
+        self._host: Optional[np.ndarray] = None
+
+    @property
+    def shape(self) -> Tuple[int, ...]:
+        return tuple(self.tensor.shape)
+
+    def numpy(self) -> np.ndarray:
+        if self._host is None:
+            self._stream.synchronize()
+            self._host = self.tensor.cpu().numpy()
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __len__(self) -> int:
+        return self.tensor.shape[0]
+
+
+class HipEngine:
+    """One engine per GPU / per analyzer thread (src/inference/worker.py:21,78)."""
+
+    def __init__(self, embeddername: str = "yamnet_k2", modelname: Optional[str] = "model_general_v3",
+                 device: Optional[int] = None, embedder_variables: Optional[str] = None,
+                 embedder_blob: Optional[np.ndarray] = None):
+        self._handle = C.c_void_p()
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("buzzdetect_amd: no HIP device visible to PyTorch; this engine has no CPU path")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+
+        blob = weights.load_embedder_blob(embedder_variables) if embedder_blob is None else embedder_blob
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        mel = np.ascontiguousarray(weights.load_mel(embeddername), dtype=np.float32)
+        w = _lib.bd_weights()
+        w.embedder_blob = blob.ctypes.data_as(C.POINTER(C.c_float))
+        w.embedder_floats = blob.size
+        w.mel = mel.ctypes.data_as(C.POINTER(C.c_float))
+        self.classes = None
+        self.n_classes = 0
+        if modelname is not None:
+            head = weights.load_head(modelname)
+            hk = np.ascontiguousarray(head.kernel, dtype=np.float32)
+            hb = np.ascontiguousarray(head.bias, dtype=np.float32)
+            w.head_kernel = hk.ctypes.data_as(C.POINTER(C.c_float))
+            w.head_bias = hb.ctypes.data_as(C.POINTER(C.c_float))
+            w.n_classes = hb.size
+            self.classes = head.classes
+            self.n_classes = int(hb.size)
+        _lib.check(self._lib.bd_create(C.byref(self._handle), self.device_index, C.byref(w)))
+        self._workspace: Optional[torch.Tensor] = None
+        self._pinned: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.bd_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def set_group_windows(self, windows: int) -> None:
+        _lib.check(self._lib.bd_set_group_windows(self._handle, int(windows)))
+
+    def num_windows(self, n_samples: int, hop: int, step: int) -> int:
+        return _lib.check(self._lib.bd_num_windows(int(n_samples), int(hop), int(step)))
+
+    def num_frames(self, n_samples: int, hop: int) -> int:
+        return _lib.check(self._lib.bd_num_frames(int(n_samples), int(hop)))
+
+    def _stream(self) -> torch.cuda.Stream:
+        return torch.cuda.current_stream(self.device)
+
+    def _ws(self, nbytes: int) -> torch.Tensor:
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = None
+            self._workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def to_device(self, samples) -> torch.Tensor:
+        """1-D float32 chunk (numpy / torch CPU / torch device) -> contiguous device tensor."""
+        if isinstance(samples, DeviceResult):
+            samples = samples.tensor
+        if isinstance(samples, torch.Tensor):
+            t = samples
+            if t.dim() != 1:
+                raise ValueError("audio samples must be one-dimensional")
+            if t.dtype != torch.float32:
+                t = t.to(torch.float32)
+            if t.device != self.device:
+                t = t.to(self.device, non_blocking=True)
+            t = t.contiguous()
+        else:
+            a = np.asarray(samples)
+            if a.ndim != 1:
+                raise ValueError("audio samples must be one-dimensional")
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            n = a.size
+            if self._pinned is None or self._pinned.numel() < n:
+                self._pinned = torch.empty(max(n, 1), dtype=torch.float32).pin_memory()
+            self._pinned[:n].copy_(torch.from_numpy(a))
+            t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)[:n]
+            t.copy_(self._pinned[:n], non_blocking=True)
+        if t.data_ptr() % 16:
+            t = t.clone()
+        return t
+
+    # ------------------------------------------------------------------ hot path
+    def frontend(self, samples, hop: int) -> torch.Tensor:
+        """[N] PCM -> [T,64] log-mel (features.py:22-58 + pad_waveform :82-108)."""
+        x = self.to_device(samples)
+        t = self.num_frames(x.numel(), hop)
+        out = torch.empty((t, _lib.MEL_BANDS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_frontend(self._handle, x.data_ptr(), x.numel(), hop, out.data_ptr(),
+                                             self._stream().cuda_stream))
+        return out
+
+    def patches(self, logmel: torch.Tensor, step: int) -> torch.Tensor:
+        """[T,64] -> [W,96,64] (features.py:65-79)."""
+        t = logmel.shape[0]
+        w = 1 + (t - _lib.PATCH_FRAMES) // step if t >= _lib.PATCH_FRAMES else 0
+        out = torch.empty((w, _lib.PATCH_FRAMES, _lib.MEL_BANDS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_patches(self._handle, logmel.data_ptr(), t, step, out.data_ptr(),
+                                            self._stream().cuda_stream))
+        return out
+
+    def run(self, samples, hop: int, step: int, want_embeddings: bool, want_logits: bool):
+        x = self.to_device(samples)
+        n = x.numel()
+        w = self.num_windows(n, hop, step)
+        ws_bytes = _lib.check(self._lib.bd_workspace_bytes(self._handle, n, hop, step))
+        ws = self._ws(ws_bytes)
+        emb = torch.empty((w, _lib.EMBEDDING_SIZE), dtype=torch.float32, device=self.device) if want_embeddings else None
+        logits = None
+        stream = self._stream()
+        with torch.cuda.device(self.device):
+            if want_logits:
+                if self.n_classes == 0:
+                    raise RuntimeError("engine was created without a classifier head")
+                logits = torch.empty((w, self.n_classes), dtype=torch.float32, device=self.device)
+                _lib.check(self._lib.bd_predict(self._handle, x.data_ptr(), n, hop, step, ws.data_ptr(), ws.numel(),
+                                                emb.data_ptr() if emb is not None else None, logits.data_ptr(),
+                                                stream.cuda_stream))
+            else:
+                _lib.check(self._lib.bd_embed(self._handle, x.data_ptr(), n, hop, step, ws.data_ptr(), ws.numel(),
+                                              emb.data_ptr(), stream.cuda_stream))
+        x.record_stream(stream)
+        return emb, logits
+
+    def embed(self, samples, framehop_s: float) -> DeviceResult:
+        emb, _ = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), True, False)
+        return DeviceResult(emb, self._stream())
+
+    def predict(self, samples, framehop_s: float) -> DeviceResult:
+        _, logits = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), False, True)
+        return DeviceResult(logits, self._stream())
+
+    def stage_tap(self, samples, hop: int, step: int, stage: int, windows: int) -> torch.Tensor:
+        """Test hook: NHWC activation after CNN stage ``stage`` for the first ``windows`` windows."""
+        x = self.to_device(samples)
+        h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self._lib.bd_stage_shape(stage, C.byref(h), C.byref(w), C.byref(c)))
+        out = torch.empty((windows, h.value, w.value, c.value), dtype=torch.float32, device=self.device)
+        ws_bytes = _lib.check(self._lib.bd_workspace_bytes(self._handle, x.numel(), hop, step))
+        ws = self._ws(ws_bytes)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_stage_tap(self._handle, x.data_ptr(), x.numel(), hop, step, ws.data_ptr(),
+                                              ws.numel(), stage, windows, out.data_ptr(),
+                                              self._stream().cuda_stream))
+        return out
+
+    # ------------------------------------------------------------------ timing
+    def profile_enable(self, on: bool) -> None:
+        _lib.check(self._lib.bd_profile_enable(self._handle, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * _lib.PROFILE_SLOTS)()
+        cnt = (C.c_int64 * _lib.PROFILE_SLOTS)()
+        _lib.check(self._lib.bd_profile_read(self._handle, ms, cnt, _lib.PROFILE_SLOTS))
+        return np.array(ms[:], dtype=np.float64), np.array(cnt[:], dtype=np.int64)

@@ -1,0 +1,146 @@
+/*
+ * buzzdetect_hip.h — C ABI of the MI355X (gfx950) engine for buzzdetect's analyze hot path.
+ *
+ * The reference (OSU-Bee-Lab/buzzdetect) is pure Python on TensorFlow; it has no FFI of its
+ * own.  These entry points are what a binding for the hot path would call, one per reference
+ * call site (paths relative to the reference checkout):
+ *
+ *   bd_create / bd_destroy   <- YamnetK2.initialize          embedders/yamnet_k2/embedder.py:14-24
+ *                               EmbedderYamnet.initialize    embedders/yamnet/embedder.py:25-31
+ *                               ModelGeneralV3.initialize    models/model_general_v3/model.py:11-16
+ *   bd_padded_length         <- pad_waveform                 embedders/yamnet/features.py:82-108
+ *   bd_num_frames            <- tf.signal.stft framing       embedders/yamnet/features.py:42-46
+ *   bd_num_windows           <- tf.signal.frame(axis=0)      embedders/yamnet/features.py:65-76
+ *   bd_frontend              <- waveform_to_log_mel_spectrogram_patches (log-mel output)
+ *                                                            embedders/yamnet/features.py:22-58
+ *   bd_patches               <- ... (patch output)           embedders/yamnet/features.py:65-79
+ *   bd_embed                 <- YamnetK2.embed / EmbedderYamnet.embed
+ *                                                            embedders/yamnet_k2/embedder.py:27-37
+ *                                                            embedders/yamnet/embedder.py:33-44
+ *   bd_predict               <- ModelGeneralV3.predict       models/model_general_v3/model.py:18-31
+ *   bd_stage_tap             <- (test hook) any intermediate activation of yamnet()
+ *                                                            embedders/yamnet/yamnet.py:96-103
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative BD_E* code; bd_last_error() gives the
+ *     text for the calling thread.  The count helpers return the count, or a negative code.
+ *   - The caller owns every device buffer (PyTorch allocates them); the library allocates only
+ *     the folded weights/tables at bd_create.  No hidden synchronisation: work is enqueued on
+ *     the stream passed in (a hipStream_t cast to void*; NULL = the legacy default stream).
+ *   - One handle per host thread / per GPU (the reference builds one model per analyzer
+ *     thread, src/inference/worker.py:21,78).  A handle is not thread-safe.
+ *   - All device buffers are float32, dense, row-major.  Pointers need 16-byte alignment.
+ *   - There is no CPU fallback: without a usable HIP device bd_create fails.
+ */
+#ifndef BUZZDETECT_HIP_H
+#define BUZZDETECT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define BD_API __attribute__((visibility("default")))
+#else
+#define BD_API
+#endif
+
+/* sizes fixed by the reference architecture (embedders/yamnet/params.py, yamnet.py:77-93) */
+#define BD_SAMPLE_RATE        16000
+#define BD_MIN_SAMPLES        15600      /* int((0.96 + 0.025 - 0.010) * 16000) */
+#define BD_STFT_WINDOW        400
+#define BD_STFT_HOP           160
+#define BD_FFT_LENGTH         512
+#define BD_SPECTRUM_BINS      257
+#define BD_MEL_BANDS          64
+#define BD_PATCH_FRAMES       96
+#define BD_EMBEDDING_SIZE     1024
+#define BD_EMBEDDER_BLOB_FLOATS 3217344  /* payload of variables.data-00000-of-00001 / 4 */
+#define BD_MAX_CLASSES        64
+#define BD_NUM_STAGES         27         /* conv1, then (depthwise, pointwise) x 13 */
+
+#define BD_OK                 0
+#define BD_EINVAL            (-1)        /* bad argument (null, negative, misaligned, hop <= 0 ...) */
+#define BD_ENODEVICE         (-2)        /* no usable HIP device / wrong architecture */
+#define BD_EHIP              (-3)        /* a HIP runtime call failed */
+#define BD_EWORKSPACE        (-4)        /* workspace too small for this call */
+#define BD_ERANGE            (-5)        /* chunk too long: float32 ceil of pad_waveform is not exact (n >= 2^24) */
+#define BD_EWEIGHTS          (-6)        /* weight blob / mel matrix not in the expected form */
+
+typedef struct bd_engine* bd_handle;
+
+/* Host-side weights, all in the reference's own layouts. */
+typedef struct bd_weights {
+    const float* embedder_blob;   /* BD_EMBEDDER_BLOB_FLOATS f32: the TensorBundle payload, unchanged
+                                     (conv1 kernel [3,3,1,32], BN beta/mean/var, then per separable
+                                     layer: depthwise [3,3,C,1], BN x3, pointwise [1,1,Cin,Cout], BN x3) */
+    int64_t      embedder_floats; /* must equal BD_EMBEDDER_BLOB_FLOATS */
+    const float* mel;             /* [257][64] linear-to-mel matrix as baked into the SavedModel graph */
+    const float* head_kernel;     /* [1024][n_classes] Dense kernel (Keras layout), or NULL: embed only */
+    const float* head_bias;       /* [n_classes] */
+    int32_t      n_classes;       /* 0..BD_MAX_CLASSES */
+} bd_weights;
+
+BD_API int bd_abi_version(void);
+BD_API const char* bd_last_error(void);
+
+BD_API int bd_create(bd_handle* out, int device, const bd_weights* weights);
+BD_API int bd_destroy(bd_handle h);
+
+/* windows processed per pass through the CNN (activations of one pass stay cache-resident);
+   0 restores the default. */
+BD_API int bd_set_group_windows(bd_handle h, int32_t windows);
+
+/* ---- index arithmetic (host only; bit-exact restatement incl. the float32 ceil) ---- */
+BD_API int64_t bd_padded_length(int64_t n_samples, int32_t hop_samples);
+BD_API int64_t bd_num_frames(int64_t n_samples, int32_t hop_samples);
+BD_API int64_t bd_num_windows(int64_t n_samples, int32_t hop_samples, int32_t patch_step);
+
+/* bytes of scratch bd_embed / bd_predict / bd_stage_tap need for such a chunk */
+BD_API int64_t bd_workspace_bytes(bd_handle h, int64_t n_samples, int32_t hop_samples, int32_t patch_step);
+
+/* ---- device entry points ---- */
+
+/* pcm_dev[n_samples] -> logmel_dev[bd_num_frames][64]; samples past n_samples read as zero. */
+BD_API int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples,
+                float* logmel_dev, void* stream);
+
+/* logmel_dev[n_frames][64] -> patches_dev[W][96][64], W = 1 + (n_frames - 96) / patch_step. */
+BD_API int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t patch_step,
+               float* patches_dev, void* stream);
+
+/* pcm_dev[n_samples] -> emb_dev[W][1024] */
+BD_API int bd_embed(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples,
+             int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
+             float* emb_dev, void* stream);
+
+/* pcm_dev[n_samples] -> logits_dev[W][n_classes]; emb_dev may be NULL. */
+BD_API int bd_predict(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples,
+               int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
+               float* emb_dev, float* logits_dev, void* stream);
+
+/* Test hook: run the path up to CNN stage `stage` (0 = conv1 output, 2k-1 / 2k = depthwise /
+   pointwise output of layer k+1) for the first `windows` windows and copy that NHWC activation
+   to out_dev ([windows][H][W][C] floats; bd_stage_shape gives H, W, C). */
+BD_API int bd_stage_shape(int32_t stage, int32_t* h, int32_t* w, int32_t* c);
+BD_API int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples,
+                 int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
+                 int32_t stage, int32_t windows, float* out_dev, void* stream);
+
+/* ---- per-stage timing (HIP events on the caller's stream) ----
+   With profiling on, every kernel launch of bd_predict/bd_embed is bracketed by events.
+   bd_profile_read synchronises on them and accumulates per slot: 0 = front end, 1 = conv1,
+   2..27 = stages 1..26 (depthwise/pointwise alternating), 28 = pool+head.
+   ms[i] += elapsed, launches[i] += count; returns the number of slots (29). */
+#define BD_PROFILE_SLOTS 29
+BD_API int bd_profile_enable(bd_handle h, int32_t on);
+BD_API int bd_profile_read(bd_handle h, double* ms, int64_t* launches, int32_t slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUZZDETECT_HIP_H */
