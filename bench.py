@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Throughput of the analyze hot path on MI355X (BASELINE.json metric: YAMNet windows/s).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the whole hot path (PCM -> log-mel -> YAMNet -> dense head) over one batch
+of synthetic 16 kHz mono audio already resident in HBM: BASELINE config 2's batch of 1024 windows
+(983.04 s = 15 728 640 samples, yamnet_k2 embedder at hop 1.0, model_general_v3 head).  With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank runs its own batch per step — the
+round-robin file sharding of config 4 — and the per-window logits are gathered to rank 0 over RCCL
+inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from buzzdetect_amd import sharding  # noqa: E402
+from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step  # noqa: E402
+
+SAMPLE_RATE = 16000
+WINDOWS_PER_BATCH = 1024
+HOP_PROP = 1.0
+FRAMELENGTH_S = 0.96
+
+# SURVEY §8d / DESIGN.md: algorithmic work per window at hop 1.0
+POINTWISE_FLOP_PER_WINDOW = 132_120_576          # 2 * 66 060 288 MAC in the thirteen 1x1 convolutions
+CNN_FLOP_PER_WINDOW = 137_289_728
+FRONTEND_BYTES_PER_WINDOW = 61_440 + 24_576      # f32 PCM in + f32 log-mel out
+PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
+
+# per-window HBM bytes each depthwise / conv1 launch must move (read input + write output, f32 NHWC)
+_DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1, 512), (1, 512),
+        (1, 512), (1, 512), (2, 1024), (1, 1024))
+
+
+def stage_table():
+    """(kind, per-window algorithmic bytes, per-window flops) for profile slots 0..28."""
+    rows = [("frontend", FRONTEND_BYTES_PER_WINDOW, 0)]
+    h, w, c = 48, 32, 32
+    rows.append(("conv1", 96 * 64 * 4 + h * w * c * 4, 2 * 9 * h * w * c))
+    for stride, cout in _DEF[1:]:
+        ho, wo = h // stride, w // stride
+        rows.append(("depthwise", (h * w * c + ho * wo * c) * 4, 2 * 9 * ho * wo * c))
+        rows.append(("pointwise", (ho * wo * c + ho * wo * cout) * 4, 2 * ho * wo * c * cout))
+        h, w, c = ho, wo, cout
+    rows.append(("pool_head", (6 * 1024 + 13) * 4, 2 * 1024 * 13))
+    return rows
+
+
+def synthetic_batch(device, n_samples: int, seed: int) -> torch.Tensor:
+    """0.1*N(0,1) noise + 0.3*sin(2*pi*220 t) bursts of 0.5 s every 5 s, clipped to [-1,1)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    x = 0.1 * torch.randn(n_samples, generator=gen, device=device, dtype=torch.float32)
+    t = torch.arange(n_samples, device=device, dtype=torch.float32) / SAMPLE_RATE
+    burst = (torch.remainder(t, 5.0) < 0.5).to(torch.float32)
+    x += 0.3 * torch.sin(2 * np.pi * 220.0 * t) * burst
+    return x.clamp_(-1.0, 1.0 - 2.0 ** -23)
+
+
+def cpu_baseline(engine: HipEngine, hop: int, step: int, windows: int):
+    """The oracle timed on this box's host cores (checker + reported baseline, never the product)."""
+    from buzzdetect_amd import weights as W
+    from oracle import yamnet_oracle as O
+    from oracle.torch_baseline import TorchYamnet, time_cpu_baseline
+    head = W.load_head()
+    model = TorchYamnet(W.synthetic_embedder_blob(), W.load_mel("yamnet_k2"), head.kernel, head.bias)
+    wave = O.synthetic_audio(hop * windows, seed=4321)
+    res = time_cpu_baseline(model, wave, hop, step, repeats=3)
+    cpu_logits = model.predict(wave, hop, step)
+    gpu_logits = engine.predict(wave, FRAMELENGTH_S * HOP_PROP).numpy()
+    ref64 = O.predict(wave[: hop * 8], W.synthetic_embedder_blob(), W.load_mel("yamnet_k2"), head.kernel,
+                      head.bias, hop, step, np.float64)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": round(res["windows_per_s"], 2), "unit": "windows/s", "cores": res["threads"], "kind": "port",
+        "implementation": "CPU restatement (torch-CPU fp32), not TensorFlow",
+        "sample": f"{res['windows']} windows ({res['windows'] * 0.96:.2f} s of audio), 1 warm-up + median of 3",
+        "seconds_per_pass": round(res["seconds"], 4), "cpu_model": cpu_model,
+        "max_abs_dlogit_gpu_vs_cpu_f32": float(np.abs(gpu_logits - cpu_logits).max()),
+        "max_abs_dlogit_gpu_vs_cpu_f64_first8": float(np.abs(gpu_logits[:8] - ref64[:8]).max()),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cpu-windows", type=int, default=256, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X; there is no CPU path for the product")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    engine = HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=local_rank)
+    if args.group_windows:
+        engine.set_group_windows(args.group_windows)
+    framehop_s = FRAMELENGTH_S * HOP_PROP
+    hop, step = hop_samples(framehop_s), patch_step(framehop_s)
+    n_samples = hop * WINDOWS_PER_BATCH                      # 15 728 640
+    assert engine.num_windows(n_samples, hop, step) == WINDOWS_PER_BATCH
+
+    # a few distinct batches so that a step never re-reads the PCM it has just processed
+    batches = [synthetic_batch(device, n_samples, 1234 + rank * 16 + i) for i in range(4)]
+    torch.cuda.synchronize()
+
+    def one_step(i: int):
+        res = engine.predict(batches[i % len(batches)], framehop_s)
+        gathered = sharding.gather_rows(res.tensor, dst=0) if world > 1 else None
+        return res, gathered
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    engine.profile_read()                                    # drop anything recorded so far
+    events_on = not args.no_kernel_events
+    engine.profile_enable(events_on)
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last, gathered = one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    engine.profile_enable(False)
+    ms, launches = engine.profile_read()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    total_windows = WINDOWS_PER_BATCH * args.steps * world
+    value = total_windows / elapsed
+
+    if rank == 0:
+        out = {
+            "metric": "yamnet_windows_per_s", "value": round(value, 1), "unit": "windows/s",
+            "audio_seconds_per_s": round(value * framehop_s, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 2: 16 kHz mono, batches of 1024 windows (983.04 s), yamnet_k2 hop 1.0 "
+                                   "+ model_general_v3 head; embedder weights seeded synthetic in the reference "
+                                   "layout, head weights real",
+                       "windows_per_step_per_gpu": WINDOWS_PER_BATCH, "samples_per_step_per_gpu": n_samples,
+                       "hop_samples": hop, "patch_step": step, "sharding": "round-robin batches per rank, "
+                       "RCCL gather of [W,13] logits to rank 0 each step" if world > 1 else "single GPU",
+                       "kernel_events_in_timed_region": events_on},
+        }
+        if events_on and launches.sum() > 0:
+            table = stage_table()
+            kinds = {}
+            for slot, (kind, nbytes, flops) in enumerate(table):
+                k = kinds.setdefault(kind, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0})
+                k["ms"] += ms[slot]
+                k["launches"] += int(launches[slot])
+                k["bytes"] += nbytes * WINDOWS_PER_BATCH * args.steps
+                k["flops"] += flops * WINDOWS_PER_BATCH * args.steps
+            pw = kinds["pointwise"]
+            achieved = pw["flops"] / (pw["ms"] * 1e-3) / 1e12
+            out["roofline"] = {
+                "kernel": "pointwise_kernel (13 launches per step: the 1x1 convolutions of layers 2-14)",
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(1e3 * pw["ms"] / pw["launches"], 2), "launches": pw["launches"],
+                "flop_per_launch_avg": pw["flops"] // pw["launches"],
+                "share_of_step_time": round(pw["ms"] / ms.sum(), 4),
+            }
+            stages = {}
+            for kind, k in kinds.items():
+                if k["launches"] == 0:
+                    continue
+                sec = k["ms"] * 1e-3
+                stages[kind] = {"ms_per_step": round(k["ms"] / args.steps, 4),
+                                "GBps_algorithmic": round(k["bytes"] / sec / 1e9, 1),
+                                "frac_hbm_peak": round(k["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4),
+                                "TFLOPs": round(k["flops"] / sec / 1e12, 2)}
+            out["stages"] = stages
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(engine, hop, step, args.cpu_windows)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""The C-ABI library: builds, loads, exports every symbol include/buzzdetect_hip.h declares, and its
+host-only index arithmetic is bit-exact against the oracle (no device compute here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from buzzdetect_amd import _lib, build
+from oracle import yamnet_oracle as O
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "buzzdetect_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"^BD_API[^;(]*?\b(bd_[a-z_0-9]+)\s*\(", text, flags=re.M)))
+
+
+def test_header_and_binding_list_the_same_functions():
+    assert declared_symbols() == sorted(_lib.PROTOTYPES)
+    assert len(declared_symbols()) == 17
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = C.CDLL(_lib.library_path())
+    for name in declared_symbols():
+        assert hasattr(raw, name), f"{name} not exported"
+    assert lib.bd_abi_version() == 1
+
+
+def test_header_constants_match_binding():
+    text = open(HEADER).read()
+    consts = {k: int(v) for k, v in re.findall(r"#define\s+(BD_[A-Z_]+)\s+\(?(-?\d+)\)?", text)}
+    assert consts["BD_EMBEDDER_BLOB_FLOATS"] == _lib.EMBEDDER_BLOB_FLOATS == 3217344
+    assert consts["BD_NUM_STAGES"] == _lib.NUM_STAGES and consts["BD_PROFILE_SLOTS"] == _lib.PROFILE_SLOTS
+    assert consts["BD_MIN_SAMPLES"] == O.MIN_SAMPLES and consts["BD_PATCH_FRAMES"] == O.PATCH_FRAMES
+    for code, name in _lib.ERROR_NAMES.items():
+        assert consts[name] == code
+
+
+@pytest.mark.parametrize("hop,step", [(15360, 96), (7680, 48), (4608, 29), (16000, 100), (333, 2)])
+def test_index_arithmetic_bit_exact_vs_oracle(lib, hop, step):
+    rng = np.random.default_rng(hop)
+    ns = [0, 1, 399, 400, 15359, 15360, 15599, 15600, 15601, 23360, 3_194_880, 9_600_000, 15_728_640,
+          (1 << 24) - 1] + rng.integers(0, 1 << 24, 200).tolist()
+    for n in ns:
+        assert lib.bd_padded_length(n, hop) == O.padded_length(n, hop)
+        assert lib.bd_num_frames(n, hop) == O.num_frames(O.padded_length(n, hop))
+        assert lib.bd_num_windows(n, hop, step) == O.num_windows(n, hop, step)
+
+
+def test_index_arithmetic_errors(lib):
+    assert lib.bd_num_windows(-1, 15360, 96) == -1                 # BD_EINVAL
+    assert lib.bd_num_windows(100, 0, 96) == -1
+    assert lib.bd_num_windows(100, 15360, 0) == -1
+    assert lib.bd_num_windows(1 << 24, 15360, 96) == -5           # BD_ERANGE (hazard H2)
+    assert b"float32" in lib.bd_last_error()
+
+
+def test_stage_shapes(lib):
+    h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
+    expect = {0: (48, 32, 32), 1: (48, 32, 32), 2: (48, 32, 64), 3: (24, 16, 64), 4: (24, 16, 128),
+              12: (6, 4, 512), 23: (3, 2, 512), 24: (3, 2, 1024), 26: (3, 2, 1024)}
+    for s, shape in expect.items():
+        assert lib.bd_stage_shape(s, C.byref(h), C.byref(w), C.byref(c)) == 0
+        assert (h.value, w.value, c.value) == shape
+    assert lib.bd_stage_shape(27, C.byref(h), C.byref(w), C.byref(c)) == -1
+
+
+def test_create_rejects_bad_arguments_before_touching_a_device(lib):
+    handle = C.c_void_p()
+    w = _lib.bd_weights()
+    assert lib.bd_create(C.byref(handle), 0, C.byref(w)) == -1          # null blob
+    blob = np.zeros(10, np.float32)
+    mel = np.zeros(257 * 64, np.float32)
+    w.embedder_blob = blob.ctypes.data_as(C.POINTER(C.c_float))
+    w.embedder_floats = blob.size
+    w.mel = mel.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib.bd_create(C.byref(handle), 0, C.byref(w)) == -6          # BD_EWEIGHTS: wrong blob size
+    assert handle.value is None
+
+
+def test_create_without_device_is_enodevice(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from buzzdetect_amd import weights as W
+    blob = W.synthetic_embedder_blob()
+    mel = W.load_mel()
+    w = _lib.bd_weights()
+    w.embedder_blob = blob.ctypes.data_as(C.POINTER(C.c_float))
+    w.embedder_floats = blob.size
+    w.mel = mel.ctypes.data_as(C.POINTER(C.c_float))
+    handle = C.c_void_p()
+    assert lib.bd_create(C.byref(handle), 0, C.byref(w)) == -2          # BD_ENODEVICE, no CPU fallback
+    assert b"no CPU path" in lib.bd_last_error()

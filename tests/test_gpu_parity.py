@@ -1,0 +1,224 @@
+"""HIP path vs the CPU oracle, through the C-ABI (run on the GPU box: ``pytest -m gpu``).
+
+Tolerances (north_star: logits within 1e-4 of the CPU path, window indexing bit-exact):
+  * logits / embeddings / CNN activations: max |HIP - f64 oracle| <= 1e-4 (absolute; |logit| ~ 10)
+  * log-mel: <= 5e-5 absolute on noise-like audio; for pure tones an error model is used (see test)
+  * window / frame counts, row order, determinism, group invariance: exact
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import yamnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOGITS = 1e-4
+HOP, STEP = 15360, 96
+
+
+def oracle_logits(x, b, hop=HOP, step=STEP, dtype=np.float64):
+    return O.predict(x, b["blob"], b["mel"], b["head_kernel"], b["head_bias"], hop, step, dtype)
+
+
+# --------------------------------------------------------------------------- front end
+@pytest.mark.parametrize("n", [0, 1, 399, 400, 15360, 15600, 15601, 23360, 100_001])
+def test_frontend_shapes_and_values_ragged_lengths(engine, weights_bundle, n):
+    x = O.synthetic_audio(max(n, 1), seed=n)[:n]
+    ref = O.log_mel(O.pad_waveform(x, HOP), weights_bundle["mel"], np.float64)
+    got = engine.frontend(x if n else np.zeros(0, np.float32), HOP).cpu().numpy()
+    assert got.shape == ref.shape == (O.num_frames(O.padded_length(n, HOP)), 64)
+    assert np.abs(got - ref).max() < 5e-5
+
+
+def test_frontend_silence_is_the_log_floor(engine):
+    # log(0 + 0.001): one constant everywhere, within float32 libm accuracy (1-2 ulp) of ln(0.001f)
+    got = engine.frontend(np.zeros(40000, np.float32), HOP).cpu().numpy()
+    assert np.all(got == got[0, 0])
+    assert abs(float(got[0, 0]) - np.log(np.float64(np.float32(0.001)))) < 1e-6
+
+
+def test_frontend_full_scale_sine(engine, weights_bundle):
+    # A pure tone leaves most bands ~60-100 dB below the peak; float32 FFT round-off (any float32
+    # FFT, TensorFlow's included) is relative to the PEAK magnitude, so the error budget per band is
+    # eps32 * c * peak / (mel + 0.001) after the log.  Checked in the mel domain instead.
+    t = np.arange(48000) / 16000.0
+    x = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    mel = weights_bundle["mel"]
+    ref = O.log_mel(O.pad_waveform(x, HOP), mel, np.float64)
+    got = engine.frontend(x, HOP).cpu().numpy().astype(np.float64)
+    peak = np.exp(ref).max()
+    err_mel = np.abs(np.exp(got) - np.exp(ref))
+    assert err_mel.max() < 64 * np.finfo(np.float32).eps * peak
+    loud = ref > np.log(peak) - np.log(1e3)          # bands within 60 dB of the peak
+    assert np.abs(got - ref)[loud].max() < 5e-5
+    f32 = O.log_mel(O.pad_waveform(x, HOP), mel, np.float32)
+    assert np.abs(got - ref).max() <= 4 * max(np.abs(f32 - ref).max(), 1e-5)   # no worse than a CPU f32 FFT
+
+
+def test_patches_are_views_of_logmel(engine, weights_bundle):
+    x = O.synthetic_audio(60000, seed=3)
+    lm = engine.frontend(x, 7680)
+    p = engine.patches(lm, 48).cpu().numpy()
+    assert np.array_equal(p, O.frame_patches(lm.cpu().numpy(), 48))
+    assert p.shape == (O.num_windows(60000, 7680), 96, 64)
+
+
+def test_frontend_matches_golden_rows(engine):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_oracle_f64.npz"))
+    x = O.synthetic_audio(int(g["n_samples"]), seed=int(g["seed"]))
+    assert hashlib.sha256(x.tobytes()).hexdigest() == str(g["audio_sha256"])
+    got = engine.frontend(x, HOP).cpu().numpy()
+    assert np.abs(got[g["logmel_row_index"]] - g["logmel_rows"]).max() < 5e-5
+
+
+# --------------------------------------------------------------------------- CNN stages
+def test_every_cnn_stage_against_oracle(engine, weights_bundle):
+    b = weights_bundle
+    x = O.synthetic_audio(HOP * 3 + 500, seed=11)
+    taps = []
+    lm = O.log_mel(O.pad_waveform(x, HOP), b["mel"], np.float64)
+    O.yamnet_body(O.frame_patches(lm, STEP), b["blob"], np.float64, taps)
+    assert len(taps) == 27
+    for stage, ref in enumerate(taps):
+        got = engine.stage_tap(x, HOP, STEP, stage, ref.shape[0]).cpu().numpy()
+        assert got.shape == ref.shape, stage
+        assert np.abs(got - ref).max() < TOL_LOGITS, f"stage {stage}"
+
+
+def test_pointwise_gemm_tile_edges(engine, weights_bundle):
+    # 1 window -> the GEMM M dimension (rows = positions) is not a multiple of the 128-row tile for the
+    # deep layers (24 and 6 rows): exercises the bounds checks on loads and stores.
+    b = weights_bundle
+    x = O.synthetic_audio(9000, seed=12)
+    taps = []
+    lm = O.log_mel(O.pad_waveform(x, HOP), b["mel"], np.float64)
+    O.yamnet_body(O.frame_patches(lm, STEP), b["blob"], np.float64, taps)
+    for stage in (12, 14, 24, 26):
+        got = engine.stage_tap(x, HOP, STEP, stage, 1).cpu().numpy()
+        assert np.abs(got - taps[stage]).max() < TOL_LOGITS
+
+
+# --------------------------------------------------------------------------- whole path
+def test_logits_match_golden_fixture(engine):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_oracle_f64.npz"))
+    x = O.synthetic_audio(int(g["n_samples"]), seed=int(g["seed"]))
+    emb, logits = engine.run(x, HOP, STEP, True, True)
+    assert np.abs(logits.cpu().numpy() - g["logits_whole"]).max() < TOL_LOGITS
+    assert np.abs(emb.cpu().numpy() - g["embeddings_whole"]).max() < TOL_LOGITS
+    _, half = engine.run(x, 7680, 48, False, True)
+    assert half.shape == g["logits_half"].shape
+    assert np.abs(half.cpu().numpy() - g["logits_half"]).max() < TOL_LOGITS
+
+
+@pytest.mark.parametrize("hop,step,n", [(15360, 96, 15360 * 20 + 17), (7680, 48, 15360 * 9), (4608, 29, 70000)])
+def test_logits_vs_oracle_various_hops(engine, weights_bundle, hop, step, n):
+    x = O.synthetic_audio(n, seed=hop)
+    ref = oracle_logits(x, weights_bundle, hop, step)
+    got = engine.run(x, hop, step, False, True)[1].cpu().numpy()
+    assert got.shape == ref.shape == (O.num_windows(n, hop, step), 13)
+    assert np.abs(got - ref).max() < TOL_LOGITS
+    f32 = oracle_logits(x, weights_bundle, hop, step, np.float32)
+    assert np.abs(f32 - ref).max() < TOL_LOGITS          # the CPU f32 path itself sits inside the gate
+
+
+@pytest.mark.parametrize("n", [0, 1, 15600, 15601])
+def test_edge_lengths_whole_path(engine, weights_bundle, n):
+    x = O.synthetic_audio(max(n, 1), seed=77)[:n]
+    ref = oracle_logits(x, weights_bundle)
+    got = engine.predict(x, 0.96).numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < TOL_LOGITS
+
+
+def test_silence_and_full_scale_inputs(engine, weights_bundle):
+    # Silence must meet the plain gate.  Full-scale DC / square waves put almost all energy where the
+    # mel matrix is zero: what is left in the bands is float32 FFT round-off sitting right at the
+    # 0.001 log offset, so ANY float32 implementation (the CPU f32 oracle included) moves by far more
+    # than 1e-4 there.  For those inputs HIP must be no worse than a small multiple of the CPU f32
+    # path's own distance from the f64 value.
+    for x in (np.zeros(50000, np.float32), np.full(50000, 1.0, np.float32),
+              np.sign(np.sin(np.arange(50000) * 0.05)).astype(np.float32)):
+        ref = oracle_logits(x, weights_bundle)
+        got = engine.predict(x, 0.96).numpy()
+        assert np.all(np.isfinite(got))
+        if not x.any():
+            assert np.abs(got - ref).max() < TOL_LOGITS
+        else:
+            cpu_f32 = np.abs(oracle_logits(x, weights_bundle, dtype=np.float32) - ref).max()
+            assert np.abs(got - ref).max() < max(TOL_LOGITS, 8 * cpu_f32)
+
+
+def test_chunk_edge_zero_padding_hazard_h1(engine, weights_bundle):
+    # the last window of a chunk sees 240 zeros, not the next chunk's audio (features.py:92-107)
+    x = O.synthetic_audio(HOP * 4, seed=31)
+    whole = engine.predict(x, 0.96).numpy()
+    first = engine.predict(x[: HOP * 2], 0.96).numpy()
+    assert whole.shape == (4, 13) and first.shape == (2, 13)
+    assert np.array_equal(whole[0], first[0])                    # interior window: identical bits
+    assert not np.array_equal(whole[1], first[1])                # edge window: depends on chunking
+    ref = oracle_logits(x[: HOP * 2], weights_bundle)
+    assert np.abs(first - ref).max() < TOL_LOGITS
+
+
+def test_too_long_chunk_is_refused(engine):
+    import torch
+    from buzzdetect_amd._lib import BuzzdetectHipError
+    x = torch.zeros(1 << 24, dtype=torch.float32, device=engine.device)
+    with pytest.raises(BuzzdetectHipError, match="BD_ERANGE"):
+        engine.predict(x, 0.96)
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_full_batch_1024_properties(engine, weights_bundle):
+    """BASELINE config 2 batch (1024 windows = 15 728 640 samples): properties that need no oracle run
+    at full size, plus oracle spot checks on a few windows."""
+    import torch
+    n = HOP * 1024
+    x = O.synthetic_audio(n, seed=2024)
+    xd = torch.from_numpy(x).to(engine.device)
+    a = engine.predict(xd, 0.96).numpy()
+    assert a.shape == (1024, 13) and np.all(np.isfinite(a))
+    # determinism
+    assert np.array_equal(a, engine.predict(xd, 0.96).numpy())
+    # invariance to the pass size (windows per CNN pass)
+    for group in (256, 100):
+        engine.set_group_windows(group)
+        assert np.array_equal(a, engine.predict(xd, 0.96).numpy()), group
+    engine.set_group_windows(0)
+    # window independence: row j depends only on samples [j*hop, j*hop + 15600)
+    for j in (0, 1, 511, 1022):
+        sub = engine.predict(xd[j * HOP: j * HOP + 15600 + HOP], 0.96).numpy()
+        assert np.array_equal(sub[0], a[j]), j
+    # time shift by one hop shifts rows by one
+    shifted = engine.predict(xd[HOP:], 0.96).numpy()
+    assert np.array_equal(shifted[:-1], a[1:-1])
+    # oracle spot checks (f64) on scattered windows, incl. the zero-padded last one
+    for j in (0, 700, 1023):
+        seg = x[j * HOP: j * HOP + 15600]
+        ref = oracle_logits(seg, weights_bundle)
+        assert np.abs(a[j] - ref[0]).max() < TOL_LOGITS, j
+
+
+def test_one_hour_file_in_batches_of_1024(engine, weights_bundle):
+    """Config 2 end to end: 57.6 M samples as 3 x 1024 + 678 windows; counts and row order exact."""
+    import torch
+    from buzzdetect_amd import framing
+    total = 57_600_000
+    chunk = framing.round_chunklength(983.04)
+    chunks = framing.gaps_to_chunklist([(0, total / 16000)], chunk)
+    assert [framing.chunk_sample_range(c, 16000) for c in chunks][0] == (0, 15_728_640)
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    audio = (0.1 * torch.randn(total, generator=gen)).clamp_(-1, 1)
+    rows = []
+    for c in chunks:
+        a, b = framing.chunk_sample_range(c, 16000)
+        rows.append(engine.predict(audio[a:b].to(engine.device), 0.96).numpy())
+    assert [r.shape[0] for r in rows] == [1024, 1024, 1024, 678]
+    assert sum(r.shape[0] for r in rows) == 3750
+    starts = np.concatenate([framing.window_starts(r.shape[0], c[0], 0.96) for r, c in zip(rows, chunks)])
+    assert np.all(np.diff(starts) > 0) and starts[-1] == 3599.04
+    seg = audio[15_728_640: 15_728_640 + 15600].numpy()
+    assert np.abs(rows[1][0] - oracle_logits(seg, weights_bundle)[0]).max() < TOL_LOGITS
