@@ -95,12 +95,26 @@ class TorchYamnet:
         return torch.cat(out, 0).numpy()
 
 
+def usable_cores(cap: int = 32) -> int:
+    """Cores this process may really use: affinity mask, cgroup CPU quota, and a cap (a GPU box
+    exposes all host cores to ``os.cpu_count()`` but grants only a share of them)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def time_cpu_baseline(model: TorchYamnet, wave: np.ndarray, hop: int, step: int, repeats: int = 3,
                       threads: int = None) -> Dict:
     """windows/s of the torch-CPU restatement on ``wave`` (1 warm-up + median of ``repeats``)."""
-    import os
     import time
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cores()
     torch.set_num_threads(threads)
     w = model.predict(wave, hop, step).shape[0]
     times = []
