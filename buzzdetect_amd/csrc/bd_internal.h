@@ -31,6 +31,7 @@ struct SepLayer {
     const float* dw_b;   // [cin]      beta - mean * scale
     const float* pw_wt;  // [cout][cin] pointwise kernel transposed * bn scale (K contiguous)
     const float* pw_b;   // [cout]
+    int pw_variant;      // tile choice for launch_pointwise (0 = by shape)
 };
 
 // ---- launchers (each enqueues exactly one kernel on `stream`) ----
@@ -42,6 +43,8 @@ void launch_conv1(const float* logmel, int patch_step, int windows, const float*
                   const float* b32, float* out, hipStream_t stream);
 void launch_depthwise(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream);
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream);
+int launch_pointwise_variant(const float* A, const float* Wt, const float* bias, float* C, long long M, int N,
+                             int K, int variant, hipStream_t stream);
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
                       int n_classes, float* emb, float* logits, hipStream_t stream);
 

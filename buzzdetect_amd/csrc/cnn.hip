@@ -67,42 +67,70 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ lo
 }
 
 // --------------------------------------------------------------------------- depthwise
+// One thread = OWB consecutive outputs of one row for one float4 of channels: the 3 x ((OWB-1)*S+3)
+// input patch is loaded once into registers and reused by the OWB outputs (4.5 instead of 9 loads per
+// output at stride 1), the 9 taps are loaded once per thread.  Channels are the fastest thread index,
+// so a wavefront reads/writes whole 128-byte-or-longer runs of the NHWC rows.
+// TF SAME: stride 1 pads 1 before; stride 2 on the even extents used here pads 0 before, 1 after.
+template <int STRIDE, int OWB>
 __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ w9xc,
                                                         const float* __restrict__ bias, int windows, int H,
-                                                        int W, int C, int OH, int OW, int stride, int pad) {
+                                                        int W, int C, int OH, int OW) {
+    constexpr int PAD = STRIDE == 1 ? 1 : 0;
+    constexpr int NCOL = (OWB - 1) * STRIDE + 3;
     const int c4n = C >> 2;
-    const long long total = (long long)windows * OH * OW * c4n;
+    const int owg = OW / OWB;
+    const long long total = (long long)windows * OH * owg * c4n;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
         const int c4 = (int)(i % c4n);
         long long t = i / c4n;
-        const int ow = (int)(t % OW);
-        t /= OW;
+        const int og = (int)(t % owg);
+        t /= owg;
         const int oh = (int)(t % OH);
         const long long n = t / OH;
-        const float* src = in + (size_t)n * H * W * C;
-        float4 acc = reinterpret_cast<const float4*>(bias)[c4];
+        const int ow0 = og * OWB;
+        const float4* src = reinterpret_cast<const float4*>(in + (size_t)n * H * W * C) + c4;
+        float4 wt[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[k] = reinterpret_cast<const float4*>(w9xc + k * C)[c4];
+        const float4 b = reinterpret_cast<const float4*>(bias)[c4];
+        float4 acc[OWB];
+#pragma unroll
+        for (int o = 0; o < OWB; ++o) acc[o] = b;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int ih = oh * stride + kh - pad;
-            if (ih < 0 || ih >= H) continue;
+            const int ih = oh * STRIDE + kh - PAD;
+            const bool row_ok = ih >= 0 && ih < H;
+            float4 col[NCOL];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int iw = ow * stride + kw - pad;
-                if (iw < 0 || iw >= W) continue;
-                const float4 v = reinterpret_cast<const float4*>(src + ((size_t)ih * W + iw) * C)[c4];
-                const float4 w = reinterpret_cast<const float4*>(w9xc + (kh * 3 + kw) * C)[c4];
-                acc.x = fmaf(v.x, w.x, acc.x);
-                acc.y = fmaf(v.y, w.y, acc.y);
-                acc.z = fmaf(v.z, w.z, acc.z);
-                acc.w = fmaf(v.w, w.w, acc.w);
+            for (int c = 0; c < NCOL; ++c) {
+                const int iw = ow0 * STRIDE + c - PAD;
+                col[c] = (row_ok && iw >= 0 && iw < W) ? src[((size_t)ih * W + iw) * c4n]
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+#pragma unroll
+            for (int o = 0; o < OWB; ++o)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 v = col[o * STRIDE + kw];
+                    const float4 w = wt[kh * 3 + kw];
+                    acc[o].x = fmaf(v.x, w.x, acc[o].x);
+                    acc[o].y = fmaf(v.y, w.y, acc[o].y);
+                    acc[o].z = fmaf(v.z, w.z, acc[o].z);
+                    acc[o].w = fmaf(v.w, w.w, acc[o].w);
+                }
         }
-        acc.x = fmaxf(acc.x, 0.0f);
-        acc.y = fmaxf(acc.y, 0.0f);
-        acc.z = fmaxf(acc.z, 0.0f);
-        acc.w = fmaxf(acc.w, 0.0f);
-        reinterpret_cast<float4*>(out)[i] = acc;
+        float4* dst = reinterpret_cast<float4*>(out + (((size_t)n * OH + oh) * OW + ow0) * C) + c4;
+#pragma unroll
+        for (int o = 0; o < OWB; ++o) {
+            float4 r = acc[o];
+            r.x = fmaxf(r.x, 0.0f);
+            r.y = fmaxf(r.y, 0.0f);
+            r.z = fmaxf(r.z, 0.0f);
+            r.w = fmaxf(r.w, 0.0f);
+            dst[(size_t)o * c4n] = r;
+        }
     }
 }
 
@@ -111,60 +139,56 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
 // [rows = windows*H*W][K = Cin]; Wt = folded kernel stored [Cout][Cin] so that both operands
 // have K contiguous and one ds_read_b128 feeds four MFMA k-steps.
 //
-// Workgroup = 4 waves (2 x 2) on a BM x BN tile, BK = 32 per LDS stage, register-staged
-// double buffering (global_load_dwordx4 of tile t+1 in flight while tile t is on the MFMAs).
+// Workgroup = WGM x WGN waves on a BM x BN tile, BK = 32 per LDS stage, register-staged double
+// buffering: the global_load_dwordx4 of stage t+1 are issued before the MFMAs of stage t and
+// written to the other LDS buffer after them, one barrier per stage.
 // v_mfma_f32_32x32x2_f32 operand map: lane l supplies A[i = l & 31][k = l >> 5] and
-// B[k = l >> 5][j = l & 31]; the k index of a step is arbitrary as long as both operands
-// agree, so lane-half h takes k = 8*s + 4*h + j for the j-th MFMA of super-step s.
+// B[k = l >> 5][j = l & 31]; which k a step covers is free as long as both operands agree, so
+// lane-half h takes k = 8*s + 4*h + j for the j-th MFMA of super-step s (one b128 per operand).
+// Rows past M are loaded from row M-1 (always in bounds) and never stored.
 constexpr int kBK = 32;
 constexpr int kLds = kBK + 4;   // row stride in floats: 144 B = odd multiple of 16 B -> conflict-free b128
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ A,
-                                                        const float* __restrict__ Wt,
-                                                        const float* __restrict__ bias,
-                                                        float* __restrict__ C, long long M, int N, int K) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* __restrict__ A,
+                                                                  const float* __restrict__ Wt,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ C, long long M, int N,
+                                                                  int K, int tiles_n) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int LA = BM / 32, LB = BN / 32;   // float4 global loads per thread per stage
-    __shared__ __attribute__((aligned(16))) float As[2][BM * kLds];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLds];
+    constexpr int RPP = NT / 8;                  // tile rows covered by one float4-per-thread pass
+    constexpr int LA = BM / RPP, LB = BN / RPP;  // float4 global loads per thread per stage
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                      // [2][BM * kLds]
+    float* const Bs = smem + 2 * BM * kLds;      // [2][BN * kLds]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int n_tiles = N / BN;
-    const long long tile_m = blockIdx.x / n_tiles;
-    const int tile_n = blockIdx.x % n_tiles;
+    const int wr = wave / WGN, wc = wave % WGN;
+    // consecutive workgroups walk the n-tiles of one m-tile: they share the A rows through L2
+    const long long tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x % tiles_n;
     const long long m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
-    const int lrow = tid >> 3;   // 0..31
+    const int lrow = tid >> 3;   // 0 .. RPP-1
     const int lc4 = tid & 7;     // float4 column within the 32-wide k slab
 
-    float4 ra[LA], rb[LB];
-    auto gload = [&](int k0) {
+    const float* ap[LA];
+    const float* bp[LB];
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const long long m = m0 + lrow + 32 * i;
-            ra[i] = m < M ? reinterpret_cast<const float4*>(A + (size_t)m * K + k0)[lc4]
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int i = 0; i < LA; ++i) {
+        long long m = m0 + lrow + RPP * i;
+        m = m < M ? m : M - 1;
+        ap[i] = A + (size_t)m * K + lc4 * 4;
+    }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int n = n0 + lrow + 32 * i;
-            rb[i] = reinterpret_cast<const float4*>(Wt + (size_t)n * K + k0)[lc4];
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i)
-            *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * kLds + lc4 * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < LB; ++i)
-            *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * i) * kLds + lc4 * 4]) = rb[i];
-    };
+    for (int i = 0; i < LB; ++i) bp[i] = Wt + (size_t)(n0 + lrow + RPP * i) * K + lc4 * 4;
+    const int st_off = lrow * kLds + lc4 * 4;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -174,38 +198,60 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = K / kBK;
-    gload(0);
-    lstore(0);
+    float4 ra[LA], rb[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i]);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i]);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(As + st_off + RPP * i * kLds) = ra[i];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(Bs + st_off + RPP * i * kLds) = rb[i];
     __syncthreads();
 
     const int frow = lane & 31;
     const int fk = (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
+    const float* const a_frag = As + (wr * WM + frow) * kLds + fk;
+    const float* const b_frag = Bs + (wc * WN + frow) * kLds + fk;
+
+#define BD_PW_COMPUTE(BUF)                                                                              \
+    {                                                                                                   \
+        const float* as_ = a_frag + (BUF) * BM * kLds;                                                  \
+        const float* bs_ = b_frag + (BUF) * BN * kLds;                                                  \
+        _Pragma("unroll") for (int s = 0; s < kBK / 8; ++s) {                                           \
+            float4 av[TM], bv[TN];                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) av[i] =                                      \
+                *reinterpret_cast<const float4*>(as_ + i * 32 * kLds + s * 8);                          \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[j] =                                      \
+                *reinterpret_cast<const float4*>(bs_ + j * 32 * kLds + s * 8);                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0); \
+            }                                                                                           \
+        }                                                                                               \
+    }
+
+    const int nk = K / kBK;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * kBK);
-        const float* as = &As[buf][(wr * WM + frow) * kLds + fk];
-        const float* bs = &Bs[buf][(wc * WN + frow) * kLds + fk];
+        const int koff = (kt + 1) * kBK;
 #pragma unroll
-        for (int s = 0; s < kBK / 8; ++s) {
-            float4 av[TM], bv[TN];
+        for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + koff);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(as + i * 32 * kLds + s * 8);
+        for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + koff);
+        BD_PW_COMPUTE(buf)
+        float* an = As + (buf ^ 1) * BM * kLds + st_off;
+        float* bn = Bs + (buf ^ 1) * BN * kLds + st_off;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(bs + j * 32 * kLds + s * 8);
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(an + RPP * i * kLds) = ra[i];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(bn + RPP * i * kLds) = rb[i];
         __syncthreads();
     }
+    BD_PW_COMPUTE((nk - 1) & 1)
+#undef BD_PW_COMPUTE
 
     // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
     const int half = lane >> 5;
@@ -223,6 +269,23 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict_
             }
         }
     }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_pw(const float* A, const float* Wt, const float* bias, float* C, long long M, int N, int K,
+               hipStream_t stream) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr size_t lds = 2u * (BM + BN) * kLds * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_kernel<BM, BN, WGM, WGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int tiles_n = N / BN;
+    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A, Wt,
+                       bias, C, M, N, K, tiles_n);
 }
 
 // --------------------------------------------------------------------------- pool + head
@@ -275,27 +338,49 @@ void launch_conv1(const float* logmel, int patch_step, int windows, const float*
                        w9x32, b32, out);
 }
 
-void launch_depthwise(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream) {
-    if (windows <= 0) return;
-    const long long total = (long long)windows * L.h_out * L.w_out * (L.cin / 4);
+template <int STRIDE, int OWB>
+static void launch_dw(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream) {
+    const long long total = (long long)windows * L.h_out * (L.w_out / OWB) * (L.cin / 4);
     const long long blocks = (total + 255) / 256;
     const int grid = (int)(blocks < (1 << 20) ? blocks : (1 << 20));
-    const int pad = L.stride == 1 ? 1 : 0;   // TF SAME, even extents (yamnet: 48x32 ... 6x4)
-    hipLaunchKernelGGL(depthwise_kernel, dim3(grid), dim3(256), 0, stream, in, out, L.dw_w, L.dw_b, windows,
-                       L.h_in, L.w_in, L.cin, L.h_out, L.w_out, L.stride, pad);
+    hipLaunchKernelGGL((depthwise_kernel<STRIDE, OWB>), dim3(grid), dim3(256), 0, stream, in, out, L.dw_w, L.dw_b,
+                       windows, L.h_in, L.w_in, L.cin, L.h_out, L.w_out);
+}
+
+void launch_depthwise(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream) {
+    if (windows <= 0) return;
+    const bool wide = L.w_out % 4 == 0;
+    if (L.stride == 1) {
+        if (wide) launch_dw<1, 4>(in, out, windows, L, stream);
+        else launch_dw<1, 2>(in, out, windows, L, stream);
+    } else {
+        if (wide) launch_dw<2, 4>(in, out, windows, L, stream);
+        else launch_dw<2, 2>(in, out, windows, L, stream);
+    }
+}
+
+// variant: 0 = pick by shape; otherwise an explicit tile (test / tuning hook)
+int launch_pointwise_variant(const float* A, const float* Wt, const float* bias, float* C, long long M, int N,
+                             int K, int variant, hipStream_t stream) {
+    if (M <= 0) return 0;
+    if (K % kBK != 0 || N % 64 != 0) return -1;
+    if (variant == 0) variant = (K == 256 && N == 256) ? 7 : 8;   // tools/gemm_sweep.py on MI355X
+    switch (variant) {
+        case 1: if (N % 128) return -1; launch_pw<128, 128, 2, 2>(A, Wt, bias, C, M, N, K, stream); break;
+        case 2: launch_pw<128, 64, 2, 2>(A, Wt, bias, C, M, N, K, stream); break;
+        case 3: if (N % 128) return -1; launch_pw<256, 128, 4, 2>(A, Wt, bias, C, M, N, K, stream); break;
+        case 4: if (N % 128) return -1; launch_pw<192, 128, 2, 2>(A, Wt, bias, C, M, N, K, stream); break;
+        case 5: launch_pw<256, 64, 4, 1>(A, Wt, bias, C, M, N, K, stream); break;
+        case 6: if (N % 128) return -1; launch_pw<64, 128, 1, 4>(A, Wt, bias, C, M, N, K, stream); break;
+        case 7: if (N % 256) return -1; launch_pw<128, 256, 2, 4>(A, Wt, bias, C, M, N, K, stream); break;
+        case 8: launch_pw<64, 64, 2, 2>(A, Wt, bias, C, M, N, K, stream); break;
+        default: return -1;
+    }
+    return 0;
 }
 
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
-    if (rows <= 0) return;
-    if (L.cout % 128 == 0) {
-        const long long tiles = ((rows + 127) / 128) * (L.cout / 128);
-        hipLaunchKernelGGL((pointwise_kernel<128, 128>), dim3((unsigned)tiles), dim3(256), 0, stream, in,
-                           L.pw_wt, L.pw_b, out, (long long)rows, L.cout, L.cin);
-    } else {
-        const long long tiles = ((rows + 127) / 128) * (L.cout / 64);
-        hipLaunchKernelGGL((pointwise_kernel<128, 64>), dim3((unsigned)tiles), dim3(256), 0, stream, in,
-                           L.pw_wt, L.pw_b, out, (long long)rows, L.cout, L.cin);
-    }
+    launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,

@@ -350,6 +350,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         L.dw_b = e->d_pool + off_dw_b[l];
         L.pw_wt = e->d_pool + off_pw_w[l];
         L.pw_b = e->d_pool + off_pw_b[l];
+        L.pw_variant = 0;
         h = L.h_out;
         wd = L.w_out;
         cin = L.cout;
@@ -528,6 +529,21 @@ int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t h
     if (stage < 0 || stage >= BD_NUM_STAGES) return fail(BD_EINVAL, "bd_stage_tap: stage out of range");
     return run_chunk(h, pcm_dev, n_samples, hop_samples, patch_step, workspace_dev, workspace_bytes, nullptr,
                      nullptr, stage, windows, out_dev, (hipStream_t)stream);
+}
+
+int bd_debug_pointwise(const float* a_dev, const float* wt_dev, const float* bias_dev, float* c_dev, int64_t m,
+                       int32_t n, int32_t k, int32_t variant, void* stream) {
+    if (!a_dev || !wt_dev || !bias_dev || !c_dev || m < 0) return fail(BD_EINVAL, "bd_debug_pointwise: bad argument");
+    if (bd::launch_pointwise_variant(a_dev, wt_dev, bias_dev, c_dev, m, n, k, variant, (hipStream_t)stream) != 0)
+        return fail(BD_EINVAL, "bd_debug_pointwise: shape/variant not supported (K % 32, N % tile)");
+    BD_HIP(hipGetLastError());
+    return BD_OK;
+}
+
+int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
+    if (!h || layer < 2 || layer > 14) return fail(BD_EINVAL, "bd_set_pointwise_variant: layer must be 2..14");
+    h->sep[layer - 2].pw_variant = variant;
+    return BD_OK;
 }
 
 int bd_profile_enable(bd_handle h, int32_t on) {

@@ -131,6 +131,13 @@ BD_API int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, in
                  int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
                  int32_t stage, int32_t windows, float* out_dev, void* stream);
 
+/* Tuning / test hooks for the pointwise (1x1 convolution) GEMM, yamnet.py:64-70 after BN folding:
+   c[m][n] = relu(sum_k a[m][k] * wt[n][k] + bias[n]); k % 32 == 0, n % 64 == 0.
+   variant 0 = the library's choice for the shape; 1..8 = explicit tile shapes (see cnn.hip). */
+BD_API int bd_debug_pointwise(const float* a_dev, const float* wt_dev, const float* bias_dev, float* c_dev,
+                              int64_t m, int32_t n, int32_t k, int32_t variant, void* stream);
+BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int32_t variant);
+
 /* ---- per-stage timing (HIP events on the caller's stream) ----
    With profiling on, every kernel launch of bd_predict/bd_embed is bracketed by events.
    bd_profile_read synchronises on them and accumulates per slot: 0 = front end, 1 = conv1,
