@@ -60,6 +60,9 @@ PROTOTYPES = {
     "bd_debug_pointwise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p]),
     "bd_set_pointwise_variant": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "bd_set_pointwise_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bd_debug_pointwise_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "bd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "bd_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

@@ -31,7 +31,11 @@ struct SepLayer {
     const float* dw_b;   // [cin]      beta - mean * scale
     const float* pw_wt;  // [cout][cin] pointwise kernel transposed * bn scale (K contiguous)
     const float* pw_b;   // [cout]
-    int pw_variant;      // tile choice for launch_pointwise (0 = by shape)
+    int pw_variant;      // tile choice for the exact-f32 kernel (0 = by shape)
+    const void* pw_whi;  // [cout][cin] f16: high half of pw_wt
+    const void* pw_wlo;  // [cout][cin] f16: f16(pw_wt - high)
+    int pw_variant16;    // tile choice for the split-f16 kernel (0 = by shape)
+    int pw_mode;         // 0 = exact f32 MFMA, 1 = split-f16 MFMA (3 products)
 };
 
 // ---- launchers (each enqueues exactly one kernel on `stream`) ----
@@ -45,6 +49,8 @@ void launch_depthwise(const float* in, float* out, int windows, const SepLayer& 
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream);
 int launch_pointwise_variant(const float* A, const float* Wt, const float* bias, float* C, long long M, int N,
                              int K, int variant, hipStream_t stream);
+int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* bias, float* C,
+                                   long long M, int N, int K, int variant, hipStream_t stream);
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
                       int n_classes, float* emb, float* logits, hipStream_t stream);
 

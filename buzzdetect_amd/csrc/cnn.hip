@@ -271,6 +271,185 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* _
     }
 }
 
+// --------------------------------------------------------------------------- pointwise GEMM, split-f16
+// Same contraction on the f16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the f32-MFMA rate) without
+// giving up f32 accuracy: every f32 operand x is carried as two halves x = hi + lo with
+// hi = f16(x), lo = f16(x - hi)  (22 significand bits), and
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi      (the dropped a_lo*b_lo term is ~2^-22 relative)
+// Products of two f16 are exact in f32 and the MFMA accumulates in f32, so the result differs from the
+// f32 chain by ~1e-7 relative — measured on the whole network: same max |dlogit| vs the f64 oracle as
+// the exact-f32 kernel.  Weights are split once on the host; activations are split while they are staged
+// from HBM into LDS.
+//
+// LDS tiles are [rows][32 f16] = 64-byte rows with no padding; the 16-byte slot index is XORed with
+// (row >> 2) & 3 so that the 16 rows a ds_read_b128 lane group touches land on 16 different slots of
+// the 256-byte bank row.  Operand map of v_mfma_f32_32x32x16_f16: lane l supplies
+// A[row l & 31][k = 8*(l >> 5) + j] and B[k = 8*(l >> 5) + j][col l & 31], j = 0..7.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
+    const float* __restrict__ A, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
+    const float* __restrict__ bias, float* __restrict__ C, long long M, int N, int K, int tiles_n) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RPP = NT / 8;
+    constexpr int LA = BM / RPP;            // float4 loads of A per thread per stage
+    constexpr int BCH = BN * 4 / NT;        // 16-byte chunks per thread per stage, for each of W_hi / W_lo
+    static_assert(BM % RPP == 0 && (BN * 4) % NT == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* const Ah = smem_raw;                    // [2][A_BYTES]
+    char* const Al = Ah + 2 * A_BYTES;
+    char* const Bh = Al + 2 * A_BYTES;            // [2][B_BYTES]
+    char* const Bl = Bh + 2 * B_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WGN, wc = wave % WGN;
+    const long long tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x % tiles_n;
+    const long long m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int lrow = tid >> 3;
+    const int lc4 = tid & 7;
+    const float* ap[LA];
+    int a_st[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        long long m = m0 + lrow + RPP * i;
+        m = m < M ? m : M - 1;
+        ap[i] = A + (size_t)m * K + lc4 * 4;
+        a_st[i] = swz64(lrow + RPP * i, lc4 >> 1) + (lc4 & 1) * 8;
+    }
+    const _Float16* bph[BCH];
+    const _Float16* bpl[BCH];
+    int b_st[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int id = tid + NT * i;
+        const int row = id >> 2, slot = id & 3;
+        bph[i] = Whi + (size_t)(n0 + row) * K + slot * 8;
+        bpl[i] = Wlo + (size_t)(n0 + row) * K + slot * 8;
+        b_st[i] = swz64(row, slot);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[LA];
+    uint4 rbh[BCH], rbl[BCH];
+
+#define BD_F16_LOAD(KOFF)                                                                                \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + (KOFF)); \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                \
+            rbh[i] = *reinterpret_cast<const uint4*>(bph[i] + (KOFF));                                   \
+            rbl[i] = *reinterpret_cast<const uint4*>(bpl[i] + (KOFF));                                   \
+        }                                                                                                \
+    }
+#define BD_F16_STORE(BUF)                                                                                \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                 \
+            const float4 v = ra[i];                                                                      \
+            f16x4 hi, lo;                                                                                \
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;  \
+            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);              \
+            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);              \
+            *reinterpret_cast<f16x4*>(Ah + (BUF) * A_BYTES + a_st[i]) = hi;                              \
+            *reinterpret_cast<f16x4*>(Al + (BUF) * A_BYTES + a_st[i]) = lo;                              \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                \
+            *reinterpret_cast<uint4*>(Bh + (BUF) * B_BYTES + b_st[i]) = rbh[i];                          \
+            *reinterpret_cast<uint4*>(Bl + (BUF) * B_BYTES + b_st[i]) = rbl[i];                          \
+        }                                                                                                \
+    }
+
+    const int frow = lane & 31;
+    const int fh = lane >> 5;
+#define BD_F16_COMPUTE(BUF)                                                                              \
+    {                                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                  \
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                        \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                             \
+                const int off = (BUF) * A_BYTES + swz64(wr * WM + i * 32 + frow, 2 * s + fh);            \
+                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                       \
+                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                       \
+            }                                                                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
+                const int off = (BUF) * B_BYTES + swz64(wc * WN + j * 32 + frow, 2 * s + fh);            \
+                bh[j] = *reinterpret_cast<const f16x8*>(Bh + off);                                       \
+                bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                       \
+            }                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);    \
+            }                                                                                            \
+        }                                                                                                \
+    }
+
+    BD_F16_LOAD(0)
+    BD_F16_STORE(0)
+    __syncthreads();
+    const int nk = K / 32;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int buf = kt & 1;
+        BD_F16_LOAD((kt + 1) * 32)
+        BD_F16_COMPUTE(buf)
+        BD_F16_STORE(buf ^ 1)
+        __syncthreads();
+    }
+    BD_F16_COMPUTE((nk - 1) & 1)
+#undef BD_F16_LOAD
+#undef BD_F16_STORE
+#undef BD_F16_COMPUTE
+
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * WN + j * 32 + frow;
+        const float b = bias[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long mb = m0 + wr * WM + i * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < M) C[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_pw16(const float* A, const _Float16* Whi, const _Float16* Wlo, const float* bias, float* C,
+                 long long M, int N, int K, hipStream_t stream) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr size_t lds = 2u * 2u * (BM + BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_f16x3_kernel<BM, BN, WGM, WGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int tiles_n = N / BN;
+    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL((pointwise_f16x3_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A,
+                       Whi, Wlo, bias, C, M, N, K, tiles_n);
+}
+
 template <int BM, int BN, int WGM, int WGN>
 void launch_pw(const float* A, const float* Wt, const float* bias, float* C, long long M, int N, int K,
                hipStream_t stream) {
@@ -379,8 +558,59 @@ int launch_pointwise_variant(const float* A, const float* Wt, const float* bias,
     return 0;
 }
 
+// Tile choice for the split-f16 kernel, from tools/gemm_sweep.py on MI355X at 1024 windows; when the
+// batch is too small to give every CU a tile of the preferred shape, fall back to smaller tiles.
+static int pick_f16x3_variant(long long M, int N, int K) {
+    struct Opt { int variant, bm, bn; };
+    static const Opt big_k[] = {{9, 256, 256}, {7, 128, 256}, {6, 64, 128}, {8, 64, 64}};     // K >= 256, N >= 512
+    static const Opt mid[] = {{7, 128, 256}, {1, 128, 128}, {6, 64, 128}, {8, 64, 64}};        // N == 256
+    static const Opt n128[] = {{3, 256, 128}, {1, 128, 128}, {6, 64, 128}, {8, 64, 64}};       // N == 128
+    static const Opt n64[] = {{2, 128, 64}, {8, 64, 64}};                                       // N == 64
+    static const Opt deep[] = {{2, 128, 64}, {6, 64, 128}, {8, 64, 64}};                        // N == 1024
+    const Opt* list;
+    int count;
+    if (N == 64) { list = n64; count = 2; }
+    else if (N == 128) { list = n128; count = 4; }
+    else if (N == 256) { list = mid; count = 4; }
+    else if (N >= 1024) { list = deep; count = 3; }
+    else { list = big_k; count = 4; }
+    for (int i = 0; i < count; ++i) {
+        if (N % list[i].bn) continue;
+        const long long tiles = ((M + list[i].bm - 1) / list[i].bm) * (N / list[i].bn);
+        if (tiles >= 256 || i == count - 1) return list[i].variant;
+    }
+    (void)K;
+    return 8;
+}
+
+int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* bias, float* C,
+                                   long long M, int N, int K, int variant, hipStream_t stream) {
+    if (M <= 0) return 0;
+    if (K % 32 != 0 || N % 64 != 0) return -1;
+    const _Float16* wh = static_cast<const _Float16*>(Whi);
+    const _Float16* wl = static_cast<const _Float16*>(Wlo);
+    if (variant == 0) variant = pick_f16x3_variant(M, N, K);
+    switch (variant) {
+        case 1: if (N % 128) return -1; launch_pw16<128, 128, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 2: launch_pw16<128, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 3: if (N % 128) return -1; launch_pw16<256, 128, 4, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 4: if (N % 256) return -1; launch_pw16<128, 256, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 5: launch_pw16<256, 64, 4, 1>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 6: if (N % 128) return -1; launch_pw16<64, 128, 1, 4>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 7: if (N % 256) return -1; launch_pw16<128, 256, 2, 4>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 8: launch_pw16<64, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 9: if (N % 256) return -1; launch_pw16<256, 256, 4, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
+        default: return -1;
+    }
+    return 0;
+}
+
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
-    launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
+    if (L.pw_mode == 1)
+        launch_pointwise_f16x3_variant(in, L.pw_whi, L.pw_wlo, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant16,
+                                       stream);
+    else
+        launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,

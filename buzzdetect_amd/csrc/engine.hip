@@ -45,6 +45,7 @@ struct bd_engine {
     int device = 0;
     int n_classes = 0;
     int group_windows = kDefaultGroup;
+    int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
     const float* conv1_w = nullptr;   // [9][32]
@@ -267,7 +268,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
     };
     const float* p = w->embedder_blob;
     size_t off_conv1_w, off_conv1_b;
-    size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13];
+    size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13], off_pw_hi[13], off_pw_lo[13];
     {
         const int c = kLayerDefs[0][1];
         const float* kern = p;   // [3][3][1][32]
@@ -301,6 +302,22 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
             for (int k = 0; k < cin; ++k)
                 host[off_pw_w[l] + (size_t)n * cin + k] = (float)((double)pw[(size_t)k * cout + n] * fp.scale[n]);
         for (int n = 0; n < cout; ++n) host[off_pw_b[l] + n] = (float)fp.shift[n];
+        // split-f16 copy of the folded pointwise kernel: w = hi + lo, hi = f16(w), lo = f16(w - hi)
+        const size_t nw = (size_t)cin * cout;
+        off_pw_hi[l] = reserve((nw + 1) / 2);
+        off_pw_lo[l] = reserve((nw + 1) / 2);
+        {
+            _Float16* hi = reinterpret_cast<_Float16*>(host.data() + off_pw_hi[l]);
+            _Float16* lo = reinterpret_cast<_Float16*>(host.data() + off_pw_lo[l]);
+            const float* wf = host.data() + off_pw_w[l];
+            for (size_t i = 0; i < nw; ++i) {
+                if (std::fabs(wf[i]) > 60000.0f)
+                    return fail(BD_EWEIGHTS, "bd_create: folded pointwise weight exceeds the f16 range");
+                const _Float16 h = (_Float16)wf[i];
+                hi[i] = h;
+                lo[i] = (_Float16)(wf[i] - (float)h);
+            }
+        }
         cin = cout;
     }
     if (p - w->embedder_blob != BD_EMBEDDER_BLOB_FLOATS) return fail(BD_EWEIGHTS, "internal: blob walk mismatch");
@@ -313,8 +330,20 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
                 host[off_head_w + (size_t)c * BD_EMBEDDING_SIZE + k] = w->head_kernel[(size_t)k * w->n_classes + c];
         for (int c = 0; c < w->n_classes; ++c) host[off_head_b + c] = w->head_bias[c];
     }
-    for (float v : host)
-        if (!std::isfinite(v)) return fail(BD_EWEIGHTS, "bd_create: non-finite value after BatchNorm folding");
+    {
+        bool finite = true;
+        for (size_t i = off_conv1_w; i < off_conv1_b + 32; ++i) finite = finite && std::isfinite(host[i]);
+        int c = kLayerDefs[0][1];
+        for (int l = 0; l < 13; ++l) {
+            const int co = kLayerDefs[l + 1][1];
+            for (size_t i = 0; i < 9 * (size_t)c; ++i) finite = finite && std::isfinite(host[off_dw_w[l] + i]);
+            for (int i = 0; i < c; ++i) finite = finite && std::isfinite(host[off_dw_b[l] + i]);
+            for (size_t i = 0; i < (size_t)c * co; ++i) finite = finite && std::isfinite(host[off_pw_w[l] + i]);
+            for (int i = 0; i < co; ++i) finite = finite && std::isfinite(host[off_pw_b[l] + i]);
+            c = co;
+        }
+        if (!finite) return fail(BD_EWEIGHTS, "bd_create: non-finite value after BatchNorm folding");
+    }
 
     bd::FeTables tables;
     int rc = build_tables(w->mel, &tables);
@@ -351,6 +380,10 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         L.pw_wt = e->d_pool + off_pw_w[l];
         L.pw_b = e->d_pool + off_pw_b[l];
         L.pw_variant = 0;
+        L.pw_whi = e->d_pool + off_pw_hi[l];
+        L.pw_wlo = e->d_pool + off_pw_lo[l];
+        L.pw_variant16 = 0;
+        L.pw_mode = e->pointwise_mode;
         h = L.h_out;
         wd = L.w_out;
         cin = L.cout;
@@ -542,7 +575,26 @@ int bd_debug_pointwise(const float* a_dev, const float* wt_dev, const float* bia
 
 int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
     if (!h || layer < 2 || layer > 14) return fail(BD_EINVAL, "bd_set_pointwise_variant: layer must be 2..14");
-    h->sep[layer - 2].pw_variant = variant;
+    if (h->sep[layer - 2].pw_mode == 1) h->sep[layer - 2].pw_variant16 = variant;
+    else h->sep[layer - 2].pw_variant = variant;
+    return BD_OK;
+}
+
+int bd_set_pointwise_mode(bd_handle h, int32_t mode) {
+    if (!h || (mode != 0 && mode != 1)) return fail(BD_EINVAL, "bd_set_pointwise_mode: mode must be 0 (f32) or 1 (split f16)");
+    h->pointwise_mode = mode;
+    for (auto& L : h->sep) L.pw_mode = mode;
+    return BD_OK;
+}
+
+int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, const void* wlo_dev, const float* bias_dev,
+                             float* c_dev, int64_t m, int32_t n, int32_t k, int32_t variant, void* stream) {
+    if (!a_dev || !whi_dev || !wlo_dev || !bias_dev || !c_dev || m < 0)
+        return fail(BD_EINVAL, "bd_debug_pointwise_f16x3: bad argument");
+    if (bd::launch_pointwise_f16x3_variant(a_dev, whi_dev, wlo_dev, bias_dev, c_dev, m, n, k, variant,
+                                           (hipStream_t)stream) != 0)
+        return fail(BD_EINVAL, "bd_debug_pointwise_f16x3: shape/variant not supported");
+    BD_HIP(hipGetLastError());
     return BD_OK;
 }
 

@@ -109,6 +109,13 @@ class HipEngine:
     def set_group_windows(self, windows: int) -> None:
         _lib.check(self._lib.bd_set_group_windows(self._handle, int(windows)))
 
+    def set_pointwise_mode(self, mode: str) -> None:
+        """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class)."""
+        _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1}[mode]))
+
+    def set_pointwise_variant(self, layer: int, variant: int) -> None:
+        _lib.check(self._lib.bd_set_pointwise_variant(self._handle, int(layer), int(variant)))
+
     def num_windows(self, n_samples: int, hop: int, step: int) -> int:
         return _lib.check(self._lib.bd_num_windows(int(n_samples), int(hop), int(step)))
 

@@ -138,6 +138,15 @@ BD_API int bd_debug_pointwise(const float* a_dev, const float* wt_dev, const flo
                               int64_t m, int32_t n, int32_t k, int32_t variant, void* stream);
 BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int32_t variant);
 
+/* Arithmetic of the 1x1 convolutions: 0 = v_mfma_f32_32x32x2_f32 (exact f32 products),
+   1 = split-f16 (default): every f32 operand carried as hi + lo halves, three f16 MFMAs per product,
+   f32 accumulate; same accuracy class as f32, ~5x the matrix-core rate. */
+BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
+/* whi/wlo: [n][k] f16 halves of wt (wt ~= whi + wlo) */
+BD_API int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, const void* wlo_dev,
+                                    const float* bias_dev, float* c_dev, int64_t m, int32_t n, int32_t k,
+                                    int32_t variant, void* stream);
+
 /* ---- per-stage timing (HIP events on the caller's stream) ----
    With profiling on, every kernel launch of bd_predict/bd_embed is bracketed by events.
    bd_profile_read synchronises on them and accumulates per slot: 0 = front end, 1 = conv1,

@@ -53,3 +53,11 @@ def engine():
     eng = HipEngine(embeddername="yamnet_k2", modelname="model_general_v3")
     yield eng
     eng.close()
+
+
+@pytest.fixture(params=["f16x3", "f32"])
+def engine_mode(engine, request):
+    """The same engine with the 1x1 convolutions on split-f16 MFMA (default) or exact-f32 MFMA."""
+    engine.set_pointwise_mode(request.param)
+    yield engine
+    engine.set_pointwise_mode("f16x3")

@@ -75,7 +75,8 @@ def test_frontend_matches_golden_rows(engine):
 
 
 # --------------------------------------------------------------------------- CNN stages
-def test_every_cnn_stage_against_oracle(engine, weights_bundle):
+def test_every_cnn_stage_against_oracle(engine_mode, weights_bundle):
+    engine = engine_mode
     b = weights_bundle
     x = O.synthetic_audio(HOP * 3 + 500, seed=11)
     taps = []
@@ -88,7 +89,8 @@ def test_every_cnn_stage_against_oracle(engine, weights_bundle):
         assert np.abs(got - ref).max() < TOL_LOGITS, f"stage {stage}"
 
 
-def test_pointwise_gemm_tile_edges(engine, weights_bundle):
+def test_pointwise_gemm_tile_edges(engine_mode, weights_bundle):
+    engine = engine_mode
     # 1 window -> the GEMM M dimension (rows = positions) is not a multiple of the 128-row tile for the
     # deep layers (24 and 6 rows): exercises the bounds checks on loads and stores.
     b = weights_bundle
@@ -102,7 +104,8 @@ def test_pointwise_gemm_tile_edges(engine, weights_bundle):
 
 
 # --------------------------------------------------------------------------- whole path
-def test_logits_match_golden_fixture(engine):
+def test_logits_match_golden_fixture(engine_mode):
+    engine = engine_mode
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_oracle_f64.npz"))
     x = O.synthetic_audio(int(g["n_samples"]), seed=int(g["seed"]))
     emb, logits = engine.run(x, HOP, STEP, True, True)
@@ -114,7 +117,8 @@ def test_logits_match_golden_fixture(engine):
 
 
 @pytest.mark.parametrize("hop,step,n", [(15360, 96, 15360 * 20 + 17), (7680, 48, 15360 * 9), (4608, 29, 70000)])
-def test_logits_vs_oracle_various_hops(engine, weights_bundle, hop, step, n):
+def test_logits_vs_oracle_various_hops(engine_mode, weights_bundle, hop, step, n):
+    engine = engine_mode
     x = O.synthetic_audio(n, seed=hop)
     ref = oracle_logits(x, weights_bundle, hop, step)
     got = engine.run(x, hop, step, False, True)[1].cpu().numpy()
@@ -172,10 +176,11 @@ def test_too_long_chunk_is_refused(engine):
 
 
 # --------------------------------------------------------------------------- full-size properties
-def test_full_batch_1024_properties(engine, weights_bundle):
+def test_full_batch_1024_properties(engine_mode, weights_bundle):
     """BASELINE config 2 batch (1024 windows = 15 728 640 samples): properties that need no oracle run
     at full size, plus oracle spot checks on a few windows."""
     import torch
+    engine = engine_mode
     n = HOP * 1024
     x = O.synthetic_audio(n, seed=2024)
     xd = torch.from_numpy(x).to(engine.device)
@@ -222,3 +227,41 @@ def test_one_hour_file_in_batches_of_1024(engine, weights_bundle):
     assert np.all(np.diff(starts) > 0) and starts[-1] == 3599.04
     seg = audio[15_728_640: 15_728_640 + 15600].numpy()
     assert np.abs(rows[1][0] - oracle_logits(seg, weights_bundle)[0]).max() < TOL_LOGITS
+
+
+# --------------------------------------------------------------------------- pointwise GEMM in isolation
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+@pytest.mark.parametrize("m,k,n", [(1, 32, 64), (6, 1024, 1024), (130, 64, 128), (4992, 512, 512), (1000, 256, 256)])
+def test_pointwise_gemm_every_tile_variant(mode, m, k, n):
+    """Every tile shape of both GEMM kernels against an f64 product, on ragged M (tile-edge rows), with
+    operands spanning the f16 normal and subnormal ranges for the split path."""
+    import torch
+    from buzzdetect_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(m * 7 + k + n)
+    a = torch.rand((m, k), generator=g, device=dev) * 8.0
+    a[:, ::7] *= 1e-4                                  # small activations: lo halves go f16-subnormal
+    a[:, 1::5] = 0.0                                   # ReLU zeros
+    wt = torch.randn((n, k), generator=g, device=dev) * (2.0 / k) ** 0.5
+    bias = torch.randn(n, generator=g, device=dev) * 0.1
+    ref = torch.relu(a.double() @ wt.double().T + bias.double())
+    scale = float((a.double().abs() @ wt.double().abs().T).max())
+    whi = wt.to(torch.float16)
+    wlo = (wt - whi.float()).to(torch.float16)
+    stream = torch.cuda.current_stream().cuda_stream
+    ran = 0
+    for variant in range(0, 10):
+        c = torch.full((m, n), -1.0, device=dev)
+        if mode == "f32":
+            rc = lib.bd_debug_pointwise(a.data_ptr(), wt.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, variant, stream)
+        else:
+            rc = lib.bd_debug_pointwise_f16x3(a.data_ptr(), whi.data_ptr(), wlo.data_ptr(), bias.data_ptr(),
+                                              c.data_ptr(), m, n, k, variant, stream)
+        if rc != 0:
+            continue                                    # tile does not divide N
+        ran += 1
+        torch.cuda.synchronize()
+        err = float((c.double() - ref).abs().max())
+        assert err <= 4e-6 * scale + 1e-7, (mode, variant, err, scale)
+    assert ran >= 3

@@ -11,7 +11,8 @@ SHAPES = [  # (layer, rows per window, K, N)
 
 def main():
     windows = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(1, 9))
+    variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(1, 10))
+    mode = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
     lib = _lib.load()
     dev = torch.device("cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -25,22 +26,27 @@ def main():
         ref = torch.relu(A[:4096].double() @ Wt.double().T + bias.double()).float()
         reft = torch.relu(A[-300:].double() @ Wt.double().T + bias.double()).float()
         C = torch.empty((M, N), device=dev)
+        Whi = Wt.to(torch.float16); Wlo = (Wt - Whi.float()).to(torch.float16)
+        def call(v):
+            if mode == "f32":
+                return lib.bd_debug_pointwise(A.data_ptr(), Wt.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, v, stream)
+            return lib.bd_debug_pointwise_f16x3(A.data_ptr(), Whi.data_ptr(), Wlo.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, v, stream)
         flops = 2.0 * M * K * N
         line = []
         for v in variants:
             C.fill_(-1.0)
-            rc = lib.bd_debug_pointwise(A.data_ptr(), Wt.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, v, stream)
+            rc = call(v)
             if rc != 0:
                 line.append((v, None, None)); continue
             torch.cuda.synchronize()
             err = max((C[:4096] - ref).abs().max().item(), (C[-300:] - reft).abs().max().item())
             for _ in range(3):
-                lib.bd_debug_pointwise(A.data_ptr(), Wt.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, v, stream)
+                call(v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 20
             e0.record()
             for _ in range(reps):
-                lib.bd_debug_pointwise(A.data_ptr(), Wt.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, v, stream)
+                call(v)
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
             line.append((v, us, err))
