@@ -467,6 +467,185 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
                        bias, C, M, N, K, tiles_n);
 }
 
+// --------------------------------------------------------------------------- fused stem
+// Layers 1-2 in one kernel: Conv2D 3x3 s2 (1->32) -> depthwise 3x3 s1 -> pointwise 32->64, each with
+// its folded BatchNorm + ReLU (yamnet.py:77-79).  Unfused these three launches move 1.2 GB per 1024
+// windows (conv1 out, depthwise in/out, pointwise in) around the one tensor that has to exist, the
+// layer-2 output; here a workgroup owns 4 output rows of one window, keeps the conv1 band (6 rows) and
+// the depthwise band (4 rows) in LDS, and writes only the [128 positions][64] result.
+// Arithmetic order per element is exactly that of conv1_kernel, depthwise_kernel and the split-f16
+// pointwise kernel, so the result is bit-identical to the unfused path.
+constexpr int kStemRows = 4;
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ logmel, int patch_step,
+                                                   const float* __restrict__ c1_w, const float* __restrict__ c1_b,
+                                                   const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                   const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
+                                                   const float* __restrict__ pw_b, float* __restrict__ out) {
+    constexpr int LMR = 2 * kStemRows + 5;      // log-mel rows feeding 6 conv1 rows: 13
+    constexpr int C1R = kStemRows + 2;          // conv1 rows incl. the depthwise halo: 6
+    constexpr int BM = kStemRows * 32;          // 128 output positions
+    __shared__ __attribute__((aligned(16))) float s_lm[LMR][68];
+    __shared__ __attribute__((aligned(16))) float s_c1[C1R][34][32];
+    __shared__ __attribute__((aligned(16))) char s_ah[BM * 64];
+    __shared__ __attribute__((aligned(16))) char s_al[BM * 64];
+    __shared__ __attribute__((aligned(16))) char s_bh[64 * 64];
+    __shared__ __attribute__((aligned(16))) char s_bl[64 * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int win = blockIdx.y;
+    const int oh0 = blockIdx.x * kStemRows;
+    const float* patch = logmel + (size_t)win * patch_step * BD_MEL_BANDS;
+
+    // ---- phase A: log-mel band, pointwise weights, zero halo columns ----
+    for (int i = tid; i < LMR * 17; i += 256) {
+        const int j = i / 17, q = i % 17;
+        const int ih = 2 * oh0 - 2 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < 16 && ih >= 0 && ih < BD_PATCH_FRAMES) v = reinterpret_cast<const float4*>(patch + ih * BD_MEL_BANDS)[q];
+        *reinterpret_cast<float4*>(&s_lm[j][q * 4]) = v;      // q == 16: columns 64..67 stay zero (SAME pad right)
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i;                         // 512 chunks: 64 rows x 4 slots x {hi, lo}
+        const int which = id >> 8, rem = id & 255;
+        const int row = rem >> 2, slot = rem & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>((which ? Wlo : Whi) + row * 32 + slot * 8);
+        *reinterpret_cast<uint4*>((which ? s_bl : s_bh) + swz64(row, slot)) = v;
+    }
+    for (int i = tid; i < C1R * 2 * 8; i += 256) {
+        const int r = i / 16, side = (i >> 3) & 1, c4 = i & 7;
+        *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    // ---- phase B: conv1 band (rows oh0-1 .. oh0+4) -> s_c1[.][1 + col][ch] ----
+    const int c4 = tid & 7;
+    const int col = tid >> 3;                                  // 0..31
+    {
+        float4 wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(c1_w + t * 32)[c4];
+        const float4 bias = reinterpret_cast<const float4*>(c1_b)[c4];
+#pragma unroll
+        for (int i = 0; i < C1R; ++i) {
+            const int c1r = oh0 - 1 + i;
+            float4 acc = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* row = &s_lm[2 * i + kh][2 * col];
+                const bool ok = 2 * c1r + kh < BD_PATCH_FRAMES;          // SAME pad bottom (row 96)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    if (!ok) continue;
+                    const float v = row[kw];
+                    const float4 w = wt[kh * 3 + kw];
+                    acc.x = fmaf(v, w.x, acc.x);
+                    acc.y = fmaf(v, w.y, acc.y);
+                    acc.z = fmaf(v, w.z, acc.z);
+                    acc.w = fmaf(v, w.w, acc.w);
+                }
+            }
+            const bool valid = c1r >= 0 && c1r < 48;                      // outside: zero padding of the depthwise
+            float4 r4;
+            r4.x = valid ? fmaxf(acc.x, 0.0f) : 0.0f;
+            r4.y = valid ? fmaxf(acc.y, 0.0f) : 0.0f;
+            r4.z = valid ? fmaxf(acc.z, 0.0f) : 0.0f;
+            r4.w = valid ? fmaxf(acc.w, 0.0f) : 0.0f;
+            *reinterpret_cast<float4*>(&s_c1[i][col + 1][c4 * 4]) = r4;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: depthwise on the band -> split-f16 A tile [128][32] ----
+    {
+        float4 wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(dw_w + t * 32)[c4];
+        const float4 bias = reinterpret_cast<const float4*>(dw_b)[c4];
+        float4 acc[kStemRows];
+#pragma unroll
+        for (int r = 0; r < kStemRows; ++r) acc[r] = bias;
+        // taps must be applied per output in (kh, kw) order: walk the 6 band rows once, feeding each
+        // output row r its kh = i - r tap row while keeping that order (r descending => kh ascending per r)
+#pragma unroll
+        for (int r = 0; r < kStemRows; ++r) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_c1[r + kh][col + kw][c4 * 4]);
+                    const float4 w = wt[kh * 3 + kw];
+                    acc[r].x = fmaf(v.x, w.x, acc[r].x);
+                    acc[r].y = fmaf(v.y, w.y, acc[r].y);
+                    acc[r].z = fmaf(v.z, w.z, acc[r].z);
+                    acc[r].w = fmaf(v.w, w.w, acc[r].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kStemRows; ++r) {
+            float4 v = acc[r];
+            v.x = fmaxf(v.x, 0.0f);
+            v.y = fmaxf(v.y, 0.0f);
+            v.z = fmaxf(v.z, 0.0f);
+            v.w = fmaxf(v.w, 0.0f);
+            f16x4 hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+            const int off = swz64(r * 32 + col, c4 >> 1) + (c4 & 1) * 8;
+            *reinterpret_cast<f16x4*>(s_ah + off) = hi;
+            *reinterpret_cast<f16x4*>(s_al + off) = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D: [128][32] x [32][64] on the f16 matrix cores, 2 x 2 waves, wave tile 64 x 32 ----
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 31, fh = lane >> 5;
+    f32x16 acc2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = swz64(wr * 64 + i * 32 + frow, 2 * s2 + fh);
+            ah[i] = *reinterpret_cast<const f16x8*>(s_ah + off);
+            al[i] = *reinterpret_cast<const f16x8*>(s_al + off);
+        }
+        const int boff = swz64(wc * 32 + frow, 2 * s2 + fh);
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(s_bh + boff);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(s_bl + boff);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc2[i], 0, 0, 0);
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc2[i], 0, 0, 0);
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc2[i], 0, 0, 0);
+        }
+    }
+
+    // ---- phase E: bias + ReLU, store the 128 x 64 block (rows are consecutive NHWC positions) ----
+    float* dst = out + ((size_t)win * 48 + oh0) * 32 * 64;
+    const int n = wc * 32 + frow;
+    const float b = pw_b[n];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mb = wr * 64 + i * 32 + 4 * fh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            dst[(size_t)m * 64 + n] = fmaxf(acc2[i][r] + b, 0.0f);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- pool + head
 __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ act,
                                                         const float* __restrict__ head_wt,
@@ -611,6 +790,14 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
                                        stream);
     else
         launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
+}
+
+void launch_stem(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
+                 const SepLayer& L2, float* out, hipStream_t stream) {
+    if (windows <= 0) return;
+    hipLaunchKernelGGL(stem_kernel, dim3(48 / kStemRows, windows), dim3(256), 0, stream, logmel, patch_step, c1_w,
+                       c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, out);
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,

@@ -46,6 +46,7 @@ struct bd_engine {
     int n_classes = 0;
     int group_windows = kDefaultGroup;
     int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA
+    bool fuse_stem = true;            // layers 1-2 as one kernel (split-f16 mode only)
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
     const float* conv1_w = nullptr;   // [9][32]
@@ -495,14 +496,29 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
     for (int64_t w0 = 0; w0 < g.n_windows; w0 += group) {
         const int gw = stop_stage >= 0 ? tap_windows : (int)(g.n_windows - w0 < group ? g.n_windows - w0 : group);
         const float* lm = logmel + w0 * step * BD_MEL_BANDS;
-        {
-            Scope sc(e, stream, 1);
-            bd::launch_conv1(lm, step, gw, e->conv1_w, e->conv1_b, buf_a, stream);
-        }
+        // layers 1-2 run as one fused kernel (split-f16 mode) unless a test taps inside them
+        const bool fuse_stem = e->fuse_stem && e->pointwise_mode == 1 && (stop_stage < 0 || stop_stage >= 2);
         const float* last = buf_a;
-        int64_t last_floats = (int64_t)gw * 48 * 32 * 32;
-        bool stopped = stop_stage == 0;
-        for (int l = 0; l < 13 && !stopped; ++l) {
+        int64_t last_floats = 0;
+        bool stopped = false;
+        int first_layer = 0;
+        if (fuse_stem) {
+            {
+                Scope sc(e, stream, 3);
+                bd::launch_stem(lm, step, gw, e->conv1_w, e->conv1_b, e->sep[0], buf_a, stream);
+            }
+            last_floats = (int64_t)gw * 48 * 32 * 64;
+            stopped = stop_stage == 2;
+            first_layer = 1;
+        } else {
+            {
+                Scope sc(e, stream, 1);
+                bd::launch_conv1(lm, step, gw, e->conv1_w, e->conv1_b, buf_a, stream);
+            }
+            last_floats = (int64_t)gw * 48 * 32 * 32;
+            stopped = stop_stage == 0;
+        }
+        for (int l = first_layer; l < 13 && !stopped; ++l) {
             const bd::SepLayer& L = e->sep[l];
             {
                 Scope sc(e, stream, 2 + 2 * l);
@@ -577,6 +593,12 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
     if (!h || layer < 2 || layer > 14) return fail(BD_EINVAL, "bd_set_pointwise_variant: layer must be 2..14");
     if (h->sep[layer - 2].pw_mode == 1) h->sep[layer - 2].pw_variant16 = variant;
     else h->sep[layer - 2].pw_variant = variant;
+    return BD_OK;
+}
+
+int bd_set_fusion(bd_handle h, int32_t stem) {
+    if (!h) return fail(BD_EINVAL, "null handle");
+    h->fuse_stem = stem != 0;
     return BD_OK;
 }
 

@@ -142,6 +142,9 @@ BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int3
    1 = split-f16 (default): every f32 operand carried as hi + lo halves, three f16 MFMAs per product,
    f32 accumulate; same accuracy class as f32, ~5x the matrix-core rate. */
 BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
+/* stem != 0 (default): layers 1-2 (conv, depthwise, pointwise) run as one fused kernel in mode 1;
+   its time is reported in profile slot 3 (slots 1-2 stay empty).  0 = one kernel per op. */
+BD_API int bd_set_fusion(bd_handle h, int32_t stem);
 /* whi/wlo: [n][k] f16 halves of wt (wt ~= whi + wlo) */
 BD_API int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, const void* wlo_dev,
                                     const float* bias_dev, float* c_dev, int64_t m, int32_t n, int32_t k,

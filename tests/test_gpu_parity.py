@@ -265,3 +265,25 @@ def test_pointwise_gemm_every_tile_variant(mode, m, k, n):
         err = float((c.double() - ref).abs().max())
         assert err <= 4e-6 * scale + 1e-7, (mode, variant, err, scale)
     assert ran >= 3
+
+
+def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
+    """Layers 1-2 as one kernel must reproduce conv1 -> depthwise -> pointwise launch by launch."""
+    x = O.synthetic_audio(HOP * 37 + 1234, seed=55)
+    engine.set_pointwise_mode("f16x3")
+    try:
+        engine.set_fusion(True)
+        fused_tap = engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy()
+        fused = engine.predict(x, 0.96).numpy()
+        engine.set_fusion(False)
+        plain_tap = engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy()
+        plain = engine.predict(x, 0.96).numpy()
+    finally:
+        engine.set_fusion(True)
+    assert np.array_equal(fused_tap, plain_tap)
+    assert np.array_equal(fused, plain)
+    half_f = engine.predict(x, 0.48).numpy()          # overlapping windows read shared log-mel rows
+    engine.set_fusion(False)
+    half_p = engine.predict(x, 0.48).numpy()
+    engine.set_fusion(True)
+    assert np.array_equal(half_f, half_p)
