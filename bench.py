@@ -119,6 +119,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--per-slot", action="store_true", help="print per-kernel times to stderr")
+    ap.add_argument("--sep-variant", type=int, default=None, help="fused separable-layer kernel variant (tuning)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     args = ap.parse_args()
 
@@ -139,6 +140,8 @@ def main() -> None:
     engine = HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=local_rank)
     if args.group_windows:
         engine.set_group_windows(args.group_windows)
+    if args.sep_variant is not None:
+        engine.set_fusion(True, args.sep_variant)
     framehop_s = FRAMELENGTH_S * HOP_PROP
     hop, step = hop_samples(framehop_s), patch_step(framehop_s)
     n_samples = hop * WINDOWS_PER_BATCH                      # 15 728 640

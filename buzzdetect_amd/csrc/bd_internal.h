@@ -51,6 +51,8 @@ int launch_pointwise_variant(const float* A, const float* Wt, const float* bias,
                              int K, int variant, hipStream_t stream);
 int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* bias, float* C,
                                    long long M, int N, int K, int variant, hipStream_t stream);
+bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
+                            hipStream_t stream);
 void launch_stem(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
                  const SepLayer& L2, float* out, hipStream_t stream);
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,

@@ -287,6 +287,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* _
 // A[row l & 31][k = 8*(l >> 5) + j] and B[k = 8*(l >> 5) + j][col l & 31], j = 0..7.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
@@ -465,6 +467,540 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
     hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A, Wt,
                        bias, C, M, N, K, tiles_n);
+}
+
+// --------------------------------------------------------------------------- fused separable layer (stride 1)
+// depthwise 3x3 s1 + BN + ReLU  ->  pointwise 1x1 + BN + ReLU in one kernel (yamnet.py:52-74): the
+// depthwise output is produced 32 channels at a time straight into the split-f16 A tile of the GEMM
+// and never exists in HBM.  Per K stage a workgroup stages the input rows it needs (its BM output
+// positions plus one halo row above and below when the tile is a band of one window; whole windows
+// otherwise — either way ONE contiguous run of NHWC rows) as f32 into LDS, every thread computes
+// BM/32 depthwise outputs x 4 channels from it (9 ds_read_b128 each), splits them into hi/lo halves
+// and the MFMA phase proceeds exactly as in pointwise_f16x3_kernel.  Same arithmetic order as the
+// unfused kernels, so results are bit-identical to them.
+//
+// Requirements (checked by the launcher): stride 1, OH*OW % BM == 0 with BM % OW == 0 (band of rows)
+// or BM % (OH*OW) == 0 (whole windows); XPMAX >= rows staged.
+template <int BM, int BN, int WGM, int WGN, int XPMAX>
+__global__ __launch_bounds__(WGM* WGN * 64) void sep_s1_kernel(
+    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
+    float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n) {
+    constexpr int NT = WGM * WGN * 64;
+    static_assert(NT == 256, "thread mapping assumes 256 threads");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int LA = BM / 32;             // depthwise outputs (float4 of channels) per thread per stage
+    constexpr int XL = (XPMAX + 31) / 32;   // float4 loads of the input tile per thread per stage
+    constexpr int BCH = BN * 4 / NT;
+    static_assert(BM % 32 == 0 && (BN * 4) % NT == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* const Xs = reinterpret_cast<float*>(smem_raw);            // [XPMAX + 1][32]; row XPMAX stays zero
+    float* const Ws = Xs + (XPMAX + 1) * 32;                          // [10][32]: 9 depthwise taps + bias of the stage
+    char* const Ah = smem_raw + (XPMAX + 1) * 128 + 10 * 128;         // [2][A_BYTES]
+    char* const Al = Ah + 2 * A_BYTES;
+    char* const Bh = Al + 2 * A_BYTES;                                // [2][B_BYTES]
+    char* const Bl = Bh + 2 * B_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WGN, wc = wave % WGN;
+    const long long tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x % tiles_n;
+    const long long m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int P = H * W;
+
+    // ---- which input rows does this tile need?  [x_lo, x_lo + x_cnt) of the flattened [rows][K] input
+    long long x_lo;
+    int x_cnt;
+    if (P >= BM) {                                   // a band of BM / W output rows of one window
+        const long long n = m0 / P;
+        const int oh_a = (int)(m0 % P) / W;
+        const int oh_b = oh_a + BM / W;
+        const int r0 = oh_a > 0 ? oh_a - 1 : 0;
+        const int r1 = oh_b < H ? oh_b + 1 : H;
+        x_lo = (n * H + r0) * W;
+        x_cnt = (r1 - r0) * W;
+    } else {                                         // whole windows
+        x_lo = m0;
+        x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
+    }
+
+    const int lrow = tid >> 3;
+    const int lc4 = tid & 7;
+
+    // input-tile loads: row lrow + 32 j of the staged run (clamped; rows past x_cnt are never read back)
+    const float* xp[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        int r = lrow + 32 * j;
+        r = r < x_cnt ? r : x_cnt - 1;
+        xp[j] = X + (size_t)(x_lo + r) * K + lc4 * 4;
+    }
+    // depthwise outputs owned by this thread: tile rows lrow + 32 i.  The float offset into Xs of each of
+    // its 9 taps is fixed for the whole K loop; taps that fall outside the window point at the zero row.
+    int xtap[LA][9];
+    int a_st[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int ml = lrow + 32 * i;
+        long long m = m0 + ml;
+        m = m < M ? m : M - 1;
+        const int q = (int)(m % P);
+        const int oh = q / W, ow = q % W;
+        const int xc = (int)(m - x_lo);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = oh + kh - 1, iw = ow + kw - 1;
+                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                xtap[i][kh * 3 + kw] = (ok ? xc + (kh - 1) * W + (kw - 1) : XPMAX) * 32 + lc4 * 4;
+            }
+        a_st[i] = swz64(ml, lc4 >> 1) + (lc4 & 1) * 8;
+    }
+    if (tid < 8) *reinterpret_cast<float4*>(Xs + XPMAX * 32 + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // stage weights of the depthwise: thread t < 80 carries tap (t >> 3) (9 = bias) for channels 4 (t & 7)
+    const float* wsrc = tid < 72 ? dw_w + (size_t)(tid >> 3) * K + lc4 * 4 : dw_b + lc4 * 4;
+    const _Float16* bph[BCH];
+    const _Float16* bpl[BCH];
+    int b_st[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int id = tid + NT * i;
+        const int row = id >> 2, slot = id & 3;
+        bph[i] = Whi + (size_t)(n0 + row) * K + slot * 8;
+        bpl[i] = Wlo + (size_t)(n0 + row) * K + slot * 8;
+        b_st[i] = swz64(row, slot);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // native vector types: HIP's float4/uint4 structs end up as stack objects when carried around the loop
+    v4f rx[XL];
+    v4f rw = {0.f, 0.f, 0.f, 0.f};
+    v4u rbh[BCH], rbl[BCH];
+
+#define BD_SEP_LOAD(KOFF)                                                                                 \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < XL; ++j) rx[j] = *reinterpret_cast<const v4f*>(xp[j] + (KOFF)); \
+        if (tid < 80) rw = *reinterpret_cast<const v4f*>(wsrc + (KOFF));                               \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
+            rbh[i] = *reinterpret_cast<const v4u*>(bph[i] + (KOFF));                                    \
+            rbl[i] = *reinterpret_cast<const v4u*>(bpl[i] + (KOFF));                                    \
+        }                                                                                                 \
+    }
+#define BD_SEP_STORE(BUF)                                                                                 \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                    \
+            if (lrow + 32 * j < XPMAX) *reinterpret_cast<v4f*>(Xs + (lrow + 32 * j) * 32 + lc4 * 4) = rx[j]; \
+        if (tid < 80) *reinterpret_cast<v4f*>(Ws + tid * 4) = rw;                                      \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
+            *reinterpret_cast<v4u*>(Bh + (BUF) * B_BYTES + b_st[i]) = rbh[i];                           \
+            *reinterpret_cast<v4u*>(Bl + (BUF) * B_BYTES + b_st[i]) = rbl[i];                           \
+        }                                                                                                 \
+    }
+    // depthwise of the staged slab: Xs, Ws -> split-f16 A tile BUF
+#define BD_SEP_DW(BUF)                                                                                    \
+    {                                                                                                     \
+        float4 wt[9];                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(Ws + t * 32 + lc4 * 4); \
+        const float4 bias4 = *reinterpret_cast<const float4*>(Ws + 9 * 32 + lc4 * 4);                     \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
+            float4 a4 = bias4;                                                                            \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                               \
+                const float4 v = *reinterpret_cast<const float4*>(Xs + xtap[i][t]);                       \
+                a4.x = fmaf(v.x, wt[t].x, a4.x);                                                          \
+                a4.y = fmaf(v.y, wt[t].y, a4.y);                                                          \
+                a4.z = fmaf(v.z, wt[t].z, a4.z);                                                          \
+                a4.w = fmaf(v.w, wt[t].w, a4.w);                                                          \
+            }                                                                                             \
+            a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
+            f16x4 hi, lo;                                                                                 \
+            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
+            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
+            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
+            *reinterpret_cast<f16x4*>(Ah + (BUF) * A_BYTES + a_st[i]) = hi;                               \
+            *reinterpret_cast<f16x4*>(Al + (BUF) * A_BYTES + a_st[i]) = lo;                               \
+        }                                                                                                 \
+    }
+
+    const int frow = lane & 31;
+    const int fh = lane >> 5;
+#define BD_SEP_COMPUTE(BUF)                                                                               \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
+                const int off = (BUF) * A_BYTES + swz64(wr * WM + i * 32 + frow, 2 * s + fh);             \
+                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
+                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
+            }                                                                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
+                const int off = (BUF) * B_BYTES + swz64(wc * WN + j * 32 + frow, 2 * s + fh);             \
+                bh[j] = *reinterpret_cast<const f16x8*>(Bh + off);                                        \
+                bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                        \
+            }                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);     \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+
+    // Software pipeline: the global loads of stage k+2 are issued right after stage k+1 has been written
+    // to LDS, so they have a whole depthwise phase and a whole MFMA phase to land.
+    // (K >= 64, i.e. at least two stages, is guaranteed by the launcher; every load below is
+    // unconditional so that the staging registers never become a stack object.)
+    const int nk = K / 32;
+    BD_SEP_LOAD(0)
+    BD_SEP_STORE(0)
+    BD_SEP_LOAD(32)
+    __syncthreads();
+    BD_SEP_DW(0)
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        const int buf = kt & 1;
+        BD_SEP_COMPUTE(buf)
+        BD_SEP_STORE(buf ^ 1)               // stage kt+1 (loaded one iteration ago); Xs is free again
+        BD_SEP_LOAD((kt + 2) * 32)
+        __syncthreads();
+        BD_SEP_DW(buf ^ 1)
+        __syncthreads();
+    }
+    {                                       // kt == nk - 2: last stage to stage
+        const int buf = kt & 1;
+        BD_SEP_COMPUTE(buf)
+        BD_SEP_STORE(buf ^ 1)
+        __syncthreads();
+        BD_SEP_DW(buf ^ 1)
+        __syncthreads();
+    }
+    BD_SEP_COMPUTE((nk - 1) & 1)
+#undef BD_SEP_LOAD
+#undef BD_SEP_STORE
+#undef BD_SEP_DW
+#undef BD_SEP_COMPUTE
+
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * WN + j * 32 + frow;
+        const float b = pw_b[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long mb = m0 + wr * WM + i * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < M) Cout[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int XPMAX>
+void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
+    constexpr size_t lds = (size_t)(XPMAX + 1 + 10) * 128 + 2u * 2u * (BM + BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_s1_kernel<BM, BN, WGM, WGN, XPMAX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int tiles_n = L.cout / BN;
+    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL((sep_s1_kernel<BM, BN, WGM, WGN, XPMAX>), dim3((unsigned)tiles), dim3(256), lds, stream, X,
+                       L.dw_w, L.dw_b, static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo),
+                       L.pw_b, out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n);
+}
+
+// --------------------------------------------------------------------------- fused separable layer, wave-specialised
+// Same computation as sep_s1_kernel, restructured for the CU: a workgroup is 8 waves; waves 4-7 are
+// PRODUCERS (stage the f32 input slab, run the depthwise on the VALU, write the split-f16 A tile of
+// stage k+1) and waves 0-3 are CONSUMERS (stage the split-f16 weights, run the MFMAs of stage k).
+// Waves w and w+4 share a SIMD, so every SIMD has one matrix wave and one vector wave and the two
+// pipes overlap inside the workgroup; there is one barrier per 32-channel stage.
+//   stage k   consumers: B[(k+1)&1] <- regs (stage k+1), issue loads of stage k+2, MFMA(A[k&1], B[k&1])
+//             producers: Xs[k&1] <- regs (stage k+2), issue loads of stage k+3, depthwise(Xs[(k+1)&1]) -> A[(k+1)&1]
+// BM = 96 output positions (3 MFMA row tiles; 4 / 1 / 16 whole windows for the 6x4 / 12x8 / 3x2 maps, a
+// band of 6 rows for the 24x16 map), BN = 128 or 256 output channels.  Arithmetic order is that of the
+// unfused kernels: results are bit-identical.
+// ABL (timing-only ablations, results wrong): 1 = no global loads inside the K loop, 2 = no depthwise
+// arithmetic, 3 = no MFMAs.  0 = the real kernel.
+template <int BN, int XPMAX, int ABL>
+__global__ __launch_bounds__(512) void sep_ws_kernel(
+    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
+    float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n) {
+    constexpr int BM = 96;
+    constexpr int WN = BN / 4;               // consumer wave tile: 96 x WN
+    constexpr int TM = 3, TN = WN / 32;
+    constexpr int LA = 3;                    // depthwise outputs (x4 channels) per producer thread per stage
+    constexpr int XL = (XPMAX + 31) / 32;    // float4 slab loads per producer thread per stage
+    constexpr int BCH = BN * 4 / 256;        // 16-byte weight chunks per consumer thread per stage (each of hi / lo)
+    constexpr int XS_FLOATS = (XPMAX + 1) * 32;   // + the zero row
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* const Xs = reinterpret_cast<float*>(smem_raw);             // [2][XS_FLOATS]
+    float* const Ws = Xs + 2 * XS_FLOATS;                              // [2][10][32]
+    char* const Ah = reinterpret_cast<char*>(Ws + 2 * 320);            // [2][A_BYTES]
+    char* const Al = Ah + 2 * A_BYTES;
+    char* const Bh = Al + 2 * A_BYTES;                                 // [2][B_BYTES]
+    char* const Bl = Bh + 2 * B_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x % tiles_n;
+    const long long m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int nk = K / 32;                    // >= 4 (launcher)
+
+    if (wave >= 4) {
+        // ================================================================= producers
+        const int pt = tid - 256;
+        const int lrow = pt >> 3, lc4 = pt & 7;
+        const int P = H * W;
+        long long x_lo;
+        int x_cnt;
+        if (P >= BM) {
+            const long long n = m0 / P;
+            const int oh_a = (int)(m0 % P) / W;
+            const int oh_b = oh_a + BM / W;
+            const int r0 = oh_a > 0 ? oh_a - 1 : 0;
+            const int r1 = oh_b < H ? oh_b + 1 : H;
+            x_lo = (n * H + r0) * W;
+            x_cnt = (r1 - r0) * W;
+        } else {
+            x_lo = m0;
+            x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
+        }
+        const float* xp[XL];
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            int r = lrow + 32 * j;
+            r = r < x_cnt ? r : x_cnt - 1;
+            xp[j] = X + (size_t)(x_lo + r) * K + lc4 * 4;
+        }
+        int xtap[LA][9];
+        int a_st[LA];
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int ml = lrow + 32 * i;
+            long long m = m0 + ml;
+            m = m < M ? m : M - 1;
+            const int q = (int)(m % P);
+            const int oh = q / W, ow = q % W;
+            const int xc = (int)(m - x_lo);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = oh + kh - 1, iw = ow + kw - 1;
+                    const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    xtap[i][kh * 3 + kw] = (ok ? xc + (kh - 1) * W + (kw - 1) : XPMAX) * 32 + lc4 * 4;
+                }
+            a_st[i] = swz64(ml, lc4 >> 1) + (lc4 & 1) * 8;
+        }
+        if (pt < 16) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+        const float* wsrc = pt < 72 ? dw_w + (size_t)(pt >> 3) * K + lc4 * 4 : dw_b + lc4 * 4;
+
+        v4f rx[XL];
+        v4f rw = {0.f, 0.f, 0.f, 0.f};
+#define BD_P_LOAD(KOFF)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < XL; ++j) rx[j] = *reinterpret_cast<const v4f*>(xp[j] + (KOFF)); \
+        if (pt < 80) rw = *reinterpret_cast<const v4f*>(wsrc + (KOFF));                                   \
+    }
+#define BD_P_STORE(XB)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                    \
+            if (lrow + 32 * j < XPMAX)                                                                    \
+                *reinterpret_cast<v4f*>(Xs + (XB) * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = rx[j];  \
+        if (pt < 80) *reinterpret_cast<v4f*>(Ws + (XB) * 320 + pt * 4) = rw;                              \
+    }
+#define BD_P_DW(XB, AB)                                                                                   \
+    {                                                                                                     \
+        const float* xs_ = Xs + (XB) * XS_FLOATS;                                                         \
+        const float* ws_ = Ws + (XB) * 320 + lc4 * 4;                                                     \
+        v4f wt[9];                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * 32); \
+        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * 32);                                    \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
+            v4f a4 = bias4;                                                                               \
+            _Pragma("unroll") for (int t = 0; t < (ABL == 2 ? 1 : 9); ++t) {                              \
+                const v4f v = *reinterpret_cast<const v4f*>(xs_ + xtap[i][t]);                            \
+                a4.x = fmaf(v.x, wt[t].x, a4.x);                                                          \
+                a4.y = fmaf(v.y, wt[t].y, a4.y);                                                          \
+                a4.z = fmaf(v.z, wt[t].z, a4.z);                                                          \
+                a4.w = fmaf(v.w, wt[t].w, a4.w);                                                          \
+            }                                                                                             \
+            a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
+            f16x4 hi, lo;                                                                                 \
+            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
+            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
+            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
+            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
+            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
+        }                                                                                                 \
+    }
+        // prologue: slabs 0 and 1 resident, slab 2 in flight, A[0] computed
+        BD_P_LOAD(0)
+        BD_P_STORE(0)
+        BD_P_LOAD(32)
+        BD_P_STORE(1)
+        BD_P_LOAD(64)
+        __syncthreads();
+        BD_P_DW(0, 0)
+        __syncthreads();
+        int k = 0;
+        for (; k + 3 < nk; ++k) {             // stage k: everything in range
+            BD_P_STORE(k & 1)                 // slab k+2 (loaded during stage k-1)
+            if (ABL != 1) BD_P_LOAD((k + 3) * 32)
+            BD_P_DW((k + 1) & 1, (k + 1) & 1)
+            __syncthreads();
+        }
+        BD_P_STORE(k & 1)                     // k = nk-3: last slab (nk-1) goes in, nothing left to load
+        BD_P_DW((k + 1) & 1, (k + 1) & 1)
+        __syncthreads();
+        ++k;                                  // k = nk-2: depthwise of the last slab
+        BD_P_DW((k + 1) & 1, (k + 1) & 1)
+        __syncthreads();
+        __syncthreads();                      // k = nk-1: consumers' last MFMA stage
+#undef BD_P_LOAD
+#undef BD_P_STORE
+#undef BD_P_DW
+        return;
+    }
+
+    // ===================================================================== consumers
+    const int wc = wave;                      // column block of this wave
+    const _Float16* bph[BCH];
+    const _Float16* bpl[BCH];
+    int b_st[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id >> 2, slot = id & 3;
+        bph[i] = Whi + (size_t)(n0 + row) * K + slot * 8;
+        bpl[i] = Wlo + (size_t)(n0 + row) * K + slot * 8;
+        b_st[i] = swz64(row, slot);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    v4u rbh[BCH], rbl[BCH];
+#define BD_C_LOAD(KOFF)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
+            rbh[i] = *reinterpret_cast<const v4u*>(bph[i] + (KOFF));                                      \
+            rbl[i] = *reinterpret_cast<const v4u*>(bpl[i] + (KOFF));                                      \
+        }                                                                                                 \
+    }
+#define BD_C_STORE(BB)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
+            *reinterpret_cast<v4u*>(Bh + (BB) * B_BYTES + b_st[i]) = rbh[i];                              \
+            *reinterpret_cast<v4u*>(Bl + (BB) * B_BYTES + b_st[i]) = rbl[i];                              \
+        }                                                                                                 \
+    }
+    const int frow = lane & 31;
+    const int fh = lane >> 5;
+#define BD_C_MFMA(BUF)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
+                const int off = (BUF) * A_BYTES + swz64(i * 32 + frow, 2 * s + fh);                       \
+                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
+                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
+            }                                                                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
+                const int off = (BUF) * B_BYTES + swz64(wc * WN + j * 32 + frow, 2 * s + fh);             \
+                bh[j] = *reinterpret_cast<const f16x8*>(Bh + off);                                        \
+                bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                        \
+            }                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+                if (ABL == 3) {                                                                           \
+                    asm volatile("" ::"v"(al[i]), "v"(ah[i]), "v"(bl[j]), "v"(bh[j]));                    \
+                } else {                                                                                  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+    // prologue: weights of stage 0 resident, stage 1 in flight
+    BD_C_LOAD(0)
+    BD_C_STORE(0)
+    BD_C_LOAD(32)
+    __syncthreads();
+    __syncthreads();
+    int k = 0;
+    for (; k + 2 < nk; ++k) {
+        BD_C_STORE((k + 1) & 1)               // weights of stage k+1 (loaded during stage k-1)
+        if (ABL != 1) BD_C_LOAD((k + 2) * 32)
+        BD_C_MFMA(k & 1)
+        __syncthreads();
+    }
+    BD_C_STORE((k + 1) & 1)                   // k = nk-2
+    BD_C_MFMA(k & 1)
+    __syncthreads();
+    ++k;
+    BD_C_MFMA(k & 1)                          // k = nk-1
+    __syncthreads();
+#undef BD_C_LOAD
+#undef BD_C_STORE
+#undef BD_C_MFMA
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * WN + j * 32 + frow;
+        const float b = pw_b[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long mb = m0 + i * 32 + 4 * fh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < M) Cout[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+            }
+        }
+    }
+}
+
+template <int BN, int XPMAX, int ABL = 0>
+void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
+    constexpr size_t lds = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (96 + BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int tiles_n = L.cout / BN;
+    const long long tiles = ((M + 95) / 96) * tiles_n;
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w, L.dw_b,
+                       static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo), L.pw_b, out, M,
+                       L.cout, L.cin, L.h_out, L.w_out, tiles_n);
 }
 
 // --------------------------------------------------------------------------- fused stem
@@ -790,6 +1326,47 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
                                        stream);
     else
         launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
+}
+
+// Fused depthwise+pointwise for a stride-1 layer; returns false if the layer shape is not covered.
+bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
+                            hipStream_t stream) {
+    if (L.stride != 1 || windows <= 0 || L.cin < 64) return false;
+    const long long M = (long long)windows * L.h_out * L.w_out;
+    const int P = L.h_out * L.w_out;
+    // auto (measured on MI355X): the small deep maps (6x4, 3x2) run best on the wave-specialised kernel
+    // with 256-wide column tiles, the larger maps on the 4-wave kernel
+    if (variant <= 1 && (P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128) variant = 3;
+    if (variant >= 3 && L.cin >= 128) {                            // wave-specialised kernels (BM = 96)
+        if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 rows (+ halo rows)
+            launch_sep_ws<128, 128>(in, L, out, M, stream);
+            return true;
+        }
+        if (P == 96 || P == 24 || P == 6) {
+            if (variant >= 11 && variant <= 13 && L.cout % 256 == 0) {   // timing-only ablations
+                if (variant == 11) launch_sep_ws<256, 96, 1>(in, L, out, M, stream);
+                if (variant == 12) launch_sep_ws<256, 96, 2>(in, L, out, M, stream);
+                if (variant == 13) launch_sep_ws<256, 96, 3>(in, L, out, M, stream);
+                return true;
+            }
+            if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
+            else if (L.cout % 128 == 0) launch_sep_ws<128, 96>(in, L, out, M, stream);
+            else return false;
+            return true;
+        }
+        return false;
+    }
+    if (P == 384 && L.w_out == 16 && L.cout % 64 == 0) {          // layer 4: 24x16, bands of 8 rows
+        if (variant == 2 && L.cout % 128 == 0) launch_sep<128, 128, 2, 2, 160>(in, L, out, M, stream);
+        else launch_sep<128, 64, 2, 2, 160>(in, L, out, M, stream);
+        return true;
+    }
+    if ((P == 96 || P == 24 || P == 6) && L.cout % 128 == 0) {    // layers 6, 8-12, 14: whole windows, 96 rows
+        if (variant == 2 && L.cout % 256 == 0) launch_sep<96, 256, 1, 4, 96>(in, L, out, M, stream);
+        else launch_sep<96, 128, 1, 4, 96>(in, L, out, M, stream);
+        return true;
+    }
+    return false;
 }
 
 void launch_stem(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,

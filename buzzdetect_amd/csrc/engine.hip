@@ -47,6 +47,8 @@ struct bd_engine {
     int group_windows = kDefaultGroup;
     int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA
     bool fuse_stem = true;            // layers 1-2 as one kernel (split-f16 mode only)
+    bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
+    int sep_variant = 0;
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
     const float* conv1_w = nullptr;   // [9][32]
@@ -486,8 +488,8 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
     const int64_t group = g.n_windows < e->group_windows ? g.n_windows : e->group_windows;
     char* base = static_cast<char*>(ws);
     float* logmel = reinterpret_cast<float*>(base);
-    float* buf_a = reinterpret_cast<float*>(base + align_up(g.n_frames * BD_MEL_BANDS * 4, 256));
-    float* buf_b = reinterpret_cast<float*>(reinterpret_cast<char*>(buf_a) + align_up(group * kFloatsA * 4, 256));
+    float* const buf_a0 = reinterpret_cast<float*>(base + align_up(g.n_frames * BD_MEL_BANDS * 4, 256));
+    float* const buf_b0 = reinterpret_cast<float*>(reinterpret_cast<char*>(buf_a0) + align_up(group * kFloatsA * 4, 256));
 
     {
         Scope sc(e, stream, 0);
@@ -496,6 +498,11 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
     for (int64_t w0 = 0; w0 < g.n_windows; w0 += group) {
         const int gw = stop_stage >= 0 ? tap_windows : (int)(g.n_windows - w0 < group ? g.n_windows - w0 : group);
         const float* lm = logmel + w0 * step * BD_MEL_BANDS;
+        // buf_a holds the latest conv/pointwise output, buf_b the scratch side; the fused separable
+        // layers swap the two (everything after layer 2 fits the smaller buffer), so start each pass
+        // from the sized assignment: A = 98 304 floats/window, B = 49 152
+        float* buf_a = buf_a0;
+        float* buf_b = buf_b0;
         // layers 1-2 run as one fused kernel (split-f16 mode) unless a test taps inside them
         const bool fuse_stem = e->fuse_stem && e->pointwise_mode == 1 && (stop_stage < 0 || stop_stage >= 2);
         const float* last = buf_a;
@@ -520,6 +527,20 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         }
         for (int l = first_layer; l < 13 && !stopped; ++l) {
             const bd::SepLayer& L = e->sep[l];
+            // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
+            if (e->fuse_sep && e->pointwise_mode == 1 && stop_stage != 2 * l + 1) {
+                Scope sc(e, stream, 3 + 2 * l);
+                if (bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
+                    // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
+                    float* t = buf_a;
+                    buf_a = buf_b;
+                    buf_b = t;
+                    last = buf_a;
+                    last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
+                    if (stop_stage == 2 * l + 2) stopped = true;
+                    continue;
+                }
+            }
             {
                 Scope sc(e, stream, 2 + 2 * l);
                 bd::launch_depthwise(buf_a, buf_b, gw, L, stream);
@@ -596,9 +617,11 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
     return BD_OK;
 }
 
-int bd_set_fusion(bd_handle h, int32_t stem) {
+int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     h->fuse_stem = stem != 0;
+    h->fuse_sep = separable != 0;
+    h->sep_variant = separable > 1 ? separable : 0;
     return BD_OK;
 }
 

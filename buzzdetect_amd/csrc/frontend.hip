@@ -22,6 +22,11 @@ constexpr int kFramesPerWave = 4;
 constexpr int kGroupFrames = kWaves * kFramesPerWave;                         // 16 frames per pass
 constexpr int kGroupSamples = (kGroupFrames - 1) * BD_STFT_HOP + BD_STFT_WINDOW;  // 2800
 
+// Each wavefront works on its own z / mag tile, and LDS executes one wave's DS instructions in order,
+// so passes of a frame only need their LDS traffic drained and the compiler kept from reordering
+// across the point - not a workgroup barrier.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             dft4(u[0], u[1], u[2], u[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[4 * lane + r] = u[r];
-            __syncthreads();
+            wave_lds_sync();
 
             // ---- passes 2..4 (p = 4, 16, 64) ----
 #pragma unroll
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 const int j0 = ((lane - k) << 2) + k;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[j0 + p * r] = u[r];
-                __syncthreads();
+                wave_lds_sync();
             }
 
             // ---- split the packed transform into the real spectrum, take magnitudes ----
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 mag[k] = sqrtf(xr * xr + xi * xi);
             }
             if (lane == 0) mag[256] = fabsf(z[0].x - z[0].y);
-            __syncthreads();
+            wave_lds_sync();
 
             // ---- banded mel reduction + log ----
             float acc = 0.0f;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 if (j < band_len) acc = fmaf(mag[band_start + j], s_bw[j * BD_MEL_BANDS + lane], acc);
             }
             if (frame < n_frames) out[frame * BD_MEL_BANDS + lane] = logf(acc + 0.001f);
-            // the next frame's first write to z / mag happens after its own first barrier
+            wave_lds_sync();   // mag / z reads of this frame retire before the next frame overwrites them
         }
     }
 }

@@ -113,9 +113,9 @@ class HipEngine:
         """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class)."""
         _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1}[mode]))
 
-    def set_fusion(self, stem: bool) -> None:
-        """Fused conv1+depthwise+pointwise stem kernel on/off (on by default)."""
-        _lib.check(self._lib.bd_set_fusion(self._handle, 1 if stem else 0))
+    def set_fusion(self, stem: bool = True, separable=True) -> None:
+        """Fused stem kernel / fused depthwise+pointwise kernels on or off (both on by default)."""
+        _lib.check(self._lib.bd_set_fusion(self._handle, 1 if stem else 0, int(separable)))
 
     def set_pointwise_variant(self, layer: int, variant: int) -> None:
         _lib.check(self._lib.bd_set_pointwise_variant(self._handle, int(layer), int(variant)))

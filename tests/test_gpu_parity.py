@@ -272,18 +272,38 @@ def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
     x = O.synthetic_audio(HOP * 37 + 1234, seed=55)
     engine.set_pointwise_mode("f16x3")
     try:
-        engine.set_fusion(True)
+        engine.set_fusion(True, False)
         fused_tap = engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy()
         fused = engine.predict(x, 0.96).numpy()
-        engine.set_fusion(False)
+        engine.set_fusion(False, False)
         plain_tap = engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy()
         plain = engine.predict(x, 0.96).numpy()
+        assert np.array_equal(fused_tap, plain_tap)
+        assert np.array_equal(fused, plain)
+        engine.set_fusion(True, False)
+        half_f = engine.predict(x, 0.48).numpy()          # overlapping windows read shared log-mel rows
+        engine.set_fusion(False, False)
+        half_p = engine.predict(x, 0.48).numpy()
+        assert np.array_equal(half_f, half_p)
     finally:
-        engine.set_fusion(True)
-    assert np.array_equal(fused_tap, plain_tap)
-    assert np.array_equal(fused, plain)
-    half_f = engine.predict(x, 0.48).numpy()          # overlapping windows read shared log-mel rows
-    engine.set_fusion(False)
-    half_p = engine.predict(x, 0.48).numpy()
-    engine.set_fusion(True)
-    assert np.array_equal(half_f, half_p)
+        engine.set_fusion(True, True)
+
+
+@pytest.mark.parametrize("windows", [1, 3, 37, 300])
+def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
+    """Depthwise-inside-GEMM (layers 4, 6, 8-12, 14) vs depthwise kernel + GEMM kernel: every pointwise
+    output of those layers, and the logits, must match bit for bit — including partial last tiles."""
+    x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
+    engine.set_pointwise_mode("f16x3")
+    try:
+        for variant in (1, 2, 3, 4):
+            engine.set_fusion(False, False)
+            plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 14, 22, 26)}
+            plain_logits = engine.predict(x, 0.96).numpy()
+            engine.set_fusion(False, variant)
+            for st, ref in plain.items():
+                got = engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy()
+                assert np.array_equal(got, ref), (variant, st)
+            assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
+    finally:
+        engine.set_fusion(True, True)

@@ -13,6 +13,10 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
+    mm = re.search(r"\d+([a-z0-9_]+_kernel)(?:I((?:Li\d+E)+)E)?", name) if name.startswith("_ZN2bd") else None
+    if mm:   # mangled (the demangler does not know _Float16): rebuild name<args>
+        args = re.findall(r"Li(\d+)E", mm.group(2) or "")
+        return mm.group(1) + ("<" + ", ".join(args) + ">" if args else "")
     m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
@@ -30,7 +34,7 @@ def main():
             name = r["Kernel_Name"]
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             total += dur
-            if "bd::" not in name:
+            if "bd::" not in name and "_ZN2bd" not in name:
                 continue
             key = (short(name), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r.get("Grid_Size_Y", 1)),
                    r["VGPR_Count"], r["Accum_VGPR_Count"], r["LDS_Block_Size"])
