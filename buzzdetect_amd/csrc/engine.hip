@@ -34,8 +34,12 @@ constexpr int kDefaultGroup = 1024;
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// One event is recorded after every launch; the time between consecutive events on the stream is
+// charged to the later one's slot (slot < 0 = the marker at the head of a call).  Event pairs around
+// each launch leave the gaps between pairs unattributed, and on this stack they under-read some
+// kernels by tens of microseconds against rocprofv3.
 struct Event2 {
-    hipEvent_t a, b;
+    hipEvent_t ev;
     int slot;
 };
 
@@ -66,30 +70,27 @@ struct bd_engine {
 
 namespace {
 
-// Time one launch with a pair of events on the caller's stream when profiling is on.
+// Records the marker event of one launch (or, with slot < 0, the head marker of a call).
 struct Scope {
     bd_engine* e;
     hipStream_t s;
-    Event2 ev;
+    int slot;
     bool on;
-    Scope(bd_engine* e_, hipStream_t s_, int slot) : e(e_), s(s_), on(e_->profiling) {
-        if (!on) return;
+    static void mark(bd_engine* e, hipStream_t s, int slot) {
+        Event2 ev;
         if (!e->free_events.empty()) {
             ev = e->free_events.back();
             e->free_events.pop_back();
-        } else {
-            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
-                on = false;
-                return;
-            }
+        } else if (hipEventCreate(&ev.ev) != hipSuccess) {
+            return;
         }
         ev.slot = slot;
-        (void)hipEventRecord(ev.a, s);
-    }
-    ~Scope() {
-        if (!on) return;
-        (void)hipEventRecord(ev.b, s);
+        (void)hipEventRecord(ev.ev, s);
         e->pending.push_back(ev);
+    }
+    Scope(bd_engine* e_, hipStream_t s_, int slot_) : e(e_), s(s_), slot(slot_), on(e_->profiling) {}
+    ~Scope() {
+        if (on) mark(e, s, slot);
     }
 };
 
@@ -402,14 +403,8 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
 int bd_destroy(bd_handle h) {
     if (!h) return BD_OK;
     (void)hipSetDevice(h->device);
-    for (auto& ev : h->pending) {
-        (void)hipEventDestroy(ev.a);
-        (void)hipEventDestroy(ev.b);
-    }
-    for (auto& ev : h->free_events) {
-        (void)hipEventDestroy(ev.a);
-        (void)hipEventDestroy(ev.b);
-    }
+    for (auto& ev : h->pending) (void)hipEventDestroy(ev.ev);
+    for (auto& ev : h->free_events) (void)hipEventDestroy(ev.ev);
     if (h->d_pool) (void)hipFree(h->d_pool);
     if (h->d_tables) (void)hipFree(h->d_tables);
     delete h;
@@ -441,6 +436,7 @@ int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t ho
     const int rc = geometry(n_samples, hop_samples, 0, &g);
     if (rc < 0) return rc;
     BD_HIP(hipSetDevice(h->device));
+    if (h->profiling) Scope::mark(h, (hipStream_t)stream, -1);
     {
         Scope sc(h, (hipStream_t)stream, 0);
         bd::launch_logmel(pcm_dev, n_samples, g.n_frames, logmel_dev, h->d_tables, (hipStream_t)stream);
@@ -491,6 +487,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
     float* const buf_a0 = reinterpret_cast<float*>(base + align_up(g.n_frames * BD_MEL_BANDS * 4, 256));
     float* const buf_b0 = reinterpret_cast<float*>(reinterpret_cast<char*>(buf_a0) + align_up(group * kFloatsA * 4, 256));
 
+    if (e->profiling) Scope::mark(e, stream, -1);
     {
         Scope sc(e, stream, 0);
         bd::launch_logmel(pcm, n, g.n_frames, logmel, e->d_tables, stream);
@@ -528,18 +525,17 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         for (int l = first_layer; l < 13 && !stopped; ++l) {
             const bd::SepLayer& L = e->sep[l];
             // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
-            if (e->fuse_sep && e->pointwise_mode == 1 && stop_stage != 2 * l + 1) {
-                Scope sc(e, stream, 3 + 2 * l);
-                if (bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
-                    // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
-                    float* t = buf_a;
-                    buf_a = buf_b;
-                    buf_b = t;
-                    last = buf_a;
-                    last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
-                    if (stop_stage == 2 * l + 2) stopped = true;
-                    continue;
-                }
+            if (e->fuse_sep && e->pointwise_mode == 1 && stop_stage != 2 * l + 1 &&
+                bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
+                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
+                float* t = buf_a;
+                buf_a = buf_b;
+                buf_b = t;
+                last = buf_a;
+                last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
+                if (stop_stage == 2 * l + 2) stopped = true;
+                continue;
             }
             {
                 Scope sc(e, stream, 2 + 2 * l);
@@ -652,14 +648,17 @@ int bd_profile_enable(bd_handle h, int32_t on) {
 int bd_profile_read(bd_handle h, double* ms, int64_t* launches, int32_t slots) {
     if (!h || !ms || !launches || slots < BD_PROFILE_SLOTS) return fail(BD_EINVAL, "bd_profile_read: bad argument");
     BD_HIP(hipSetDevice(h->device));
-    for (auto& ev : h->pending) {
-        BD_HIP(hipEventSynchronize(ev.b));
-        float t = 0.f;
-        BD_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
-        h->ms[ev.slot] += t;
-        h->launches[ev.slot] += 1;
-        h->free_events.push_back(ev);
+    for (size_t i = 0; i < h->pending.size(); ++i) {
+        const Event2& ev = h->pending[i];
+        BD_HIP(hipEventSynchronize(ev.ev));
+        if (ev.slot >= 0 && i > 0) {
+            float t = 0.f;
+            BD_HIP(hipEventElapsedTime(&t, h->pending[i - 1].ev, ev.ev));
+            h->ms[ev.slot] += t;
+            h->launches[ev.slot] += 1;
+        }
     }
+    for (auto& ev : h->pending) h->free_events.push_back(ev);
     h->pending.clear();
     for (int i = 0; i < BD_PROFILE_SLOTS; ++i) {
         ms[i] = h->ms[i];

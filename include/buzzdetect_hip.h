@@ -154,7 +154,8 @@ BD_API int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, con
                                     int32_t variant, void* stream);
 
 /* ---- per-stage timing (HIP events on the caller's stream) ----
-   With profiling on, every kernel launch of bd_predict/bd_embed is bracketed by events.
+   With profiling on, one event is recorded at the head of every bd_predict/bd_embed call and one after
+   each kernel launch; the interval between consecutive events is charged to the later launch's slot.
    bd_profile_read synchronises on them and accumulates per slot: 0 = front end, 1 = conv1,
    2..27 = stages 1..26 (depthwise/pointwise alternating), 28 = pool+head.
    ms[i] += elapsed, launches[i] += count; returns the number of slots (29). */
