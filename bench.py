@@ -148,6 +148,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--per-slot", action="store_true", help="print per-kernel times to stderr")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="analyzer streams per GPU: steps are dealt round-robin to this many engines, each on "
+                         "its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253)")
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable-layer kernel variant (tuning)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     args = ap.parse_args()
@@ -166,11 +169,15 @@ def main() -> None:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
-    engine = HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=local_rank)
-    if args.group_windows:
-        engine.set_group_windows(args.group_windows)
-    if args.sep_variant is not None:
-        engine.set_fusion(True, args.sep_variant)
+    engines = [HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=local_rank)
+               for _ in range(max(1, args.streams))]
+    streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in engines[1:]]
+    engine = engines[0]
+    for e in engines:
+        if args.group_windows:
+            e.set_group_windows(args.group_windows)
+        if args.sep_variant is not None:
+            e.set_fusion(True, args.sep_variant)
     framehop_s = FRAMELENGTH_S * HOP_PROP
     hop, step = hop_samples(framehop_s), patch_step(framehop_s)
     n_samples = hop * WINDOWS_PER_BATCH                      # 15 728 640
@@ -181,8 +188,15 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def one_step(i: int):
-        res = engine.predict(batches[i % len(batches)], framehop_s)
-        gathered = sharding.gather_rows(res.tensor, dst=0) if world > 1 else None
+        j = i % len(engines)
+        with torch.cuda.stream(streams[j]):
+            res = engines[j].predict(batches[i % len(batches)], framehop_s)
+        gathered = None
+        if world > 1:             # one communicator: collectives are issued in step order on stream 0
+            streams[0].wait_stream(streams[j])
+            with torch.cuda.stream(streams[0]):
+                gathered = sharding.gather_rows(res.tensor, dst=0)
+                res.tensor.record_stream(streams[0])
         return res, gathered
 
     def fence():
@@ -195,11 +209,14 @@ def main() -> None:
     for i in range(args.warmup):
         one_step(i)
     fence()
-    def timed_region(steps: int) -> float:
+    def timed_region(steps: int, single_stream: bool = False) -> float:
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
-            one_step(i)
+            if single_stream:     # per-kernel event timing needs the kernels of one stream back to back
+                engine.predict(batches[i % len(batches)], framehop_s)
+            else:
+                one_step(i)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -219,7 +236,7 @@ def main() -> None:
     if events_on:
         engine.profile_read()                                # drop anything recorded so far
         engine.profile_enable(True)
-        elapsed_events = timed_region(args.steps)
+        elapsed_events = timed_region(args.steps, single_stream=True)
         engine.profile_enable(False)
         ms, launches = engine.profile_read()
 
@@ -239,7 +256,7 @@ def main() -> None:
                                    "+ model_general_v3 head; embedder weights seeded synthetic in the reference "
                                    "layout, head weights real",
                        "windows_per_step_per_gpu": WINDOWS_PER_BATCH, "samples_per_step_per_gpu": n_samples,
-                       "hop_samples": hop, "patch_step": step, "sharding": "round-robin batches per rank, "
+                       "hop_samples": hop, "patch_step": step, "analyzer_streams": len(engines), "sharding": "round-robin batches per rank, "
                        "RCCL gather of [W,13] logits to rank 0 each step" if world > 1 else "single GPU",
                        "timing": "value from K clean steps; per-kernel HIP-event times from a second identical K-step region"},
         }

@@ -857,12 +857,29 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
             *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
         }                                                                                                 \
     }
-        // prologue: slabs 0 and 1 resident, slab 2 in flight, A[0] computed
-        BD_P_LOAD(0)
-        BD_P_STORE(0)
-        BD_P_LOAD(32)
-        BD_P_STORE(1)
-        BD_P_LOAD(64)
+        // prologue: slabs 0 and 1 resident, slab 2 in flight, A[0] computed.  All three loads are issued
+        // before the first store so the workgroup pays the HBM latency once, not three times.
+        {
+            v4f r0[XL], r1[XL];
+            v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < XL; ++j) r0[j] = *reinterpret_cast<const v4f*>(xp[j]);
+            if (pt < 80) w0 = *reinterpret_cast<const v4f*>(wsrc);
+#pragma unroll
+            for (int j = 0; j < XL; ++j) r1[j] = *reinterpret_cast<const v4f*>(xp[j] + 32);
+            if (pt < 80) w1 = *reinterpret_cast<const v4f*>(wsrc + 32);
+            BD_P_LOAD(64)
+#pragma unroll
+            for (int j = 0; j < XL; ++j)
+                if (lrow + 32 * j < XPMAX) {
+                    *reinterpret_cast<v4f*>(Xs + (lrow + 32 * j) * 32 + lc4 * 4) = r0[j];
+                    *reinterpret_cast<v4f*>(Xs + XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = r1[j];
+                }
+            if (pt < 80) {
+                *reinterpret_cast<v4f*>(Ws + pt * 4) = w0;
+                *reinterpret_cast<v4f*>(Ws + 320 + pt * 4) = w1;
+            }
+        }
         __syncthreads();
         BD_P_DW(0, 0)
         __syncthreads();
@@ -948,10 +965,21 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
             }                                                                                             \
         }                                                                                                 \
     }
-    // prologue: weights of stage 0 resident, stage 1 in flight
-    BD_C_LOAD(0)
-    BD_C_STORE(0)
-    BD_C_LOAD(32)
+    // prologue: weights of stage 0 resident, stage 1 in flight (both loads issued before the store)
+    {
+        v4u h0[BCH], l0[BCH];
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            h0[i] = *reinterpret_cast<const v4u*>(bph[i]);
+            l0[i] = *reinterpret_cast<const v4u*>(bpl[i]);
+        }
+        BD_C_LOAD(32)
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            *reinterpret_cast<v4u*>(Bh + b_st[i]) = h0[i];
+            *reinterpret_cast<v4u*>(Bl + b_st[i]) = l0[i];
+        }
+    }
     __syncthreads();
     __syncthreads();
     int k = 0;
