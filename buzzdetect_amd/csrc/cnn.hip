@@ -292,6 +292,24 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
+// Epilogue of a 32x32 tile accumulated TRANSPOSED (weights fed as the MFMA "A" operand, activations as
+// "B"): lane l then owns output row m = l & 31 and, per register quad g, the four consecutive channels
+// n = 8 g + 4 (l >> 5) + 0..3 - one 16-byte store per quad instead of four 4-byte ones.  Products and
+// their k order are those of the untransposed form.
+__device__ __forceinline__ void store_tile_t(const f32x16& acc, const float* __restrict__ bias_n, float* crow,
+                                             bool live, int half) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(bias_n + 8 * g + 4 * half);
+        float4 v;
+        v.x = fmaxf(acc[4 * g + 0] + b.x, 0.0f);
+        v.y = fmaxf(acc[4 * g + 1] + b.y, 0.0f);
+        v.z = fmaxf(acc[4 * g + 2] + b.z, 0.0f);
+        v.w = fmaxf(acc[4 * g + 3] + b.w, 0.0f);
+        if (live) *reinterpret_cast<float4*>(crow + 8 * g + 4 * half) = v;
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
     const float* __restrict__ A, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
@@ -395,9 +413,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
                 bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                       \
             }                                                                                            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);    \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);    \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);    \
             }                                                                                            \
         }                                                                                                \
     }
@@ -418,19 +436,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
 #undef BD_F16_STORE
 #undef BD_F16_COMPUTE
 
+    // transposed accumulators: lane owns row m0 + .. + (lane & 31), 16-byte stores (store_tile_t)
     const int half = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * WN + j * 32 + frow;
-        const float b = bias[n];
+    for (int i = 0; i < TM; ++i) {
+        const long long m = m0 + wr * WM + i * 32 + frow;
+        float* crow = C + (size_t)(m < M ? m : 0) * N;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long long mb = m0 + wr * WM + i * 32 + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M) C[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
-            }
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + wc * WN + j * 32;
+            store_tile_t(acc[i][j], bias + nb, crow + nb, m < M, half);
         }
     }
 }
@@ -651,9 +666,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void sep_s1_kernel(
                 bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                        \
             }                                                                                             \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);     \
             }                                                                                             \
         }                                                                                                 \
     }
@@ -695,17 +710,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void sep_s1_kernel(
 
     const int half = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * WN + j * 32 + frow;
-        const float b = pw_b[n];
+    for (int i = 0; i < TM; ++i) {
+        const long long m = m0 + wr * WM + i * 32 + frow;
+        float* crow = Cout + (size_t)(m < M ? m : 0) * N;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long long mb = m0 + wr * WM + i * 32 + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M) Cout[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
-            }
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + wc * WN + j * 32;
+            store_tile_t(acc[i][j], pw_b + nb, crow + nb, m < M, half);
         }
     }
 }
@@ -738,7 +749,8 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // band of 6 rows for the 24x16 map), BN = 128 or 256 output channels.  Arithmetic order is that of the
 // unfused kernels: results are bit-identical.
 // ABL (timing-only ablations, results wrong): 1 = no global loads inside the K loop, 2 = no depthwise
-// arithmetic, 3 = no MFMAs.  0 = the real kernel.
+// arithmetic, 3 = no MFMAs, 4 = producers only keep the barriers, 5 = consumers only keep the barriers,
+// 6 = no C store.  0 = the real kernel.
 template <int BN, int XPMAX, int ABL>
 __global__ __launch_bounds__(512) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
@@ -885,9 +897,11 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
         __syncthreads();
         int k = 0;
         for (; k + 3 < nk; ++k) {             // stage k: everything in range
-            BD_P_STORE(k & 1)                 // slab k+2 (loaded during stage k-1)
-            if (ABL != 1) BD_P_LOAD((k + 3) * 32)
-            BD_P_DW((k + 1) & 1, (k + 1) & 1)
+            if (ABL != 4) {
+                BD_P_STORE(k & 1)             // slab k+2 (loaded during stage k-1)
+                if (ABL != 1) BD_P_LOAD((k + 3) * 32)
+                BD_P_DW((k + 1) & 1, (k + 1) & 1)
+            }
             __syncthreads();
         }
         BD_P_STORE(k & 1)                     // k = nk-3: last slab (nk-1) goes in, nothing left to load
@@ -900,9 +914,7 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
 #undef BD_P_LOAD
 #undef BD_P_STORE
 #undef BD_P_DW
-        return;
-    }
-
+    } else {
     // ===================================================================== consumers
     const int wc = wave;                      // column block of this wave
     const _Float16* bph[BCH];
@@ -984,9 +996,11 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     __syncthreads();
     int k = 0;
     for (; k + 2 < nk; ++k) {
-        BD_C_STORE((k + 1) & 1)               // weights of stage k+1 (loaded during stage k-1)
-        if (ABL != 1) BD_C_LOAD((k + 2) * 32)
-        BD_C_MFMA(k & 1)
+        if (ABL != 5) {
+            BD_C_STORE((k + 1) & 1)           // weights of stage k+1 (loaded during stage k-1)
+            if (ABL != 1) BD_C_LOAD((k + 2) * 32)
+            BD_C_MFMA(k & 1)
+        }
         __syncthreads();
     }
     BD_C_STORE((k + 1) & 1)                   // k = nk-2
@@ -999,25 +1013,50 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
 #undef BD_C_STORE
 #undef BD_C_MFMA
 
+    // bias + ReLU into an f32 tile in LDS (every stage buffer is dead after the last barrier)
+    float* const Ct = reinterpret_cast<float*>(smem_raw);          // [96][BN + 4]
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * WN + j * 32 + frow;
-        const float b = pw_b[n];
+        const int nl = wc * WN + j * 32 + frow;
+        const float b = pw_b[n0 + nl];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long long mb = m0 + i * 32 + 4 * fh;
+            const int mb = i * 32 + 4 * fh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M) Cout[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+                const int ml = mb + (r & 3) + 8 * (r >> 2);
+                if (ABL == 6) {
+                    if (acc[i][j][r] == 12345.678f) Ct[ml * (BN + 4) + nl] = b;
+                } else {
+                    Ct[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + b, 0.0f);
+                }
             }
+        }
+    }
+    }   // consumers
+
+    // ---- all 8 waves: tile -> HBM as whole rows, 16 bytes per lane ----
+    __syncthreads();
+    if (ABL != 6) {
+        const float* Ct = reinterpret_cast<const float*>(smem_raw);
+        constexpr int C4 = BN / 4;                                   // float4 per tile row
+#pragma unroll
+        for (int it = 0; it < 96 * C4 / 512; ++it) {
+            const int id = tid + 512 * it;
+            const int ml = id / C4, c4 = id % C4;
+            const long long m = m0 + ml;
+            if (m < M)
+                *reinterpret_cast<v4f*>(Cout + (size_t)m * N + n0 + c4 * 4) =
+                    *reinterpret_cast<const v4f*>(Ct + ml * (BN + 4) + c4 * 4);
         }
     }
 }
 
 template <int BN, int XPMAX, int ABL = 0>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
-    constexpr size_t lds = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (96 + BN) * 64;
+    constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (96 + BN) * 64;
+    constexpr size_t lds_tile = 96u * (BN + 4) * 4;
+    constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL>),
@@ -1195,7 +1234,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
         }
     }
 
-    // ---- phase E: bias + ReLU, store the 128 x 64 block (rows are consecutive NHWC positions) ----
+    // ---- phase E: bias + ReLU, store the 128 x 64 block (rows are consecutive NHWC positions).
+    // With 64-channel rows the untransposed map (a wave instruction writes two full 128-byte row halves)
+    // measured faster than 16-byte stores (151 vs 168 us per 1024 windows). ----
     float* dst = out + ((size_t)win * 48 + oh0) * 32 * 64;
     const int n = wc * 32 + frow;
     const float b = pw_b[n];
@@ -1371,10 +1412,13 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
-            if (variant >= 11 && variant <= 13 && L.cout % 256 == 0) {   // timing-only ablations
+            if (variant >= 11 && variant <= 16 && L.cout % 256 == 0) {   // timing-only ablations
                 if (variant == 11) launch_sep_ws<256, 96, 1>(in, L, out, M, stream);
                 if (variant == 12) launch_sep_ws<256, 96, 2>(in, L, out, M, stream);
                 if (variant == 13) launch_sep_ws<256, 96, 3>(in, L, out, M, stream);
+                if (variant == 14) launch_sep_ws<256, 96, 4>(in, L, out, M, stream);
+                if (variant == 15) launch_sep_ws<256, 96, 5>(in, L, out, M, stream);
+                if (variant == 16) launch_sep_ws<256, 96, 6>(in, L, out, M, stream);
                 return true;
             }
             if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
