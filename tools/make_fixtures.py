@@ -168,6 +168,18 @@ def golden_vectors(ref: str, out: str) -> None:
             {"precision": p, "threshold": float(calculate_threshold("model_general_v3", p))}
             for p in (0.90, 0.95, 0.99, 0.80, 0.975)]
 
+        # manifest reconciliation (src/pipeline/manifest.py:13-85)
+        from src.pipeline.manifest import build_manifest, diff_manifests
+        m_act = build_manifest("model_general_v3", 1.0, None, ["ins_buzz", "ambient_rain"])
+        m_act2 = build_manifest("model_general_v3", 1.0, None, ["ambient_rain", "ins_buzz"])
+        m_act3 = build_manifest("model_general_v3", 0.5, None, ["ins_buzz", "mech_auto"])
+        m_det = build_manifest("model_general_v3", 1.0, 0.95, ["ins_buzz"])
+        g["manifest"] = {
+            "activations": m_act, "activations_reordered": m_act2, "other": m_act3, "detections": m_det,
+            "diff_same": diff_manifests(m_act, m_act2), "diff_other": diff_manifests(m_act, m_act3),
+            "diff_mode": diff_manifests(m_act, m_det),
+        }
+
         # front-end constants (embedders/yamnet/params.py:26-51)
         p = Params()
         g["params"] = {k: getattr(p, k) for k in (
