@@ -48,6 +48,11 @@ PROTOTYPES = {
     "bd_num_frames": (C.c_int64, [C.c_int64, C.c_int32]),
     "bd_num_windows": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "bd_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
+    "bd_resample_length": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "bd_resample_taps": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "bd_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                              C.c_void_p]),
     "bd_frontend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "bd_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "bd_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,

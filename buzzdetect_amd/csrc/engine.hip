@@ -60,6 +60,9 @@ struct bd_engine {
     bd::SepLayer sep[13];
     const float* head_wt = nullptr;   // [n_classes][1024]
     const float* head_b = nullptr;
+    // resampler: taps of the last (up, down) pair used, kept on the device
+    int rs_up = 0, rs_down = 0, rs_half = 0;
+    float* d_taps = nullptr;
     // profiling
     bool profiling = false;
     std::vector<Event2> pending;
@@ -126,6 +129,52 @@ int geometry(int64_t n, int32_t hop, int32_t step, Geometry* g) {
     else
         g->n_windows = 0;
     return BD_OK;
+}
+
+// ---- resampler design: scipy.signal.resample_poly's default filter, restated ----
+//   half = 10 * max(up, down); h = firwin(2 half + 1, 1 / max(up, down), window = ('kaiser', 5.0)) * up
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= (x / (2.0 * k)) * (x / (2.0 * k));
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+void rational_ratio(int32_t rate_in, int32_t rate_out, int* up, int* down) {
+    int a = rate_out, b = rate_in;
+    while (b) {
+        const int t = a % b;
+        a = b;
+        b = t;
+    }
+    *up = rate_out / a;
+    *down = rate_in / a;
+}
+
+std::vector<float> design_taps(int up, int down, int* half_out) {
+    const int max_rate = up > down ? up : down;
+    const int half = 10 * max_rate;
+    const int n = 2 * half + 1;
+    const double cutoff = 1.0 / max_rate;          // as a fraction of Nyquist
+    const double beta = 5.0;
+    std::vector<double> h(n);
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double m = i - half;
+        const double x = cutoff * m;
+        const double sinc = m == 0 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
+        const double r = 2.0 * i / (n - 1) - 1.0;
+        const double w = bessel_i0(beta * std::sqrt(1.0 - r * r)) / bessel_i0(beta);
+        h[i] = cutoff * sinc * w;
+        sum += h[i];
+    }
+    std::vector<float> out(n);
+    for (int i = 0; i < n; ++i) out[i] = (float)(h[i] / sum * up);
+    *half_out = half;
+    return out;
 }
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
@@ -407,6 +456,7 @@ int bd_destroy(bd_handle h) {
     for (auto& ev : h->free_events) (void)hipEventDestroy(ev.ev);
     if (h->d_pool) (void)hipFree(h->d_pool);
     if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->d_taps) (void)hipFree(h->d_taps);
     delete h;
     return BD_OK;
 }
@@ -441,6 +491,55 @@ int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t ho
         Scope sc(h, (hipStream_t)stream, 0);
         bd::launch_logmel(pcm_dev, n_samples, g.n_frames, logmel_dev, h->d_tables, (hipStream_t)stream);
     }
+    BD_HIP(hipGetLastError());
+    return BD_OK;
+}
+
+int64_t bd_resample_length(int64_t n_in, int32_t rate_in, int32_t rate_out) {
+    if (n_in < 0 || rate_in <= 0 || rate_out <= 0) return fail(BD_EINVAL, "bd_resample_length: bad argument");
+    int up, down;
+    rational_ratio(rate_in, rate_out, &up, &down);
+    return (n_in * up + down - 1) / down;          // ceil(n_in * up / down), as resample_poly
+}
+
+int bd_resample_taps(int32_t rate_in, int32_t rate_out, float* taps_host, int64_t capacity, int32_t* up, int32_t* down,
+                     int32_t* half) {
+    if (rate_in <= 0 || rate_out <= 0 || !up || !down || !half) return fail(BD_EINVAL, "bd_resample_taps: bad argument");
+    int u, d, hl;
+    rational_ratio(rate_in, rate_out, &u, &d);
+    const std::vector<float> t = design_taps(u, d, &hl);
+    *up = u;
+    *down = d;
+    *half = hl;
+    if (taps_host) {
+        if (capacity < (int64_t)t.size()) return fail(BD_EINVAL, "bd_resample_taps: buffer too small");
+        std::memcpy(taps_host, t.data(), t.size() * sizeof(float));
+    }
+    return (int)t.size();
+}
+
+int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels, int32_t rate_in, int32_t rate_out,
+                float* out_dev, void* stream) {
+    if (!h || !out_dev || (!in_dev && n_in > 0)) return fail(BD_EINVAL, "bd_resample: null argument");
+    if (n_in < 0 || channels <= 0 || rate_in <= 0 || rate_out <= 0) return fail(BD_EINVAL, "bd_resample: bad size");
+    if (misaligned(in_dev) || misaligned(out_dev)) return fail(BD_EINVAL, "bd_resample: pointers need 16-byte alignment");
+    int up, down;
+    rational_ratio(rate_in, rate_out, &up, &down);
+    if (up > 4096 || down > 4096) return fail(BD_EINVAL, "bd_resample: rate ratio does not reduce to <= 4096");
+    BD_HIP(hipSetDevice(h->device));
+    if (h->rs_up != up || h->rs_down != down) {           // (re)design; the copy is stream-ordered
+        int half;
+        const std::vector<float> taps = design_taps(up, down, &half);
+        if (h->d_taps) BD_HIP(hipFree(h->d_taps));
+        h->d_taps = nullptr;
+        BD_HIP(hipMalloc(&h->d_taps, taps.size() * sizeof(float)));
+        BD_HIP(hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->rs_up = up;
+        h->rs_down = down;
+        h->rs_half = half;
+    }
+    const int64_t n_out = (n_in * up + down - 1) / down;
+    bd::launch_resample(in_dev, n_in, channels, h->d_taps, h->rs_half, up, down, out_dev, n_out, (hipStream_t)stream);
     BD_HIP(hipGetLastError());
     return BD_OK;
 }

@@ -163,6 +163,28 @@ class HipEngine:
             t = t.clone()
         return t
 
+    # ------------------------------------------------------------------ streamer stage
+    def resample(self, samples, rate_in: int, rate_out: int = SAMPLE_RATE) -> torch.Tensor:
+        """[n] or [n, channels] float32 at ``rate_in`` -> mono [m] at ``rate_out`` on the device
+        (np.mean(axis=1) + librosa.resample of src/stream/worker.py:116-128 as one kernel)."""
+        if isinstance(samples, torch.Tensor):
+            t = samples.to(self.device, dtype=torch.float32, non_blocking=True)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(samples), dtype=np.float32)).to(self.device)
+        if t.dim() == 1:
+            t = t[:, None]
+        if t.dim() != 2:
+            raise ValueError("samples must be [n] or [n, channels]")
+        t = t.contiguous()
+        n_in, channels = t.shape
+        n_out = _lib.check(self._lib.bd_resample_length(n_in, int(rate_in), int(rate_out)))
+        out = torch.empty(max(n_out, 1), dtype=torch.float32, device=self.device)[:n_out]
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_resample(self._handle, t.data_ptr(), n_in, channels, int(rate_in), int(rate_out),
+                                             out.data_ptr(), self._stream().cuda_stream))
+        t.record_stream(self._stream())
+        return out
+
     # ------------------------------------------------------------------ hot path
     def frontend(self, samples, hop: int) -> torch.Tensor:
         """[N] PCM -> [T,64] log-mel (features.py:22-58 + pad_waveform :82-108)."""

@@ -11,6 +11,8 @@
  *   bd_padded_length         <- pad_waveform                 embedders/yamnet/features.py:82-108
  *   bd_num_frames            <- tf.signal.stft framing       embedders/yamnet/features.py:42-46
  *   bd_num_windows           <- tf.signal.frame(axis=0)      embedders/yamnet/features.py:65-76
+ *   bd_resample              <- WorkerStreamer.queue_chunk: np.mean(axis=1) + librosa.resample
+ *                                                            src/stream/worker.py:116-128
  *   bd_frontend              <- waveform_to_log_mel_spectrogram_patches (log-mel output)
  *                                                            embedders/yamnet/features.py:22-58
  *   bd_patches               <- ... (patch output)           embedders/yamnet/features.py:65-79
@@ -108,6 +110,18 @@ BD_API int64_t bd_workspace_bytes(bd_handle h, int64_t n_samples, int32_t hop_sa
 /* pcm_dev[n_samples] -> logmel_dev[bd_num_frames][64]; samples past n_samples read as zero. */
 BD_API int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples,
                 float* logmel_dev, void* stream);
+
+/* Streamer stage (src/stream/worker.py:116-128): mean over channels, then rational resample rate_in ->
+   rate_out with a Kaiser(5.0)-windowed-sinc polyphase filter of 20*max(up,down)+1 taps (up/down = the
+   reduced rate ratio).  in_dev is [n_in][channels] interleaved f32; out_dev gets bd_resample_length()
+   samples.  The reference resamples with soxr_hq (librosa default): a different low-pass, NOT reproduced
+   bit for bit - see DESIGN.md.  bd_resample_taps returns the tap count and (optionally) the taps, so that
+   a host restatement can use the identical filter. */
+BD_API int64_t bd_resample_length(int64_t n_in, int32_t rate_in, int32_t rate_out);
+BD_API int bd_resample_taps(int32_t rate_in, int32_t rate_out, float* taps_host, int64_t capacity, int32_t* up,
+                            int32_t* down, int32_t* half);
+BD_API int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels, int32_t rate_in,
+                       int32_t rate_out, float* out_dev, void* stream);
 
 /* logmel_dev[n_frames][64] -> patches_dev[W][96][64], W = 1 + (n_frames - 96) / patch_step. */
 BD_API int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t patch_step,

@@ -1,0 +1,67 @@
+"""Downmix + resample stage (BASELINE config 5's 48 kHz stereo input)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.signal
+
+from oracle import resample_oracle as RO
+
+
+@pytest.mark.parametrize("rate_in,n", [(48000, 4800), (32000, 3001), (44100, 2205), (16000, 500), (8000, 400)])
+def test_oracle_is_resample_poly(rate_in, n):
+    rng = np.random.default_rng(rate_in)
+    x = rng.standard_normal(n).astype(np.float32)
+    up, down = RO.ratio(rate_in, 16000)
+    want = scipy.signal.resample_poly(x.astype(np.float64), up, down)
+    got = RO.resample(x, rate_in)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-12
+
+
+def test_library_designs_the_same_filter():
+    from buzzdetect_amd import _lib
+    lib = _lib.load()
+    for rate_in in (48000, 32000, 44100, 8000, 22050):
+        up, down, half = C.c_int32(), C.c_int32(), C.c_int32()
+        n = lib.bd_resample_taps(rate_in, 16000, None, 0, C.byref(up), C.byref(down), C.byref(half))
+        buf = np.zeros(n, np.float32)
+        assert lib.bd_resample_taps(rate_in, 16000, buf.ctypes.data, n, C.byref(up), C.byref(down), C.byref(half)) == n
+        h, hl = RO.taps(*RO.ratio(rate_in, 16000))
+        assert (up.value, down.value) == RO.ratio(rate_in, 16000) and half.value == hl and n == h.size
+        assert np.abs(buf - h).max() < 1e-7
+        for n_in in (0, 1, 160, 48000, 1234567):
+            assert lib.bd_resample_length(n_in, rate_in, 16000) == -(-n_in * up.value // down.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate_in,channels,n", [(48000, 2, 48000), (48000, 1, 7001), (32000, 1, 61144 // 2),
+                                                 (44100, 2, 22050), (16000, 2, 9999), (48000, 3, 3000)])
+def test_device_resample_matches_restatement(engine, rate_in, channels, n):
+    rng = np.random.default_rng(n)
+    x = (0.5 * rng.standard_normal((n, channels))).astype(np.float32)
+    if channels == 1:
+        x = x[:, 0]
+    got = engine.resample(x, rate_in).cpu().numpy()
+    want = RO.resample(x, rate_in)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_config5_input_48k_stereo_end_to_end(engine, weights_bundle):
+    """48 kHz stereo -> device downmix/resample -> predict, against the CPU restatement of the same chain."""
+    from oracle import yamnet_oracle as O
+    t = np.arange(48000 * 3) / 48000.0
+    rng = np.random.default_rng(5)
+    left = 0.1 * rng.standard_normal(t.size) + 0.3 * np.sin(2 * np.pi * 220 * t)
+    right = 0.1 * rng.standard_normal(t.size)
+    x = np.stack([left, right], 1).astype(np.float32)
+    mono = engine.resample(x, 48000)
+    assert mono.shape[0] == 48000
+    got = engine.predict(mono, 0.96).numpy()
+    b = weights_bundle
+    ref = O.predict(RO.resample(x, 48000).astype(np.float32), b["blob"], b["mel"], b["head_kernel"], b["head_bias"],
+                    15360, 96, np.float64)
+    assert got.shape == ref.shape == (4, 13)
+    assert np.abs(got - ref).max() < 1e-4
