@@ -1403,9 +1403,9 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     if (L.stride != 1 || windows <= 0 || L.cin < 64) return false;
     const long long M = (long long)windows * L.h_out * L.w_out;
     const int P = L.h_out * L.w_out;
-    // auto (measured on MI355X): the small deep maps (6x4, 3x2) run best on the wave-specialised kernel
-    // with 256-wide column tiles, the larger maps on the 4-wave kernel
-    if (variant <= 1 && (P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128) variant = 3;
+    // auto (measured on MI355X): the 12x8, 6x4 and 3x2 maps run best on the wave-specialised kernel with
+    // 256-wide column tiles, the 24x16 map (K = 128, only 4 stages) on the 4-wave kernel
+    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128) variant = 3;
     if (variant >= 3 && L.cin >= 128) {                            // wave-specialised kernels (BM = 96)
         if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 rows (+ halo rows)
             launch_sep_ws<128, 128>(in, L, out, M, stream);

@@ -21,6 +21,7 @@ constexpr int kWaves = 4;
 constexpr int kFramesPerWave = 4;
 constexpr int kGroupFrames = kWaves * kFramesPerWave;                         // 16 frames per pass
 constexpr int kGroupSamples = (kGroupFrames - 1) * BD_STFT_HOP + BD_STFT_WINDOW;  // 2800
+constexpr int kMelTaps = 20;   // mel weights a lane keeps in registers (longest band of the YAMNet filterbank: 17)
 
 // Each wavefront works on its own z / mag tile, and LDS executes one wave's DS instructions in order,
 // so passes of a frame only need their LDS traffic drained and the compiler kept from reordering
@@ -47,31 +48,48 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                                                      long long n_frames, float* __restrict__ out,
                                                      const FeTables* __restrict__ tab) {
     __shared__ __attribute__((aligned(16))) float s_pcm[kGroupSamples];
-    __shared__ __attribute__((aligned(16))) float s_hann[BD_STFT_WINDOW];
-    __shared__ __attribute__((aligned(16))) float2 s_tw256[256];
-    __shared__ __attribute__((aligned(16))) float2 s_tw512[BD_SPECTRUM_BINS + 1];
     __shared__ __attribute__((aligned(16))) float2 s_z[kWaves][256];
     __shared__ __attribute__((aligned(16))) float s_mag[kWaves][BD_SPECTRUM_BINS + 7];
-    __shared__ __attribute__((aligned(16))) float s_bw[kMelMaxLen * BD_MEL_BANDS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    for (int i = tid; i < BD_STFT_WINDOW; i += 256) s_hann[i] = tab->hann[i];
-    s_tw256[tid] = tab->tw256[tid];
-    for (int i = tid; i < BD_SPECTRUM_BINS + 1; i += 256) s_tw512[i] = tab->tw512[i];
-    const int max_len = tab->max_len;
-    for (int i = tid; i < max_len * BD_MEL_BANDS; i += 256) s_bw[i] = (&tab->band_w[0][0])[i];
+    // Everything a lane needs from the constant tables is fixed for the whole kernel (its butterfly index,
+    // its bins, its band), so it lives in registers: per frame the LDS only carries the data itself.
+    float2 hann2[4];                      // Hann taps of the lane's four packed input points
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n2 = 2 * (lane + 64 * r);
+        hann2[r] = n2 < BD_STFT_WINDOW ? make_float2(tab->hann[n2], tab->hann[n2 + 1]) : make_float2(0.f, 0.f);
+    }
+    float2 tw[3][3];                      // twiddles of passes p = 4, 16, 64 for inputs 1..3
+    {
+        int pi = 0;
+#pragma unroll
+        for (int p = 4; p <= 64; p *= 4, ++pi) {
+            const int tstep = (lane & (p - 1)) * (64 / p);
+#pragma unroll
+            for (int r = 1; r <= 3; ++r) tw[pi][r - 1] = tab->tw256[(r * tstep) & 255];
+        }
+    }
+    float2 tws[4];                        // real-FFT split twiddles exp(-2 pi i k / 512), k = lane + 64 r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tws[r] = tab->tw512[lane + 64 * r];
     const int band_start = tab->band_start[lane];
     const int band_len = tab->band_len[lane];
+    float bw[kMelTaps];                   // the band's mel weights (zero past band_len)
+#pragma unroll
+    for (int j = 0; j < kMelTaps; ++j) bw[j] = j < band_len ? tab->band_w[j][lane] : 0.0f;
+    const int max_len = tab->max_len;     // <= kMelTaps, checked by the launcher
 
     float2* z = s_z[wave];
     float* mag = s_mag[wave];
+    if (lane < 7) mag[BD_SPECTRUM_BINS + lane] = 0.0f;   // padding read by the fixed-length mel loop
 
     const long long n_groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
     for (long long group = blockIdx.x; group < n_groups; group += gridDim.x) {
-        __syncthreads();   // tables visible / previous pass done with s_pcm
+        __syncthreads();   // previous pass done with s_pcm
         const long long base = group * (long long)(kGroupFrames * BD_STFT_HOP);
         for (int i = tid; i < kGroupSamples; i += 256) {
             const long long idx = base + i;
@@ -91,8 +109,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 const int n2 = 2 * (lane + 64 * r);   // z[n] = x[2n] + i x[2n+1]; zero past 400
                 if (n2 < BD_STFT_WINDOW) {
                     const float2 xv = *reinterpret_cast<const float2*>(x + n2);
-                    const float2 hv = *reinterpret_cast<const float2*>(s_hann + n2);
-                    u[r] = make_float2(xv.x * hv.x, xv.y * hv.y);
+                    u[r] = make_float2(xv.x * hann2[r].x, xv.y * hann2[r].y);
                 } else {
                     u[r] = make_float2(0.0f, 0.0f);
                 }
@@ -103,20 +120,22 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             wave_lds_sync();
 
             // ---- passes 2..4 (p = 4, 16, 64) ----
+            {
+                int pi = 0;
 #pragma unroll
-            for (int p = 4; p <= 64; p *= 4) {
-                const int k = lane & (p - 1);
-                const int tstep = k * (64 / p);
+                for (int p = 4; p <= 64; p *= 4, ++pi) {
+                    const int k = lane & (p - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) u[r] = z[lane + 64 * r];
-                u[1] = cmul(u[1], s_tw256[tstep & 255]);
-                u[2] = cmul(u[2], s_tw256[(2 * tstep) & 255]);
-                u[3] = cmul(u[3], s_tw256[(3 * tstep) & 255]);
-                dft4(u[0], u[1], u[2], u[3]);
-                const int j0 = ((lane - k) << 2) + k;
+                    for (int r = 0; r < 4; ++r) u[r] = z[lane + 64 * r];
+                    u[1] = cmul(u[1], tw[pi][0]);
+                    u[2] = cmul(u[2], tw[pi][1]);
+                    u[3] = cmul(u[3], tw[pi][2]);
+                    dft4(u[0], u[1], u[2], u[3]);
+                    const int j0 = ((lane - k) << 2) + k;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[j0 + p * r] = u[r];
-                wave_lds_sync();
+                    for (int r = 0; r < 4; ++r) z[j0 + p * r] = u[r];
+                    wave_lds_sync();
+                }
             }
 
             // ---- split the packed transform into the real spectrum, take magnitudes ----
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 const float ey = 0.5f * (zk.y - zm.y);
                 const float ox = 0.5f * (zk.y + zm.y);    // O = -i/2 * (Zk - conj(Zm))
                 const float oy = -0.5f * (zk.x - zm.x);
-                const float2 t = s_tw512[k];
+                const float2 t = tws[r];
                 const float xr = ex + (t.x * ox - t.y * oy);
                 const float xi = ey + (t.x * oy + t.y * ox);
                 mag[k] = sqrtf(xr * xr + xi * xi);
@@ -139,8 +158,12 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
 
             // ---- banded mel reduction + log ----
             float acc = 0.0f;
-            for (int j = 0; j < max_len; ++j) {
-                if (j < band_len) acc = fmaf(mag[band_start + j], s_bw[j * BD_MEL_BANDS + lane], acc);
+#pragma unroll
+            for (int j = 0; j < kMelTaps; ++j) {
+                if (j < max_len) {
+                    const float m = mag[band_start + j];     // finite (padding is zero); weight is zero past band_len
+                    if (j < band_len) acc = fmaf(m, bw[j], acc);
+                }
             }
             if (frame < n_frames) out[frame * BD_MEL_BANDS + lane] = logf(acc + 0.001f);
             wave_lds_sync();   // mag / z reads of this frame retire before the next frame overwrites them
