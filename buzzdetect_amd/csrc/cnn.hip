@@ -1092,8 +1092,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
     __shared__ __attribute__((aligned(16))) float s_c1[C1R][34][32];
     __shared__ __attribute__((aligned(16))) char s_ah[BM * 64];
     __shared__ __attribute__((aligned(16))) char s_al[BM * 64];
-    __shared__ __attribute__((aligned(16))) char s_bh[64 * 64];
-    __shared__ __attribute__((aligned(16))) char s_bl[64 * 64];
+    // (the 64 x 32 weight tile is not staged: each lane loads its four MFMA B fragments, 4 x 16 bytes of
+    //  hi and lo, straight from global/L2 - that keeps the workgroup under 1/3 of the CU's LDS)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1102,21 +1102,23 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
     const int oh0 = blockIdx.x * kStemRows;
     const float* patch = logmel + (size_t)win * patch_step * BD_MEL_BANDS;
 
-    // ---- phase A: log-mel band, pointwise weights, zero halo columns ----
+    // ---- phase A: log-mel band, zero halo columns; this lane's weight fragments (used in phase D) ----
+    f16x8 wbh[2], wbl[2];
+    {
+        const int wrow = (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int koff = (2 * s2 + (lane >> 5)) * 8;
+            wbh[s2] = *reinterpret_cast<const f16x8*>(Whi + wrow * 32 + koff);
+            wbl[s2] = *reinterpret_cast<const f16x8*>(Wlo + wrow * 32 + koff);
+        }
+    }
     for (int i = tid; i < LMR * 17; i += 256) {
         const int j = i / 17, q = i % 17;
         const int ih = 2 * oh0 - 2 + j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < 16 && ih >= 0 && ih < BD_PATCH_FRAMES) v = reinterpret_cast<const float4*>(patch + ih * BD_MEL_BANDS)[q];
         *reinterpret_cast<float4*>(&s_lm[j][q * 4]) = v;      // q == 16: columns 64..67 stay zero (SAME pad right)
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = tid + 256 * i;                         // 512 chunks: 64 rows x 4 slots x {hi, lo}
-        const int which = id >> 8, rem = id & 255;
-        const int row = rem >> 2, slot = rem & 3;
-        const uint4 v = *reinterpret_cast<const uint4*>((which ? Wlo : Whi) + row * 32 + slot * 8);
-        *reinterpret_cast<uint4*>((which ? s_bl : s_bh) + swz64(row, slot)) = v;
     }
     for (int i = tid; i < C1R * 2 * 8; i += 256) {
         const int r = i / 16, side = (i >> 3) & 1, c4 = i & 7;
@@ -1223,9 +1225,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
             ah[i] = *reinterpret_cast<const f16x8*>(s_ah + off);
             al[i] = *reinterpret_cast<const f16x8*>(s_al + off);
         }
-        const int boff = swz64(wc * 32 + frow, 2 * s2 + fh);
-        const f16x8 bh = *reinterpret_cast<const f16x8*>(s_bh + boff);
-        const f16x8 bl = *reinterpret_cast<const f16x8*>(s_bl + boff);
+        const f16x8 bh = wbh[s2];
+        const f16x8 bl = wbl[s2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc2[i], 0, 0, 0);
