@@ -58,8 +58,15 @@ def slot_plan(launches):
         dw_slot, pw_slot = 2 * layer - 2, 2 * layer - 1
         dw = ((h * w * c + ho * wo * c) * 4, 2 * 9 * ho * wo * c)
         pw = ((ho * wo * c + ho * wo * cout) * 4, 2 * ho * wo * c * cout)
+        if layer == 2:
+            stem_flops = dw[1] + pw[1]
         if launches[dw_slot] > 0:
-            plan[dw_slot] = (f"dw{layer}", "depthwise_kernel", dw[0], dw[1])
+            if layer == 3 and launches[1] == 0 and launches[3] == 0:
+                # stem3: conv1 + layer 2 + depthwise 3 in one kernel: log-mel patch in, depthwise-3 output out
+                plan[dw_slot] = ("stem3(1-3dw)", "stem3_kernel", 96 * 64 * 4 + ho * wo * c * 4,
+                                 conv1[1] + stem_flops + dw[1])
+            else:
+                plan[dw_slot] = (f"dw{layer}", "depthwise_kernel", dw[0], dw[1])
         if launches[pw_slot] > 0:
             if launches[dw_slot] > 0:
                 plan[pw_slot] = (f"pw{layer}", "pointwise_f16x3_kernel", pw[0], pw[1])
@@ -276,7 +283,7 @@ def main() -> None:
                 f["flops"] += fl * WINDOWS_PER_BATCH * args.steps
                 f["slots"].append(nm)
             total_ms = float(ms.sum())
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_s1_kernel", "sep_ws_kernel", "stem_kernel")
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_s1_kernel", "sep_ws_kernel", "stem_kernel", "stem3_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
             sec = d["ms"] * 1e-3

@@ -1252,6 +1252,217 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
     }
 }
 
+// --------------------------------------------------------------------------- fused stem + layer-3 depthwise
+// stem_kernel's chain extended by the stride-2 depthwise of layer 3 (yamnet.py:80): the layer-2 output
+// (the largest tensor of the network, 402 MB per 1024 windows) is never written.  A workgroup owns TWO
+// output rows of layer 3's depthwise in one window; they need five layer-2 rows (one is shared with the
+// neighbouring workgroup and computed twice), which need seven conv1 rows and fifteen log-mel rows.
+//   A  log-mel band -> LDS                       B  conv1 band (7 rows)  -> LDS
+//   C  depthwise 2 (5 rows) -> split-f16 A tile   D  [160][32] x [32][64] on the matrix cores
+//   E  bias + ReLU -> f32 tile P[160][64] in LDS (rows past the map's edge are the zero padding)
+//   F  depthwise 3 (stride 2, SAME = pad 0 before / 1 after) on P -> HBM, [2][16][64] per workgroup
+// Arithmetic order per element equals conv1_kernel / depthwise_kernel / pointwise_f16x3_kernel.
+__global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ logmel, int patch_step,
+                                                    const float* __restrict__ c1_w, const float* __restrict__ c1_b,
+                                                    const float* __restrict__ dw2_w, const float* __restrict__ dw2_b,
+                                                    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
+                                                    const float* __restrict__ pw_b, const float* __restrict__ dw3_w,
+                                                    const float* __restrict__ dw3_b, float* __restrict__ out) {
+    constexpr int R2 = 5;                       // layer-2 rows in the tile
+    constexpr int C1R = R2 + 2;                 // conv1 rows incl. halo: 7
+    constexpr int LMR = 2 * C1R + 1;            // log-mel rows: 15
+    constexpr int BM = R2 * 32;                 // 160 GEMM rows
+    constexpr int PW = 68;                      // padded row of the f32 output tile
+    constexpr int OFF_C1 = 4096;                                    // after s_lm (15 x 68 floats = 4080 B)
+    constexpr int OFF_AH = OFF_C1 + C1R * 34 * 32 * 4;              // 34560
+    constexpr int OFF_AL = OFF_AH + BM * 64;                        // 44800
+    constexpr int LDS_BYTES = OFF_AL + BM * 64;                     // 55040; P (43520 B) aliases from 0
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    float (*s_lm)[68] = reinterpret_cast<float (*)[68]>(smem);
+    float (*s_c1)[34][32] = reinterpret_cast<float (*)[34][32]>(smem + OFF_C1);
+    char* const s_ah = smem + OFF_AH;
+    char* const s_al = smem + OFF_AL;
+    float* const P = reinterpret_cast<float*>(smem);               // [BM][PW], valid from phase E on
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int win = blockIdx.y;
+    const int ob = blockIdx.x;                  // 0..11: depthwise-3 rows 2 ob, 2 ob + 1
+    const int r0 = 4 * ob;                      // first layer-2 row of the tile
+    const float* patch = logmel + (size_t)win * patch_step * BD_MEL_BANDS;
+
+    // this lane's pointwise weight fragments (phase D)
+    f16x8 wbh[2], wbl[2];
+    {
+        const int wrow = (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int koff = (2 * s2 + (lane >> 5)) * 8;
+            wbh[s2] = *reinterpret_cast<const f16x8*>(Whi + wrow * 32 + koff);
+            wbl[s2] = *reinterpret_cast<const f16x8*>(Wlo + wrow * 32 + koff);
+        }
+    }
+
+    // ---- A: log-mel rows 2 (r0 - 1) .. +14, zero halo columns of the conv1 band ----
+    for (int i = tid; i < LMR * 17; i += 256) {
+        const int j = i / 17, q = i % 17;
+        const int ih = 2 * r0 - 2 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < 16 && ih >= 0 && ih < BD_PATCH_FRAMES) v = reinterpret_cast<const float4*>(patch + ih * BD_MEL_BANDS)[q];
+        *reinterpret_cast<float4*>(&s_lm[j][q * 4]) = v;
+    }
+    for (int i = tid; i < C1R * 2 * 8; i += 256) {
+        const int r = i / 16, side = (i >> 3) & 1, c4 = i & 7;
+        *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    // ---- B: conv1 rows r0 - 1 .. r0 + 5 ----
+    const int c4 = tid & 7;
+    const int col = tid >> 3;
+    {
+        float4 wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(c1_w + t * 32)[c4];
+        const float4 bias = reinterpret_cast<const float4*>(c1_b)[c4];
+#pragma unroll
+        for (int i = 0; i < C1R; ++i) {
+            const int c1r = r0 - 1 + i;
+            float4 acc = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* row = &s_lm[2 * i + kh][2 * col];
+                const bool ok = 2 * c1r + kh < BD_PATCH_FRAMES;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    if (!ok) continue;
+                    const float v = row[kw];
+                    const float4 w = wt[kh * 3 + kw];
+                    acc.x = fmaf(v, w.x, acc.x);
+                    acc.y = fmaf(v, w.y, acc.y);
+                    acc.z = fmaf(v, w.z, acc.z);
+                    acc.w = fmaf(v, w.w, acc.w);
+                }
+            }
+            const bool valid = c1r >= 0 && c1r < 48;
+            float4 r4;
+            r4.x = valid ? fmaxf(acc.x, 0.0f) : 0.0f;
+            r4.y = valid ? fmaxf(acc.y, 0.0f) : 0.0f;
+            r4.z = valid ? fmaxf(acc.z, 0.0f) : 0.0f;
+            r4.w = valid ? fmaxf(acc.w, 0.0f) : 0.0f;
+            *reinterpret_cast<float4*>(&s_c1[i][col + 1][c4 * 4]) = r4;
+        }
+    }
+    __syncthreads();
+
+    // ---- C: depthwise 2 for rows r0 .. r0 + 4 -> split-f16 A tile [160][32] ----
+    {
+        float4 wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(dw2_w + t * 32)[c4];
+        const float4 bias = reinterpret_cast<const float4*>(dw2_b)[c4];
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            float4 acc = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_c1[r + kh][col + kw][c4 * 4]);
+                    const float4 w = wt[kh * 3 + kw];
+                    acc.x = fmaf(v.x, w.x, acc.x);
+                    acc.y = fmaf(v.y, w.y, acc.y);
+                    acc.z = fmaf(v.z, w.z, acc.z);
+                    acc.w = fmaf(v.w, w.w, acc.w);
+                }
+            acc.x = fmaxf(acc.x, 0.0f);
+            acc.y = fmaxf(acc.y, 0.0f);
+            acc.z = fmaxf(acc.z, 0.0f);
+            acc.w = fmaxf(acc.w, 0.0f);
+            f16x4 hi, lo;
+            hi[0] = (_Float16)acc.x; hi[1] = (_Float16)acc.y; hi[2] = (_Float16)acc.z; hi[3] = (_Float16)acc.w;
+            lo[0] = (_Float16)(acc.x - (float)hi[0]); lo[1] = (_Float16)(acc.y - (float)hi[1]);
+            lo[2] = (_Float16)(acc.z - (float)hi[2]); lo[3] = (_Float16)(acc.w - (float)hi[3]);
+            const int off = swz64(r * 32 + col, c4 >> 1) + (c4 & 1) * 8;
+            *reinterpret_cast<f16x4*>(s_ah + off) = hi;
+            *reinterpret_cast<f16x4*>(s_al + off) = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- D: GEMM.  Waves (wr, wc): column tile wc; row tiles wr, wr + 2 and, for wr == 0, 4 ----
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 31, fh = lane >> 5;
+    f32x16 acc2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rt = wr + 2 * i;                                  // row tile 0..4 (5 = none)
+            if (rt < R2) {
+                const int off = swz64(rt * 32 + frow, 2 * s2 + fh);
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(s_ah + off);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(s_al + off);
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wbh[s2], acc2[i], 0, 0, 0);
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbl[s2], acc2[i], 0, 0, 0);
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbh[s2], acc2[i], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the A tile, the conv band and the log-mel band: P may overwrite them
+
+    // ---- E: bias + ReLU -> P; layer-2 rows past row 47 are the depthwise's zero padding ----
+    {
+        const int n = wc * 32 + frow;
+        const float b = pw_b[n];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rt = wr + 2 * i;
+            if (rt < R2) {
+                const bool live = r0 + rt < 48;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rt * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                    P[m * PW + n] = live ? fmaxf(acc2[i][r] + b, 0.0f) : 0.0f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- F: depthwise 3, stride 2: out[o][ow][c] from P rows 2o + kh, columns 2ow + kw (column 32 = padding) ----
+    float* dst = out + (((size_t)win * 24 + 2 * ob) * 16) * 64;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = tid + 256 * it;              // 512 tasks: o (2) x ow (16) x c4 (16)
+        const int c16 = id & 15, ow = (id >> 4) & 15, o = id >> 8;
+        float4 acc = reinterpret_cast<const float4*>(dw3_b)[c16];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int pc = 2 * ow + kw;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pc < 32) v = *reinterpret_cast<const float4*>(P + ((2 * o + kh) * 32 + pc) * PW + c16 * 4);
+                const float4 w = reinterpret_cast<const float4*>(dw3_w + (kh * 3 + kw) * 64)[c16];
+                acc.x = fmaf(v.x, w.x, acc.x);
+                acc.y = fmaf(v.y, w.y, acc.y);
+                acc.z = fmaf(v.z, w.z, acc.z);
+                acc.w = fmaf(v.w, w.w, acc.w);
+            }
+        acc.x = fmaxf(acc.x, 0.0f);
+        acc.y = fmaxf(acc.y, 0.0f);
+        acc.z = fmaxf(acc.z, 0.0f);
+        acc.w = fmaxf(acc.w, 0.0f);
+        reinterpret_cast<float4*>(dst + ((size_t)o * 16 + ow) * 64)[c16] = acc;
+    }
+}
+
 // --------------------------------------------------------------------------- pool + head
 __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ act,
                                                         const float* __restrict__ head_wt,
@@ -1448,6 +1659,14 @@ void launch_stem(const float* logmel, int patch_step, int windows, const float* 
     hipLaunchKernelGGL(stem_kernel, dim3(48 / kStemRows, windows), dim3(256), 0, stream, logmel, patch_step, c1_w,
                        c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
                        static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, out);
+}
+
+void launch_stem3(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
+                  const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
+    if (windows <= 0) return;
+    hipLaunchKernelGGL(stem3_kernel, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, c1_w, c1_b,
+                       L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out);
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,

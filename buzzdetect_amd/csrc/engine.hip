@@ -52,6 +52,7 @@ struct bd_engine {
     int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA
     bool fuse_stem = true;            // layers 1-2 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
+    bool fuse_stem3 = true;           // the stem also applies layer 3's depthwise (needs fuse_stem)
     int sep_variant = 0;
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
@@ -605,7 +606,19 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         int64_t last_floats = 0;
         bool stopped = false;
         int first_layer = 0;
-        if (fuse_stem) {
+        // ... and the stride-2 depthwise of layer 3 rides along unless a tap wants layer 2's output
+        const bool fuse_stem3 = fuse_stem && e->fuse_stem3 && (stop_stage < 0 || stop_stage >= 4);
+        bool skip_dw3 = false;
+        if (fuse_stem3) {
+            {
+                Scope sc(e, stream, 4);      // timed in the slot of depthwise 3 (slots 1-3 stay empty)
+                bd::launch_stem3(lm, step, gw, e->conv1_w, e->conv1_b, e->sep[0], e->sep[1], buf_b, stream);
+            }
+            last = buf_b;
+            last_floats = (int64_t)gw * 24 * 16 * 64;
+            first_layer = 1;
+            skip_dw3 = true;
+        } else if (fuse_stem) {
             {
                 Scope sc(e, stream, 3);
                 bd::launch_stem(lm, step, gw, e->conv1_w, e->conv1_b, e->sep[0], buf_a, stream);
@@ -636,7 +649,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
                 if (stop_stage == 2 * l + 2) stopped = true;
                 continue;
             }
-            {
+            if (!(skip_dw3 && l == 1)) {
                 Scope sc(e, stream, 2 + 2 * l);
                 bd::launch_depthwise(buf_a, buf_b, gw, L, stream);
             }
@@ -715,6 +728,7 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     h->fuse_stem = stem != 0;
+    h->fuse_stem3 = stem >= 2;
     h->fuse_sep = separable != 0;
     h->sep_variant = separable > 1 ? separable : 0;
     return BD_OK;

@@ -113,9 +113,11 @@ class HipEngine:
         """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class)."""
         _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1}[mode]))
 
-    def set_fusion(self, stem: bool = True, separable=True) -> None:
-        """Fused stem kernel / fused depthwise+pointwise kernels on or off (both on by default)."""
-        _lib.check(self._lib.bd_set_fusion(self._handle, 1 if stem else 0, int(separable)))
+    def set_fusion(self, stem=True, separable=True) -> None:
+        """Fused stem kernel (True/2 = incl. layer 3's depthwise, 1 = layers 1-2 only, False = off) and
+        fused depthwise+pointwise kernels (True / variant number / False)."""
+        stem_code = 2 if stem is True else int(stem)
+        _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))
 
     def set_pointwise_variant(self, layer: int, variant: int) -> None:
         _lib.check(self._lib.bd_set_pointwise_variant(self._handle, int(layer), int(variant)))

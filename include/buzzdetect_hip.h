@@ -157,7 +157,9 @@ BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int3
    f32 accumulate; same accuracy class as f32, ~5x the matrix-core rate. */
 BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
 /* Kernel fusion in mode 1 (both on by default; 0 = one kernel per op, the layout the stage taps use):
-   stem != 0       layers 1-2 (conv, depthwise, pointwise) as one kernel, timed in profile slot 3;
+   stem == 1       layers 1-2 (conv, depthwise, pointwise) as one kernel, timed in profile slot 3;
+   stem == 2       (default) that kernel also applies layer 3's stride-2 depthwise and writes only its
+                   output (the 402 MB layer-2 tensor never reaches HBM); timed in profile slot 4;
    separable != 0  stride-1 layers 4, 6, 8-12, 14: depthwise computed inside the pointwise GEMM, timed
                    in the layer's pointwise slot (2 = wider column tile).
    Fused and unfused paths give bit-identical results. */
