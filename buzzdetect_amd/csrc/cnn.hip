@@ -1273,12 +1273,15 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
     constexpr int LMR = 2 * C1R + 1;            // log-mel rows: 15
     constexpr int BM = R2 * 32;                 // 160 GEMM rows
     constexpr int PW = 68;                      // padded row of the f32 output tile
-    constexpr int OFF_C1 = 4096;                                    // after s_lm (15 x 68 floats = 4080 B)
-    constexpr int OFF_AH = OFF_C1 + C1R * 34 * 32 * 4;              // 34560
-    constexpr int OFF_AL = OFF_AH + BM * 64;                        // 44800
-    constexpr int LDS_BYTES = OFF_AL + BM * 64;                     // 55040; P (43520 B) aliases from 0
+    // LDS carve-up (50 944 B -> three workgroups per CU): the log-mel band is dead once the conv band exists,
+    // so it shares the A tile's bytes; the f32 output tile P overlays everything from phase E on.
+    constexpr int OFF_C1 = 0;
+    constexpr int OFF_AH = OFF_C1 + C1R * 34 * 32 * 4;              // 30464
+    constexpr int OFF_AL = OFF_AH + BM * 64;                        // 40704
+    constexpr int LDS_BYTES = OFF_AL + BM * 64;                     // 50944; P (43520 B) aliases from 0
+    static_assert(LMR * 68 * 4 <= 2 * BM * 64, "log-mel band must fit in the A tile it aliases");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    float (*s_lm)[68] = reinterpret_cast<float (*)[68]>(smem);
+    float (*s_lm)[68] = reinterpret_cast<float (*)[68]>(smem + OFF_AH);
     float (*s_c1)[34][32] = reinterpret_cast<float (*)[34][32]>(smem + OFF_C1);
     char* const s_ah = smem + OFF_AH;
     char* const s_al = smem + OFF_AL;
