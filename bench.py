@@ -68,8 +68,13 @@ def slot_plan(launches):
             else:
                 plan[dw_slot] = (f"dw{layer}", "depthwise_kernel", dw[0], dw[1])
         if launches[pw_slot] > 0:
-            if launches[dw_slot] > 0:
+            if launches[dw_slot] > 0 or (stride == 2 and layer >= 3):
+                # (a stride-2 layer without a depthwise launch: the previous kernel applied it)
                 plan[pw_slot] = (f"pw{layer}", "pointwise_f16x3_kernel", pw[0], pw[1])
+                if launches[dw_slot] == 0 and layer >= 5 and (pw_slot - 2) in plan:
+                    nm, fam, nb, fl = plan[pw_slot - 2]
+                    # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own
+                    plan[pw_slot - 2] = (nm + f"+dw{layer}", fam, nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
             elif layer == 2:      # fused stem: log-mel patch in, layer-2 output out
                 plan[pw_slot] = ("stem(1-2)", "stem_kernel", 96 * 64 * 4 + ho * wo * cout * 4,
                                  conv1[1] + dw[1] + pw[1])

@@ -55,6 +55,8 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
                                    long long M, int N, int K, int variant, hipStream_t stream);
 bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
                             hipStream_t stream);
+bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
+                                    hipStream_t stream);
 void launch_stem(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
                  const SepLayer& L2, float* out, hipStream_t stream);
 void launch_stem3(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,

@@ -751,11 +751,14 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // ABL (timing-only ablations, results wrong): 1 = no global loads inside the K loop, 2 = no depthwise
 // arithmetic, 3 = no MFMAs, 4 = producers only keep the barriers, 5 = consumers only keep the barriers,
 // 6 = no C store.  0 = the real kernel.
-template <int BN, int XPMAX, int ABL>
+// NDW = 1: the tile (whole windows) is not written; the NEXT layer's stride-2 depthwise (taps ndw_w, shift
+// ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS and only that result goes to out2.
+template <int BN, int XPMAX, int ABL, int NDW>
 __global__ __launch_bounds__(512) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
-    float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n) {
+    float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n,
+    const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out2) {
     constexpr int BM = 96;
     constexpr int WN = BN / 4;               // consumer wave tile: 96 x WN
     constexpr int TM = 3, TN = WN / 32;
@@ -1035,9 +1038,43 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     }
     }   // consumers
 
-    // ---- all 8 waves: tile -> HBM as whole rows, 16 bytes per lane ----
     __syncthreads();
-    if (ABL != 6) {
+    if (NDW) {
+        // ---- next layer's depthwise (stride 2) on the tile: windows are whole, so every tap is in LDS ----
+        const float* Ct = reinterpret_cast<const float*>(smem_raw);
+        constexpr int C4 = BN / 4;
+        const int P = H * W;
+        const int OW2 = W / 2, P2 = (H / 2) * OW2;
+        const int tasks = (BM / P) * P2 * C4;
+        for (int id = tid; id < tasks; id += 512) {
+            const int c4 = id % C4;
+            const int q = id / C4;
+            const int pos2 = q % P2, wl = q / P2;
+            if (m0 + (long long)wl * P >= M) continue;
+            const int oh = pos2 / OW2, ow = pos2 % OW2;
+            v4f acc = *reinterpret_cast<const v4f*>(ndw_b + n0 + c4 * 4);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = 2 * oh + kh, iw = 2 * ow + kw;
+                    v4f v = {0.f, 0.f, 0.f, 0.f};
+                    if (ih < H && iw < W) v = *reinterpret_cast<const v4f*>(Ct + (wl * P + ih * W + iw) * (BN + 4) + c4 * 4);
+                    const v4f w = *reinterpret_cast<const v4f*>(ndw_w + (size_t)(kh * 3 + kw) * N + n0 + c4 * 4);
+                    acc.x = fmaf(v.x, w.x, acc.x);
+                    acc.y = fmaf(v.y, w.y, acc.y);
+                    acc.z = fmaf(v.z, w.z, acc.z);
+                    acc.w = fmaf(v.w, w.w, acc.w);
+                }
+            acc.x = fmaxf(acc.x, 0.0f);
+            acc.y = fmaxf(acc.y, 0.0f);
+            acc.z = fmaxf(acc.z, 0.0f);
+            acc.w = fmaxf(acc.w, 0.0f);
+            const long long row2 = (m0 / P + wl) * P2 + pos2;
+            *reinterpret_cast<v4f*>(out2 + (size_t)row2 * N + n0 + c4 * 4) = acc;
+        }
+    } else if (ABL != 6) {
+        // ---- all 8 waves: tile -> HBM as whole rows, 16 bytes per lane ----
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
         constexpr int C4 = BN / 4;                                   // float4 per tile row
 #pragma unroll
@@ -1052,22 +1089,24 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     }
 }
 
-template <int BN, int XPMAX, int ABL = 0>
-void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
+template <int BN, int XPMAX, int ABL = 0, int NDW = 0>
+void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
+                   const SepLayer* next = nullptr) {
     constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (96 + BN) * 64;
     constexpr size_t lds_tile = 96u * (BN + 4) * 4;
     constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int tiles_n = L.cout / BN;
     const long long tiles = ((M + 95) / 96) * tiles_n;
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w, L.dw_b,
-                       static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo), L.pw_b, out, M,
-                       L.cout, L.cin, L.h_out, L.w_out, tiles_n);
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
+                       L.dw_b, static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo), L.pw_b,
+                       out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
+                       next ? next->dw_b : nullptr, out);
 }
 
 // --------------------------------------------------------------------------- fused stem
@@ -1610,6 +1649,18 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
                                        stream);
     else
         launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
+}
+
+// Fused depthwise+pointwise of layer L followed by the stride-2 depthwise of the NEXT layer; `out` receives
+// that depthwise's output [windows][H/2][W/2][L.cout].  Only for whole-window tiles (12x8 and 6x4 maps).
+bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
+                                    hipStream_t stream) {
+    const int P = L.h_out * L.w_out;
+    if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;
+    if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & 1)) return false;
+    const long long M = (long long)windows * P;
+    launch_sep_ws<256, 96, 0, 1>(in, L, out, M, stream, &next);
+    return true;
 }
 
 // Fused depthwise+pointwise for a stride-1 layer; returns false if the layer shape is not covered.

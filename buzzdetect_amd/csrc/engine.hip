@@ -53,6 +53,7 @@ struct bd_engine {
     bool fuse_stem = true;            // layers 1-2 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
     bool fuse_stem3 = true;           // the stem also applies layer 3's depthwise (needs fuse_stem)
+    bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     int sep_variant = 0;
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
@@ -609,6 +610,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         // ... and the stride-2 depthwise of layer 3 rides along unless a tap wants layer 2's output
         const bool fuse_stem3 = fuse_stem && e->fuse_stem3 && (stop_stage < 0 || stop_stage >= 4);
         bool skip_dw3 = false;
+        int skip_dw_layer = -1;      // loop index of a layer whose depthwise the previous kernel already applied
         if (fuse_stem3) {
             {
                 Scope sc(e, stream, 4);      // timed in the slot of depthwise 3 (slots 1-3 stay empty)
@@ -637,7 +639,18 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         for (int l = first_layer; l < 13 && !stopped; ++l) {
             const bd::SepLayer& L = e->sep[l];
             // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
-            if (e->fuse_sep && e->pointwise_mode == 1 && stop_stage != 2 * l + 1 &&
+            // ... and when the NEXT layer is a stride-2 one, its depthwise is applied in that kernel's epilogue
+            // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
+            if (e->fuse_sep && e->fuse_next_dw && e->pointwise_mode == 1 && e->sep_variant <= 1 && l + 1 < 13 &&
+                (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
+                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, e->sep[l + 1], stream)) {
+                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                skip_dw_layer = l + 1;
+                last = buf_b;
+                last_floats = (int64_t)gw * e->sep[l + 1].h_out * e->sep[l + 1].w_out * L.cout;
+                continue;
+            }
+            if (e->fuse_sep && e->pointwise_mode == 1 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
                 bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
@@ -649,7 +662,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
                 if (stop_stage == 2 * l + 2) stopped = true;
                 continue;
             }
-            if (!(skip_dw3 && l == 1)) {
+            if (!(skip_dw3 && l == 1) && skip_dw_layer != l) {
                 Scope sc(e, stream, 2 + 2 * l);
                 bd::launch_depthwise(buf_a, buf_b, gw, L, stream);
             }
@@ -730,6 +743,7 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_sep = separable != 0;
+    h->fuse_next_dw = separable == 1;
     h->sep_variant = separable > 1 ? separable : 0;
     return BD_OK;
 }

@@ -161,7 +161,9 @@ BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
    stem == 2       (default) that kernel also applies layer 3's stride-2 depthwise and writes only its
                    output (the 402 MB layer-2 tensor never reaches HBM); timed in profile slot 4;
    separable != 0  stride-1 layers 4, 6, 8-12, 14: depthwise computed inside the pointwise GEMM, timed
-                   in the layer's pointwise slot (2 = wider column tile).
+                   in the layer's pointwise slot (>= 2: explicit kernel variants, tuning only).  With 1
+                   (default) layers 6 and 12 also apply the NEXT layer's stride-2 depthwise in their
+                   epilogue, so depthwise 7 and 13 have no launch of their own.
    Fused and unfused paths give bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);
 /* whi/wlo: [n][k] f16 halves of wt (wt ~= whi + wlo) */

@@ -297,7 +297,7 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     try:
         for variant in (1, 2, 3, 4):
             engine.set_fusion(False, False)
-            plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 14, 22, 26)}
+            plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
             engine.set_fusion(False, variant)
             for st, ref in plain.items():
