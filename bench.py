@@ -175,13 +175,20 @@ def main() -> None:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X; there is no CPU path for the product")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # BD_BENCH_REHEARSAL=1: every rank uses GPU 0 and the collectives run over gloo on host copies - only to
+    # exercise the multi-rank control flow on a one-GPU box; never a measurement.
+    rehearsal = os.environ.get("BD_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
-    engines = [HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=local_rank)
+    engines = [HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=dev_index)
                for _ in range(max(1, args.streams))]
     streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in engines[1:]]
     engine = engines[0]
@@ -207,7 +214,7 @@ def main() -> None:
         if world > 1:             # one communicator: collectives are issued in step order on stream 0
             streams[0].wait_stream(streams[j])
             with torch.cuda.stream(streams[0]):
-                gathered = sharding.gather_rows(res.tensor, dst=0)
+                gathered = sharding.gather_rows(res.tensor.cpu() if rehearsal else res.tensor, dst=0)
                 res.tensor.record_stream(streams[0])
         return res, gathered
 
@@ -232,7 +239,7 @@ def main() -> None:
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt
@@ -263,7 +270,7 @@ def main() -> None:
             "audio_seconds_per_s": round(value * framehop_s, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
             "config": {"workload": "config 2: 16 kHz mono, batches of 1024 windows (983.04 s), yamnet_k2 hop 1.0 "
                                    "+ model_general_v3 head; embedder weights seeded synthetic in the reference "
                                    "layout, head weights real",
