@@ -79,7 +79,7 @@ def slot_plan(launches):
                 plan[pw_slot] = ("stem(1-2)", "stem_kernel", 96 * 64 * 4 + ho * wo * cout * 4,
                                  conv1[1] + dw[1] + pw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
-                fam = "sep_ws_kernel" if ho * wo in (96, 24, 6) else "sep_s1_kernel"
+                fam = "sep_ws_kernel"     # every fused stride-1 layer runs the wave-specialised kernel by default
                 plan[pw_slot] = (f"sep{layer}", fam, (h * w * c + ho * wo * cout) * 4, dw[1] + pw[1])
         h, w, c = ho, wo, cout
     plan[28] = ("pool_head", "pool_head_kernel", (6 * 1024 + 13) * 4, 2 * 1024 * 13)

@@ -753,16 +753,16 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // 6 = no C store.  0 = the real kernel.
 // NDW = 1: the tile (whole windows) is not written; the NEXT layer's stride-2 depthwise (taps ndw_w, shift
 // ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS and only that result goes to out2.
-template <int BN, int XPMAX, int ABL, int NDW>
+template <int BN, int XPMAX, int ABL, int NDW, int BM>
 __global__ __launch_bounds__(512) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
     float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n,
     const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out2) {
-    constexpr int BM = 96;
-    constexpr int WN = BN / 4;               // consumer wave tile: 96 x WN
-    constexpr int TM = 3, TN = WN / 32;
-    constexpr int LA = 3;                    // depthwise outputs (x4 channels) per producer thread per stage
+    static_assert(BM == 96 || BM == 64, "tile height");
+    constexpr int WN = BN / 4;               // consumer wave tile: BM x WN
+    constexpr int TM = BM / 32, TN = WN / 32;
+    constexpr int LA = BM / 32;              // depthwise outputs (x4 channels) per producer thread per stage
     constexpr int XL = (XPMAX + 31) / 32;    // float4 slab loads per producer thread per stage
     constexpr int BCH = BN * 4 / 256;        // 16-byte weight chunks per consumer thread per stage (each of hi / lo)
     constexpr int XS_FLOATS = (XPMAX + 1) * 32;   // + the zero row
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
 #undef BD_C_MFMA
 
     // bias + ReLU into an f32 tile in LDS (every stage buffer is dead after the last barrier)
-    float* const Ct = reinterpret_cast<float*>(smem_raw);          // [96][BN + 4]
+    float* const Ct = reinterpret_cast<float*>(smem_raw);          // [BM][BN + 4]
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nl = wc * WN + j * 32 + frow;
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
         constexpr int C4 = BN / 4;                                   // float4 per tile row
 #pragma unroll
-        for (int it = 0; it < 96 * C4 / 512; ++it) {
+        for (int it = 0; it < BM * C4 / 512; ++it) {
             const int id = tid + 512 * it;
             const int ml = id / C4, c4 = id % C4;
             const long long m = m0 + ml;
@@ -1089,21 +1089,21 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     }
 }
 
-template <int BN, int XPMAX, int ABL = 0, int NDW = 0>
+template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
                    const SepLayer* next = nullptr) {
-    constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (96 + BN) * 64;
-    constexpr size_t lds_tile = 96u * (BN + 4) * 4;
+    constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (BM + BN) * 64;
+    constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int tiles_n = L.cout / BN;
-    const long long tiles = ((M + 95) / 96) * tiles_n;
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
+    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
                        next ? next->dw_b : nullptr, out);
@@ -1670,11 +1670,14 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     const long long M = (long long)windows * L.h_out * L.w_out;
     const int P = L.h_out * L.w_out;
     // auto (measured on MI355X): the 12x8, 6x4 and 3x2 maps run best on the wave-specialised kernel with
-    // 256-wide column tiles, the 24x16 map (K = 128, only 4 stages) on the 4-wave kernel
+    // 96-row x 256-column tiles; the 24x16 map (K = 128, only 4 stages per tile) on the same kernel with
+    // 64-row x 128-column tiles, small enough for two workgroups per CU
     if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128) variant = 3;
+    if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128) variant = 5;   // layer 4
     if (variant >= 3 && L.cin >= 128) {                            // wave-specialised kernels (BM = 96)
-        if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 rows (+ halo rows)
-            launch_sep_ws<128, 128>(in, L, out, M, stream);
+        if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
+            if (variant == 5) launch_sep_ws<128, 96, 0, 0, 64>(in, L, out, M, stream);
+            else launch_sep_ws<128, 128>(in, L, out, M, stream);
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
