@@ -748,9 +748,8 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // BM = 96 output positions (3 MFMA row tiles; 4 / 1 / 16 whole windows for the 6x4 / 12x8 / 3x2 maps, a
 // band of 6 rows for the 24x16 map), BN = 128 or 256 output channels.  Arithmetic order is that of the
 // unfused kernels: results are bit-identical.
-// ABL (timing-only ablations, results wrong): 1 = no global loads inside the K loop, 2 = no depthwise
-// arithmetic, 3 = no MFMAs, 4 = producers only keep the barriers, 5 = consumers only keep the barriers,
-// 6 = no C store.  0 = the real kernel.
+// (ABL is a leftover template slot of the timing ablations used while tuning - no loads / no depthwise /
+//  no MFMA / one role idle / no store; their results are in DESIGN.md.  Always 0.)
 // NDW = 1: the tile (whole windows) is not written; the NEXT layer's stride-2 depthwise (taps ndw_w, shift
 // ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS and only that result goes to out2.
 template <int BN, int XPMAX, int ABL, int NDW, int BM>
@@ -856,7 +855,7 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
         const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * 32);                                    \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
             v4f a4 = bias4;                                                                               \
-            _Pragma("unroll") for (int t = 0; t < (ABL == 2 ? 1 : 9); ++t) {                              \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                               \
                 const v4f v = *reinterpret_cast<const v4f*>(xs_ + xtap[i][t]);                            \
                 a4.x = fmaf(v.x, wt[t].x, a4.x);                                                          \
                 a4.y = fmaf(v.y, wt[t].y, a4.y);                                                          \
@@ -900,11 +899,9 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
         __syncthreads();
         int k = 0;
         for (; k + 3 < nk; ++k) {             // stage k: everything in range
-            if (ABL != 4) {
-                BD_P_STORE(k & 1)             // slab k+2 (loaded during stage k-1)
-                if (ABL != 1) BD_P_LOAD((k + 3) * 32)
-                BD_P_DW((k + 1) & 1, (k + 1) & 1)
-            }
+            BD_P_STORE(k & 1)                 // slab k+2 (loaded during stage k-1)
+            BD_P_LOAD((k + 3) * 32)
+            BD_P_DW((k + 1) & 1, (k + 1) & 1)
             __syncthreads();
         }
         BD_P_STORE(k & 1)                     // k = nk-3: last slab (nk-1) goes in, nothing left to load
@@ -970,13 +967,9 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
                 bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                        \
             }                                                                                             \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                if (ABL == 3) {                                                                           \
-                    asm volatile("" ::"v"(al[i]), "v"(ah[i]), "v"(bl[j]), "v"(bh[j]));                    \
-                } else {                                                                                  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
-                }                                                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);     \
             }                                                                                             \
         }                                                                                                 \
     }
@@ -999,11 +992,9 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     __syncthreads();
     int k = 0;
     for (; k + 2 < nk; ++k) {
-        if (ABL != 5) {
-            BD_C_STORE((k + 1) & 1)           // weights of stage k+1 (loaded during stage k-1)
-            if (ABL != 1) BD_C_LOAD((k + 2) * 32)
-            BD_C_MFMA(k & 1)
-        }
+        BD_C_STORE((k + 1) & 1)               // weights of stage k+1 (loaded during stage k-1)
+        BD_C_LOAD((k + 2) * 32)
+        BD_C_MFMA(k & 1)
         __syncthreads();
     }
     BD_C_STORE((k + 1) & 1)                   // k = nk-2
@@ -1028,11 +1019,7 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = mb + (r & 3) + 8 * (r >> 2);
-                if (ABL == 6) {
-                    if (acc[i][j][r] == 12345.678f) Ct[ml * (BN + 4) + nl] = b;
-                } else {
-                    Ct[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + b, 0.0f);
-                }
+                Ct[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + b, 0.0f);
             }
         }
     }
@@ -1073,7 +1060,7 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
             const long long row2 = (m0 / P + wl) * P2 + pos2;
             *reinterpret_cast<v4f*>(out2 + (size_t)row2 * N + n0 + c4 * 4) = acc;
         }
-    } else if (ABL != 6) {
+    } else {
         // ---- all 8 waves: tile -> HBM as whole rows, 16 bytes per lane ----
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
         constexpr int C4 = BN / 4;                                   // float4 per tile row
@@ -1681,15 +1668,6 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
-            if (variant >= 11 && variant <= 16 && L.cout % 256 == 0) {   // timing-only ablations
-                if (variant == 11) launch_sep_ws<256, 96, 1>(in, L, out, M, stream);
-                if (variant == 12) launch_sep_ws<256, 96, 2>(in, L, out, M, stream);
-                if (variant == 13) launch_sep_ws<256, 96, 3>(in, L, out, M, stream);
-                if (variant == 14) launch_sep_ws<256, 96, 4>(in, L, out, M, stream);
-                if (variant == 15) launch_sep_ws<256, 96, 5>(in, L, out, M, stream);
-                if (variant == 16) launch_sep_ws<256, 96, 6>(in, L, out, M, stream);
-                return true;
-            }
             if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
             else if (L.cout % 128 == 0) launch_sep_ws<128, 96>(in, L, out, M, stream);
             else return false;

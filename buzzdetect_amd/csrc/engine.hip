@@ -50,6 +50,7 @@ struct bd_engine {
     int n_classes = 0;
     int group_windows = kDefaultGroup;
     int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA
+    int frontend_variant = 0;         // 0 = radix-4 x 4 passes, 1 = radix-16 x 16 (one LDS transpose)
     bool fuse_stem = true;            // layers 1-2 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
     bool fuse_stem3 = true;           // the stem also applies layer 3's depthwise (needs fuse_stem)
@@ -491,7 +492,7 @@ int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t ho
     if (h->profiling) Scope::mark(h, (hipStream_t)stream, -1);
     {
         Scope sc(h, (hipStream_t)stream, 0);
-        bd::launch_logmel(pcm_dev, n_samples, g.n_frames, logmel_dev, h->d_tables, (hipStream_t)stream);
+        bd::launch_logmel(pcm_dev, n_samples, g.n_frames, logmel_dev, h->d_tables, (hipStream_t)stream, h->frontend_variant);
     }
     BD_HIP(hipGetLastError());
     return BD_OK;
@@ -591,7 +592,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
     if (e->profiling) Scope::mark(e, stream, -1);
     {
         Scope sc(e, stream, 0);
-        bd::launch_logmel(pcm, n, g.n_frames, logmel, e->d_tables, stream);
+        bd::launch_logmel(pcm, n, g.n_frames, logmel, e->d_tables, stream, e->frontend_variant);
     }
     for (int64_t w0 = 0; w0 < g.n_windows; w0 += group) {
         const int gw = stop_stage >= 0 ? tap_windows : (int)(g.n_windows - w0 < group ? g.n_windows - w0 : group);
@@ -735,6 +736,12 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
     if (!h || layer < 2 || layer > 14) return fail(BD_EINVAL, "bd_set_pointwise_variant: layer must be 2..14");
     if (h->sep[layer - 2].pw_mode == 1) h->sep[layer - 2].pw_variant16 = variant;
     else h->sep[layer - 2].pw_variant = variant;
+    return BD_OK;
+}
+
+int bd_set_frontend_variant(bd_handle h, int32_t variant) {
+    if (!h || variant < 0 || variant > 1) return fail(BD_EINVAL, "bd_set_frontend_variant: variant must be 0 or 1");
+    h->frontend_variant = variant;
     return BD_OK;
 }
 

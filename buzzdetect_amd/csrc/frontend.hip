@@ -171,6 +171,160 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Second formulation of the same transform: 256 = 16 x 16.  Sixteen lanes own one frame (four frames per
+// wavefront), lane n2 holds the 16 packed points z[16 n1 + n2] in registers:
+//   DFT-16 over n1 in registers -> twiddle W256^(n2 k1) -> ONE transpose through LDS -> DFT-16 over n2 in
+//   registers -> Z[k1 + 16 k2] -> natural order in LDS -> real split against Z[256 - k] -> |X| -> LDS ->
+//   banded mel with lane = band (as above), one frame after the other -> logf.
+// Three wave-level sync points per four frames instead of six per frame; same arithmetic definition
+// (results differ from logmel_kernel only by float summation order).
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 c_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+__device__ __forceinline__ void radix4(float2 u0, float2 u1, float2 u2, float2 u3, float2& y0, float2& y1,
+                                       float2& y2, float2& y3) {
+    const float2 s0 = c_add(u0, u2), s1 = c_sub(u0, u2), s2 = c_add(u1, u3), s3 = c_mi(c_sub(u1, u3));
+    y0 = c_add(s0, s2);
+    y1 = c_add(s1, s3);
+    y2 = c_sub(s0, s2);
+    y3 = c_sub(s1, s3);
+}
+
+// in-place forward DFT of 16 points, natural order in and out (two radix-4 stages in registers)
+__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+    constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f, H = 0.70710678118654752f;
+    float2 a[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) radix4(x[q], x[4 + q], x[8 + q], x[12 + q], a[q][0], a[q][1], a[q][2], a[q][3]);
+    a[1][1] = cmul(a[1][1], make_float2(C, -S));     // W16^1
+    a[1][2] = cmul(a[1][2], make_float2(H, -H));     // W16^2
+    a[1][3] = cmul(a[1][3], make_float2(S, -C));     // W16^3
+    a[2][1] = cmul(a[2][1], make_float2(H, -H));     // W16^2
+    a[2][2] = c_mi(a[2][2]);                         // W16^4 = -i
+    a[2][3] = cmul(a[2][3], make_float2(-H, -H));    // W16^6
+    a[3][1] = cmul(a[3][1], make_float2(S, -C));     // W16^3
+    a[3][2] = cmul(a[3][2], make_float2(-H, -H));    // W16^6
+    a[3][3] = cmul(a[3][3], make_float2(-C, S));     // W16^9
+#pragma unroll
+    for (int r = 0; r < 4; ++r) radix4(a[0][r], a[1][r], a[2][r], a[3][r], x[r], x[r + 4], x[r + 8], x[r + 12]);
+}
+
+__global__ __launch_bounds__(256) void logmel16_kernel(const float* __restrict__ pcm, long long n_valid,
+                                                       long long n_frames, float* __restrict__ out,
+                                                       const FeTables* __restrict__ tab) {
+    constexpr int TZ = 17 * 16;                            // transposed tile: rows of 17 (bank padding)
+    __shared__ __attribute__((aligned(16))) float s_pcm[kGroupSamples];
+    __shared__ __attribute__((aligned(16))) float2 s_t[kWaves][4][TZ];      // transpose, then Z, then |X|
+    __shared__ __attribute__((aligned(16))) float2 s_tw512[256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int fq = lane >> 4;                              // frame within the wave
+    const int n2 = lane & 15;                              // also k1 after the transpose
+
+    s_tw512[tid] = tab->tw512[tid];
+    float2 hann2[13];                                      // Hann taps of z[16 n1 + n2], n1 = 0..12
+#pragma unroll
+    for (int n1 = 0; n1 < 13; ++n1) {
+        const int e = 2 * (16 * n1 + n2);
+        hann2[n1] = e < BD_STFT_WINDOW ? make_float2(tab->hann[e], tab->hann[e + 1]) : make_float2(0.f, 0.f);
+    }
+    float2 tw[15];                                         // W256^(n2 k1), k1 = 1..15
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tab->tw256[(n2 * k1) & 255];
+    const int band_start = tab->band_start[lane];
+    const int band_len = tab->band_len[lane];
+    float bw[kMelTaps];
+#pragma unroll
+    for (int j = 0; j < kMelTaps; ++j) bw[j] = j < band_len ? tab->band_w[j][lane] : 0.0f;
+    const int max_len = tab->max_len;
+
+    float2* const t_mine = s_t[wave][fq];
+    float* const mag_wave = reinterpret_cast<float*>(s_t[wave]);            // [4][2 * TZ] floats, |X| at [f][k]
+
+    const long long n_groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
+    for (long long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        __syncthreads();
+        const long long base = group * (long long)(kGroupFrames * BD_STFT_HOP);
+        for (int i = tid; i < kGroupSamples; i += 256) {
+            const long long idx = base + i;
+            s_pcm[i] = idx < n_valid ? pcm[idx] : 0.0f;
+        }
+        __syncthreads();
+
+        const int fl = wave * 4 + fq;                                       // frame of this 16-lane group
+        const float* x = s_pcm + fl * BD_STFT_HOP;
+        float2 u[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            if (n1 < 13) {
+                const int e = 2 * (16 * n1 + n2);
+                float2 xv = make_float2(0.f, 0.f);
+                if (e < BD_STFT_WINDOW) xv = *reinterpret_cast<const float2*>(x + e);
+                u[n1] = make_float2(xv.x * hann2[n1].x, xv.y * hann2[n1].y);
+            } else {
+                u[n1] = make_float2(0.f, 0.f);
+            }
+        }
+        dft16(u);                                                           // over n1 -> k1
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) u[k1] = cmul(u[k1], tw[k1 - 1]);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) t_mine[k1 * 17 + n2] = u[k1];
+        wave_lds_sync();
+#pragma unroll
+        for (int m2 = 0; m2 < 16; ++m2) u[m2] = t_mine[n2 * 17 + m2];       // lane k1 = n2 gathers over n2
+        wave_lds_sync();                                                    // tile is rewritten below
+        dft16(u);                                                           // over n2 -> k2: u[k2] = Z[k1 + 16 k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t_mine[n2 + 16 * k2] = u[k2];       // natural order
+        wave_lds_sync();
+        float mg[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = n2 + 16 * k2;
+            const float2 zk = u[k2];
+            const float2 zm = t_mine[(256 - k) & 255];
+            const float ex = 0.5f * (zk.x + zm.x);
+            const float ey = 0.5f * (zk.y - zm.y);
+            const float ox = 0.5f * (zk.y + zm.y);
+            const float oy = -0.5f * (zk.x - zm.x);
+            const float2 t = s_tw512[k];
+            const float xr = ex + (t.x * ox - t.y * oy);
+            const float xi = ey + (t.x * oy + t.y * ox);
+            mg[k2] = sqrtf(xr * xr + xi * xi);
+        }
+        const float nyq = fabsf(u[0].x - u[0].y);                           // meaningful in lane k1 = 0 only
+        wave_lds_sync();                                                    // Z reads done: overwrite with |X|
+        float* mag = mag_wave + fq * (2 * TZ);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) mag[n2 + 16 * k2] = mg[k2];
+        if (n2 == 0) mag[256] = nyq;
+        if (n2 < 7) mag[257 + n2] = 0.0f;                                   // padding read by the fixed-length loop
+        wave_lds_sync();
+
+        // ---- banded mel + log: lane = band, the wave's four frames one after the other ----
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float* mf = mag_wave + f * (2 * TZ);
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMelTaps; ++j) {
+                if (j < max_len) {
+                    const float m = mf[band_start + j];
+                    if (j < band_len) acc = fmaf(m, bw[j], acc);
+                }
+            }
+            const long long frame = group * kGroupFrames + wave * 4 + f;
+            if (frame < n_frames) out[frame * BD_MEL_BANDS + lane] = logf(acc + 0.001f);
+        }
+        wave_lds_sync();
+    }
+}
+
 __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ logmel, long long n_windows,
                                                       int patch_step, float* __restrict__ patches) {
     // tf.signal.frame(axis=0) (features.py:72-76): patch w = frames [w*step, w*step + 96)
@@ -231,10 +385,15 @@ void launch_resample(const float* in, int64_t n_in, int channels, const float* t
 }
 
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
-                   const FeTables* tables, hipStream_t stream) {
+                   const FeTables* tables, hipStream_t stream, int variant) {
     if (n_frames <= 0) return;
     const int64_t groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
     const int grid = (int)(groups < 4096 ? groups : 4096);
+    if (variant == 1) {
+        hipLaunchKernelGGL(logmel16_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
+                           (long long)n_frames, logmel, tables);
+        return;
+    }
     hipLaunchKernelGGL(logmel_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
                        (long long)n_frames, logmel, tables);
 }

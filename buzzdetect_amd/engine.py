@@ -113,6 +113,10 @@ class HipEngine:
         """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class)."""
         _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1}[mode]))
 
+    def set_frontend_variant(self, variant: int) -> None:
+        """0 = radix-4 x 4-pass FFT, 1 = radix-16 x 16 FFT (one LDS transpose)."""
+        _lib.check(self._lib.bd_set_frontend_variant(self._handle, int(variant)))
+
     def set_fusion(self, stem=True, separable=True) -> None:
         """Fused stem kernel (True/2 = incl. layer 3's depthwise, 1 = layers 1-2 only, False = off) and
         fused depthwise+pointwise kernels (True / variant number / False)."""

@@ -156,6 +156,10 @@ BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int3
    1 = split-f16 (default): every f32 operand carried as hi + lo halves, three f16 MFMAs per product,
    f32 accumulate; same accuracy class as f32, ~5x the matrix-core rate. */
 BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
+/* Front-end FFT formulation: 0 = radix-4, four passes through LDS; 1 = radix-16 x radix-16 with one LDS
+   transpose (same definition; float summation order differs). */
+BD_API int bd_set_frontend_variant(bd_handle h, int32_t variant);
+
 /* Kernel fusion in mode 1 (both on by default; 0 = one kernel per op, the layout the stage taps use):
    stem == 1       layers 1-2 (conv, depthwise, pointwise) as one kernel, timed in profile slot 3;
    stem == 2       (default) that kernel also applies layer 3's stride-2 depthwise and writes only its

@@ -33,6 +33,22 @@ def test_frontend_shapes_and_values_ragged_lengths(engine, weights_bundle, n):
     assert np.abs(got - ref).max() < 5e-5
 
 
+@pytest.mark.parametrize("n", [0, 399, 15600, 100_001, 16 * 160 * 5 + 400])
+def test_frontend_radix16_variant(engine, weights_bundle, n):
+    """The radix-16 x radix-16 formulation of the front end against the same oracle and the default kernel."""
+    x = O.synthetic_audio(max(n, 1), seed=n + 1)[:n]
+    ref = O.log_mel(O.pad_waveform(x, HOP), weights_bundle["mel"], np.float64)
+    base = engine.frontend(x if n else np.zeros(0, np.float32), HOP).cpu().numpy()
+    try:
+        engine.set_frontend_variant(1)
+        got = engine.frontend(x if n else np.zeros(0, np.float32), HOP).cpu().numpy()
+    finally:
+        engine.set_frontend_variant(0)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 5e-5
+    assert np.abs(got - base).max() < 5e-5
+
+
 def test_frontend_silence_is_the_log_floor(engine):
     # log(0 + 0.001): one constant everywhere, within float32 libm accuracy (1-2 ulp) of ln(0.001f)
     got = engine.frontend(np.zeros(40000, np.float32), HOP).cpu().numpy()
