@@ -455,7 +455,10 @@ void launch_pw16(const float* A, const _Float16* Whi, const _Float16* Wlo, const
                  long long M, int N, int K, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = 2u * 2u * (BM + BN) * 64;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_f16x3_kernel<BM, BN, WGM, WGN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -472,7 +475,10 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
                hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = 2u * (BM + BN) * kLds * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_kernel<BM, BN, WGM, WGN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -724,7 +730,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void sep_s1_kernel(
 template <int BM, int BN, int WGM, int WGN, int XPMAX>
 void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
     constexpr size_t lds = (size_t)(XPMAX + 1 + 10) * 128 + 2u * 2u * (BM + BN) * 64;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_s1_kernel<BM, BN, WGM, WGN, XPMAX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1082,7 +1091,10 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
     constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (BM + BN) * 64;
     constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

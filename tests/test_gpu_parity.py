@@ -322,3 +322,26 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
             assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
     finally:
         engine.set_fusion(True, True)
+
+
+@pytest.mark.parametrize("hop_prop,expect", [(1.0, 625), (0.5, 1249)])
+def test_config3_ten_minute_chunk(engine, weights_bundle, hop_prop, expect):
+    """BASELINE config 3: a 600.0 s chunk (9 600 000 samples) of a 24 h recording, yamnet_k2 at whole and half hop:
+    row count exact, rows independent of the rest of the chunk, oracle spot checks incl. the padded last row."""
+    import torch
+    from buzzdetect_amd import framing
+    assert framing.round_chunklength(600) == 600.0
+    n = 9_600_000
+    gen = torch.Generator(device="cpu").manual_seed(33)
+    x = (0.1 * torch.randn(n, generator=gen)).clamp_(-1, 1)
+    xd = x.to(engine.device)
+    got = engine.predict(xd, 0.96 * hop_prop).numpy()
+    hop = int(15360 * hop_prop)
+    assert got.shape == (expect, 13) == (O.num_windows(n, hop), 13)
+    assert np.all(np.isfinite(got))
+    for j in (0, expect // 2, expect - 1):
+        seg = x[j * hop: j * hop + 15600].numpy()
+        ref = oracle_logits(seg, weights_bundle)[0]
+        assert np.abs(got[j] - ref).max() < TOL_LOGITS, j
+    sub = engine.predict(xd[5 * hop: 5 * hop + 15600 + 3 * hop], 0.96 * hop_prop).numpy()
+    assert np.array_equal(sub[:3], got[5:8])
