@@ -761,7 +761,11 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 //  no MFMA / one role idle / no store; their results are in DESIGN.md.  Always 0.)
 // NDW = 1: the tile (whole windows) is not written; the NEXT layer's stride-2 depthwise (taps ndw_w, shift
 // ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS and only that result goes to out2.
-template <int BN, int XPMAX, int ABL, int NDW, int BM>
+// BDIR = 1: the consumers do not stage the weights through LDS at all.  With the 1 x 4 consumer layout every
+// wave owns its own WN output columns, so a weight fragment is used by exactly one wave: each lane loads its
+// MFMA B fragments (16 bytes of hi, 16 of lo per k-step and column tile) straight from global/L2 into a
+// double-buffered register set, one stage ahead.
+template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR>
 __global__ __launch_bounds__(512) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
@@ -926,6 +930,69 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     } else {
     // ===================================================================== consumers
     const int wc = wave;                      // column block of this wave
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int frow = lane & 31;
+    const int fh = lane >> 5;
+    if constexpr (BDIR) {
+        // fragment pointers: column tile j -> row n0 + wc*WN + 32 j + frow of W^T, k offset 8 (2 s + fh)
+        const _Float16* wph[TN];
+        const _Float16* wpl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const size_t row = (size_t)(n0 + wc * WN + j * 32 + frow) * K + fh * 8;
+            wph[j] = Whi + row;
+            wpl[j] = Wlo + row;
+        }
+        f16x8 b0h[TN][2], b0l[TN][2], b1h[TN][2], b1l[TN][2];    // fragments of an even / an odd stage
+#define BD_W_LOAD(BH, BL, KOFF)                                                                           \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s) {    \
+            BH[j][s] = *reinterpret_cast<const f16x8*>(wph[j] + (KOFF) + 16 * s);                         \
+            BL[j][s] = *reinterpret_cast<const f16x8*>(wpl[j] + (KOFF) + 16 * s);                         \
+        }                                                                                                 \
+    }
+#define BD_W_MFMA(BUF, BH, BL)                                                                            \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
+            f16x8 ah[TM], al[TM];                                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
+                const int off = (BUF) * A_BYTES + swz64(i * 32 + frow, 2 * s + fh);                       \
+                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
+                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
+            }                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], BH[j][s], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BL[j][s], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BH[j][s], acc[i][j], 0, 0, 0);  \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+        BD_W_LOAD(b0h, b0l, 0)
+        BD_W_LOAD(b1h, b1l, 32)
+        __syncthreads();
+        __syncthreads();
+        int k = 0;
+        for (; k + 2 < nk; k += 2) {          // nk is even and >= 4
+            BD_W_MFMA(0, b0h, b0l)
+            BD_W_LOAD(b0h, b0l, (k + 2) * 32)
+            __syncthreads();
+            BD_W_MFMA(1, b1h, b1l)
+            BD_W_LOAD(b1h, b1l, (k + 3) * 32)
+            __syncthreads();
+        }
+        BD_W_MFMA(0, b0h, b0l)                // stage nk-2
+        __syncthreads();
+        BD_W_MFMA(1, b1h, b1l)                // stage nk-1
+        __syncthreads();
+#undef BD_W_LOAD
+#undef BD_W_MFMA
+    } else {
     const _Float16* bph[BCH];
     const _Float16* bpl[BCH];
     int b_st[BCH];
@@ -937,13 +1004,6 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
         bpl[i] = Wlo + (size_t)(n0 + row) * K + slot * 8;
         b_st[i] = swz64(row, slot);
     }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     v4u rbh[BCH], rbl[BCH];
 #define BD_C_LOAD(KOFF)                                                                                   \
     {                                                                                                     \
@@ -959,8 +1019,6 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
             *reinterpret_cast<v4u*>(Bl + (BB) * B_BYTES + b_st[i]) = rbl[i];                              \
         }                                                                                                 \
     }
-    const int frow = lane & 31;
-    const int fh = lane >> 5;
 #define BD_C_MFMA(BUF)                                                                                    \
     {                                                                                                     \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
@@ -1015,6 +1073,8 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
 #undef BD_C_LOAD
 #undef BD_C_STORE
 #undef BD_C_MFMA
+
+    }   // staged weights
 
     // bias + ReLU into an f32 tile in LDS (every stage buffer is dead after the last barrier)
     float* const Ct = reinterpret_cast<float*>(smem_raw);          // [BM][BN + 4]
@@ -1085,10 +1145,10 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     }
 }
 
-template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96>
+template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
                    const SepLayer* next = nullptr) {
-    constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (BM + BN) * 64;
+    constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (BM + (BDIR ? 0 : BN)) * 64;
     constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
     static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
@@ -1096,13 +1156,13 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int tiles_n = L.cout / BN;
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
                        next ? next->dw_b : nullptr, out);
@@ -1680,7 +1740,8 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
-            if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
+            if (variant == 6 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1>(in, L, out, M, stream);
+            else if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
             else if (L.cout % 128 == 0) launch_sep_ws<128, 96>(in, L, out, M, stream);
             else return false;
             return true;
