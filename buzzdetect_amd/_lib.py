@@ -59,6 +59,10 @@ PROTOTYPES = {
                            C.c_void_p, C.c_void_p]),
     "bd_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bd_batch_num_windows": (C.c_int64, [C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "bd_batch_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32]),
+    "bd_predict_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_stage_shape": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bd_stage_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -28,6 +28,7 @@ import numpy as np
 from . import framing, results, sharding
 
 FILE_SIZE_MINIMUM = 5000          # src/config.py:20
+BATCH_WINDOWS = 1024              # windows gathered per launch set
 EXTENSIONS = (".wav",)
 
 
@@ -105,7 +106,7 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
 
     ``classes_out`` / ``precision`` choose activations vs detections exactly as in the reference;
     ``rank`` / ``world_size`` default to the torch.distributed environment (one process per GPU)."""
-    from .engine import HipEngine   # device code is only needed once there is work to do
+    from .engine import HipEngine, hop_samples, patch_step   # device code is only needed once there is work to do
 
     report = AnalyzeReport()
     if rank is None or world_size is None:
@@ -156,7 +157,24 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
         track = WavTrack(path)
         try:
             chunks = rf.pending_chunks(track.duration, chunklength, framelength_s)
-            pending = None                                   # (DeviceResult, chunk) still on the device
+            # Chunks are gathered into batches of up to ~BATCH_WINDOWS windows (<= 64 chunks) and go through
+            # ONE launch set (bd_predict_batch); every chunk keeps its own end-of-chunk padding, so the rows are
+            # those of one predict() per chunk.  The previous batch's rows are written while this one runs.
+            batch, batch_windows = [], 0
+            in_flight = None                                  # (list of DeviceResult, list of chunks)
+
+            def flush():
+                nonlocal batch, batch_windows, in_flight
+                if not batch:
+                    return
+                res = eng.predict_batch([pcm for _, pcm in batch], framehop_s)
+                if in_flight is not None:
+                    for r, c in zip(*in_flight):
+                        rf.append(table_for(r.numpy(), c[0]))
+                in_flight = (res, [c for c, _ in batch])
+                report.windows += sum(len(r) for r in res)
+                batch, batch_windows = [], 0
+
             stop = False
             for chunk in chunks:
                 a, b = framing.chunk_sample_range(chunk, track.samplerate)
@@ -171,17 +189,18 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
                     pcm = eng.resample(samples, track.samplerate, 16000)
                 else:
                     pcm = samples[:, 0]
-                res = eng.predict(pcm, framehop_s)
-                if pending is not None:                      # write the previous chunk while this one runs
-                    rf.append(table_for(pending[0].numpy(), pending[1][0]))
-                pending = (res, chunk)
+                batch.append((chunk, pcm))
+                batch_windows += eng.num_windows(len(pcm), hop_samples(framehop_s), patch_step(framehop_s))
                 report.chunks += 1
-                report.windows += len(res)
                 report.audio_seconds += float(chunk[1] - chunk[0])
+                if batch_windows >= BATCH_WINDOWS or len(batch) == 64:
+                    flush()
                 if stop:
                     break
-            if pending is not None:
-                rf.append(table_for(pending[0].numpy(), pending[1][0]))
+            flush()
+            if in_flight is not None:
+                for r, c in zip(*in_flight):
+                    rf.append(table_for(r.numpy(), c[0]))
             if os.path.exists(rf.path_partial):
                 rf.finalize()
             report.files_done += 1

@@ -23,6 +23,22 @@ struct FeTables {
     float  band_w[kMelMaxLen][BD_MEL_BANDS];  // band_w[j][m] = mel[band_start[m] + j][m]
 };
 
+// Which log-mel frames a window reads when one launch covers several chunks: the chunks' log-mel rows are
+// packed back to back; window w of chunk c (win_start[c] <= w < win_start[c + 1]) is frames
+// [frame_base[c] + (w - win_start[c]) * step, + 96).  Passed to the stem kernels by value.
+constexpr int kMaxBatchChunks = 64;
+struct WindowMap {
+    int n_chunks;
+    int win_start[kMaxBatchChunks + 1];
+    int frame_base[kMaxBatchChunks];
+};
+
+__device__ __forceinline__ long long window_frame(const WindowMap& m, int w, int step) {
+    int c = 0;
+    while (c + 1 < m.n_chunks && w >= m.win_start[c + 1]) ++c;
+    return (long long)m.frame_base[c] + (long long)(w - m.win_start[c]) * step;
+}
+
 // One separable layer (yamnet.py:52-74) after BatchNorm folding.
 struct SepLayer {
     int cin, cout, stride;
@@ -45,7 +61,7 @@ void launch_resample(const float* in, int64_t n_in, int channels, const float* t
                      float* out, int64_t n_out, hipStream_t stream);
 void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
                     hipStream_t stream);
-void launch_conv1(const float* logmel, int patch_step, int windows, const float* w9x32,
+void launch_conv1(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* w9x32,
                   const float* b32, float* out, hipStream_t stream);
 void launch_depthwise(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream);
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream);
@@ -57,9 +73,11 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
                             hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     hipStream_t stream);
-void launch_stem(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
+void launch_stem(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                 const float* c1_b,
                  const SepLayer& L2, float* out, hipStream_t stream);
-void launch_stem3(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
+void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                  const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
                       int n_classes, float* emb, float* logits, hipStream_t stream);

@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kC1Rows = 4;   // output rows per workgroup
 
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ logmel, int patch_step,
+                                                    const WindowMap map, int w0,
                                                     const float* __restrict__ w9x32,
                                                     const float* __restrict__ b32,
                                                     float* __restrict__ out) {
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ lo
     const int c4 = tid & 7;
     const int ow = tid >> 3;
     const int win = blockIdx.y;
-    const float* patch = logmel + (size_t)win * patch_step * BD_MEL_BANDS;
+    const float* patch = logmel + window_frame(map, w0 + win, patch_step) * BD_MEL_BANDS;
 
     float4 wt[9];
 #pragma unroll
@@ -1179,6 +1180,7 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
 constexpr int kStemRows = 4;
 
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ logmel, int patch_step,
+                                                   const WindowMap map, int w0,
                                                    const float* __restrict__ c1_w, const float* __restrict__ c1_b,
                                                    const float* __restrict__ dw_w, const float* __restrict__ dw_b,
                                                    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
@@ -1198,7 +1200,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
     const int wave = tid >> 6;
     const int win = blockIdx.y;
     const int oh0 = blockIdx.x * kStemRows;
-    const float* patch = logmel + (size_t)win * patch_step * BD_MEL_BANDS;
+    const float* patch = logmel + window_frame(map, w0 + win, patch_step) * BD_MEL_BANDS;
 
     // ---- phase A: log-mel band, zero halo columns; this lane's weight fragments (used in phase D) ----
     f16x8 wbh[2], wbl[2];
@@ -1361,6 +1363,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
 //   F  depthwise 3 (stride 2, SAME = pad 0 before / 1 after) on P -> HBM, [2][16][64] per workgroup
 // Arithmetic order per element equals conv1_kernel / depthwise_kernel / pointwise_f16x3_kernel.
 __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ logmel, int patch_step,
+                                                    const WindowMap map, int w0,
                                                     const float* __restrict__ c1_w, const float* __restrict__ c1_b,
                                                     const float* __restrict__ dw2_w, const float* __restrict__ dw2_b,
                                                     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
@@ -1391,7 +1394,7 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
     const int win = blockIdx.y;
     const int ob = blockIdx.x;                  // 0..11: depthwise-3 rows 2 ob, 2 ob + 1
     const int r0 = 4 * ob;                      // first layer-2 row of the tile
-    const float* patch = logmel + (size_t)win * patch_step * BD_MEL_BANDS;
+    const float* patch = logmel + window_frame(map, w0 + win, patch_step) * BD_MEL_BANDS;
 
     // this lane's pointwise weight fragments (phase D)
     f16x8 wbh[2], wbl[2];
@@ -1607,10 +1610,10 @@ __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict_
 
 }  // namespace
 
-void launch_conv1(const float* logmel, int patch_step, int windows, const float* w9x32, const float* b32,
-                  float* out, hipStream_t stream) {
+void launch_conv1(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* w9x32,
+                  const float* b32, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-    hipLaunchKernelGGL(conv1_kernel, dim3(48 / kC1Rows, windows), dim3(256), 0, stream, logmel, patch_step,
+    hipLaunchKernelGGL(conv1_kernel, dim3(48 / kC1Rows, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,
                        w9x32, b32, out);
 }
 
@@ -1761,18 +1764,18 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     return false;
 }
 
-void launch_stem(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
-                 const SepLayer& L2, float* out, hipStream_t stream) {
+void launch_stem(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                 const float* c1_b, const SepLayer& L2, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-    hipLaunchKernelGGL(stem_kernel, dim3(48 / kStemRows, windows), dim3(256), 0, stream, logmel, patch_step, c1_w,
+    hipLaunchKernelGGL(stem_kernel, dim3(48 / kStemRows, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
                        c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
                        static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, out);
 }
 
-void launch_stem3(const float* logmel, int patch_step, int windows, const float* c1_w, const float* c1_b,
-                  const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
+void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                  const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-    hipLaunchKernelGGL(stem3_kernel, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, c1_w, c1_b,
+    hipLaunchKernelGGL(stem3_kernel, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w, c1_b,
                        L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
                        static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out);
 }

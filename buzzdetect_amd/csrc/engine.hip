@@ -563,22 +563,63 @@ int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t p
 
 namespace {
 
-// The launch plan of one chunk.  stop_stage < 0: run everything; otherwise stop after that CNN
-// stage of the first group and copy it to tap_out.
-int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t step, void* ws, int64_t ws_bytes,
-              float* emb, float* logits, int stop_stage, int tap_windows, float* tap_out, hipStream_t stream) {
-    if (!e) return fail(BD_EINVAL, "null handle");
-    if (!pcm && n > 0) return fail(BD_EINVAL, "null pcm pointer");
+// Geometry of a batch of chunks processed in one launch set (each chunk keeps its own zero padding).
+struct BatchPlan {
+    bd::WindowMap map;
+    int64_t sample_base[bd::kMaxBatchChunks];
+    int64_t frames[bd::kMaxBatchChunks];
+    int64_t total_frames, total_windows;
+};
+
+int plan_batch(const int64_t* chunk_samples, int32_t n_chunks, int32_t hop, int32_t step, BatchPlan* p) {
+    if (!chunk_samples || n_chunks <= 0 || n_chunks > bd::kMaxBatchChunks)
+        return fail(BD_EINVAL, "batch must hold 1..64 chunks");
     if (step <= 0) return fail(BD_EINVAL, "patch_step must be > 0");
+    p->map.n_chunks = n_chunks;
+    int64_t samples = 0, frames = 0, windows = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        Geometry g;
+        const int rc = geometry(chunk_samples[c], hop, step, &g);
+        if (rc < 0) return rc;
+        p->sample_base[c] = samples;
+        p->frames[c] = g.n_frames;
+        p->map.win_start[c] = (int)windows;
+        p->map.frame_base[c] = (int)frames;
+        samples += chunk_samples[c];
+        frames += g.n_frames;
+        windows += g.n_windows;
+        if (frames > (1LL << 30)) return fail(BD_ERANGE, "batch too large");
+    }
+    p->map.win_start[n_chunks] = (int)windows;
+    p->total_frames = frames;
+    p->total_windows = windows;
+    return BD_OK;
+}
+
+int64_t batch_workspace(const bd_engine* e, const BatchPlan& p) {
+    const int64_t group = p.total_windows < e->group_windows ? p.total_windows : e->group_windows;
+    return align_up(p.total_frames * BD_MEL_BANDS * 4, 256) + align_up(group * kFloatsA * 4, 256) +
+           align_up(group * kFloatsB * 4, 256) + 256;
+}
+
+// The launch plan of one batch of chunks.  stop_stage < 0: run everything; otherwise stop after that CNN
+// stage of the first group and copy it to tap_out.
+int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int32_t n_chunks, int32_t hop,
+               int32_t step, void* ws, int64_t ws_bytes, float* emb, float* logits, int stop_stage, int tap_windows,
+               float* tap_out, hipStream_t stream) {
+    if (!e) return fail(BD_EINVAL, "null handle");
     if (misaligned(pcm) || misaligned(ws) || misaligned(emb) || misaligned(logits) || misaligned(tap_out))
         return fail(BD_EINVAL, "device pointers need 16-byte alignment");
     if (logits && e->n_classes == 0) return fail(BD_EINVAL, "engine was created without a head");
-    Geometry g;
-    int rc = geometry(n, hop, step, &g);
+    BatchPlan plan;
+    int rc = plan_batch(chunk_samples, n_chunks, hop, step, &plan);
     if (rc < 0) return rc;
-    const int64_t need = bd_workspace_bytes(e, n, hop, step);
-    if (need < 0) return (int)need;
+    int64_t total_samples = 0;
+    for (int c = 0; c < n_chunks; ++c) total_samples += chunk_samples[c];
+    if (!pcm && total_samples > 0) return fail(BD_EINVAL, "null pcm pointer");
+    const int64_t need = batch_workspace(e, plan);
     if (!ws || ws_bytes < need) return fail(BD_EWORKSPACE, "workspace smaller than bd_workspace_bytes()");
+    struct { int64_t n_frames, n_windows; } g = {plan.total_frames, plan.total_windows};
     if (stop_stage >= 0 && (tap_windows <= 0 || tap_windows > g.n_windows || tap_windows > e->group_windows))
         return fail(BD_EINVAL, "bd_stage_tap: windows must be in 1..min(n_windows, group)");
     BD_HIP(hipSetDevice(e->device));
@@ -590,13 +631,15 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
     float* const buf_b0 = reinterpret_cast<float*>(reinterpret_cast<char*>(buf_a0) + align_up(group * kFloatsA * 4, 256));
 
     if (e->profiling) Scope::mark(e, stream, -1);
-    {
+    for (int c = 0; c < n_chunks; ++c) {       // one front-end launch per chunk: its padding is its own
         Scope sc(e, stream, 0);
-        bd::launch_logmel(pcm, n, g.n_frames, logmel, e->d_tables, stream, e->frontend_variant);
+        bd::launch_logmel(pcm + plan.sample_base[c], chunk_samples[c], plan.frames[c],
+                          logmel + (int64_t)plan.map.frame_base[c] * BD_MEL_BANDS, e->d_tables, stream,
+                          e->frontend_variant);
     }
+    const float* const lm = logmel;
     for (int64_t w0 = 0; w0 < g.n_windows; w0 += group) {
         const int gw = stop_stage >= 0 ? tap_windows : (int)(g.n_windows - w0 < group ? g.n_windows - w0 : group);
-        const float* lm = logmel + w0 * step * BD_MEL_BANDS;
         // buf_a holds the latest conv/pointwise output, buf_b the scratch side; the fused separable
         // layers swap the two (everything after layer 2 fits the smaller buffer), so start each pass
         // from the sized assignment: A = 98 304 floats/window, B = 49 152
@@ -615,7 +658,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         if (fuse_stem3) {
             {
                 Scope sc(e, stream, 4);      // timed in the slot of depthwise 3 (slots 1-3 stay empty)
-                bd::launch_stem3(lm, step, gw, e->conv1_w, e->conv1_b, e->sep[0], e->sep[1], buf_b, stream);
+                bd::launch_stem3(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, e->sep[0], e->sep[1], buf_b, stream);
             }
             last = buf_b;
             last_floats = (int64_t)gw * 24 * 16 * 64;
@@ -624,7 +667,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         } else if (fuse_stem) {
             {
                 Scope sc(e, stream, 3);
-                bd::launch_stem(lm, step, gw, e->conv1_w, e->conv1_b, e->sep[0], buf_a, stream);
+                bd::launch_stem(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, e->sep[0], buf_a, stream);
             }
             last_floats = (int64_t)gw * 48 * 32 * 64;
             stopped = stop_stage == 2;
@@ -632,7 +675,7 @@ int run_chunk(bd_engine* e, const float* pcm, int64_t n, int32_t hop, int32_t st
         } else {
             {
                 Scope sc(e, stream, 1);
-                bd::launch_conv1(lm, step, gw, e->conv1_w, e->conv1_b, buf_a, stream);
+                bd::launch_conv1(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, buf_a, stream);
             }
             last_floats = (int64_t)gw * 48 * 32 * 32;
             stopped = stop_stage == 0;
@@ -703,15 +746,42 @@ extern "C" {
 int bd_embed(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
              void* workspace_dev, int64_t workspace_bytes, float* emb_dev, void* stream) {
     if (!emb_dev) return fail(BD_EINVAL, "bd_embed: null output");
-    return run_chunk(h, pcm_dev, n_samples, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
-                     nullptr, -1, 0, nullptr, (hipStream_t)stream);
+    return run_chunks(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
+                      nullptr, -1, 0, nullptr, (hipStream_t)stream);
 }
 
 int bd_predict(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
                void* workspace_dev, int64_t workspace_bytes, float* emb_dev, float* logits_dev, void* stream) {
     if (!logits_dev) return fail(BD_EINVAL, "bd_predict: null output");
-    return run_chunk(h, pcm_dev, n_samples, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
-                     logits_dev, -1, 0, nullptr, (hipStream_t)stream);
+    return run_chunks(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
+                      logits_dev, -1, 0, nullptr, (hipStream_t)stream);
+}
+
+int64_t bd_batch_num_windows(const int64_t* chunk_samples, int32_t n_chunks, int32_t hop_samples, int32_t patch_step,
+                             int64_t* per_chunk_windows) {
+    BatchPlan plan;
+    const int rc = plan_batch(chunk_samples, n_chunks, hop_samples, patch_step, &plan);
+    if (rc < 0) return rc;
+    if (per_chunk_windows)
+        for (int c = 0; c < n_chunks; ++c) per_chunk_windows[c] = plan.map.win_start[c + 1] - plan.map.win_start[c];
+    return plan.total_windows;
+}
+
+int64_t bd_batch_workspace_bytes(bd_handle h, const int64_t* chunk_samples, int32_t n_chunks, int32_t hop_samples,
+                                 int32_t patch_step) {
+    if (!h) return fail(BD_EINVAL, "bd_batch_workspace_bytes: null handle");
+    BatchPlan plan;
+    const int rc = plan_batch(chunk_samples, n_chunks, hop_samples, patch_step, &plan);
+    if (rc < 0) return rc;
+    return batch_workspace(h, plan);
+}
+
+int bd_predict_batch(bd_handle h, const float* pcm_dev, const int64_t* chunk_samples, int32_t n_chunks,
+                     int32_t hop_samples, int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
+                     float* emb_dev, float* logits_dev, void* stream) {
+    if (!logits_dev && !emb_dev) return fail(BD_EINVAL, "bd_predict_batch: no output requested");
+    return run_chunks(h, pcm_dev, chunk_samples, n_chunks, hop_samples, patch_step, workspace_dev, workspace_bytes,
+                      emb_dev, logits_dev, -1, 0, nullptr, (hipStream_t)stream);
 }
 
 int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
@@ -719,8 +789,8 @@ int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t h
                  void* stream) {
     if (!out_dev) return fail(BD_EINVAL, "bd_stage_tap: null output");
     if (stage < 0 || stage >= BD_NUM_STAGES) return fail(BD_EINVAL, "bd_stage_tap: stage out of range");
-    return run_chunk(h, pcm_dev, n_samples, hop_samples, patch_step, workspace_dev, workspace_bytes, nullptr,
-                     nullptr, stage, windows, out_dev, (hipStream_t)stream);
+    return run_chunks(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, nullptr,
+                      nullptr, stage, windows, out_dev, (hipStream_t)stream);
 }
 
 int bd_debug_pointwise(const float* a_dev, const float* wt_dev, const float* bias_dev, float* c_dev, int64_t m,

@@ -91,7 +91,11 @@ class HipEngine:
             self.n_classes = int(hb.size)
         _lib.check(self._lib.bd_create(C.byref(self._handle), self.device_index, C.byref(w)))
         self._workspace: Optional[torch.Tensor] = None
-        self._pinned: Optional[torch.Tensor] = None
+        # host staging for NumPy inputs: a ring of pinned buffers, each guarded by the event of the async
+        # H2D copy that last read it (a single shared buffer would be overwritten while a copy is in flight)
+        self._pinned: list = [None] * 4
+        self._pinned_events: list = [None] * 4
+        self._pinned_next = 0
 
     # ------------------------------------------------------------------ lifecycle
     def close(self) -> None:
@@ -160,11 +164,19 @@ class HipEngine:
                 raise ValueError("audio samples must be one-dimensional")
             a = np.ascontiguousarray(a, dtype=np.float32)
             n = a.size
-            if self._pinned is None or self._pinned.numel() < n:
-                self._pinned = torch.empty(max(n, 1), dtype=torch.float32).pin_memory()
-            self._pinned[:n].copy_(torch.from_numpy(a))
+            slot = self._pinned_next
+            self._pinned_next = (slot + 1) % len(self._pinned)
+            if self._pinned_events[slot] is not None:
+                self._pinned_events[slot].synchronize()          # the copy that last used this buffer is done
+            if self._pinned[slot] is None or self._pinned[slot].numel() < n:
+                self._pinned[slot] = torch.empty(max(n, 1), dtype=torch.float32).pin_memory()
+            staging = self._pinned[slot]
+            staging[:n].copy_(torch.from_numpy(a))
             t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)[:n]
-            t.copy_(self._pinned[:n], non_blocking=True)
+            t.copy_(staging[:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._stream())
+            self._pinned_events[slot] = ev
         if t.data_ptr() % 16:
             t = t.clone()
         return t
@@ -234,6 +246,38 @@ class HipEngine:
                                               emb.data_ptr(), stream.cuda_stream))
         x.record_stream(stream)
         return emb, logits
+
+    def predict_batch(self, chunks, framehop_s: float, want_embeddings: bool = False):
+        """Several chunks through one launch set (``bd_predict_batch``): each chunk keeps its own end-of-chunk
+        zero padding, so the rows are exactly those of one ``predict`` per chunk.  Returns one DeviceResult per
+        chunk (views of one device tensor); with ``want_embeddings`` a second list with the embeddings."""
+        if not 1 <= len(chunks) <= 64:
+            raise ValueError("predict_batch takes 1..64 chunks")
+        hop, step = hop_samples(framehop_s), patch_step(framehop_s)
+        parts = [self.to_device(c) for c in chunks]
+        lengths = (C.c_int64 * len(parts))(*[int(p.numel()) for p in parts])
+        x = parts[0] if len(parts) == 1 else torch.cat(parts)
+        if x.data_ptr() % 16:
+            x = x.clone()
+        per = (C.c_int64 * len(parts))()
+        total = _lib.check(self._lib.bd_batch_num_windows(lengths, len(parts), hop, step, per))
+        ws_bytes = _lib.check(self._lib.bd_batch_workspace_bytes(self._handle, lengths, len(parts), hop, step))
+        ws = self._ws(ws_bytes)
+        if self.n_classes == 0:
+            raise RuntimeError("engine was created without a classifier head")
+        logits = torch.empty((total, self.n_classes), dtype=torch.float32, device=self.device)
+        emb = torch.empty((total, _lib.EMBEDDING_SIZE), dtype=torch.float32, device=self.device) if want_embeddings else None
+        stream = self._stream()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_predict_batch(self._handle, x.data_ptr(), lengths, len(parts), hop, step,
+                                                  ws.data_ptr(), ws.numel(), emb.data_ptr() if emb is not None else None,
+                                                  logits.data_ptr(), stream.cuda_stream))
+        x.record_stream(stream)
+        counts = [int(v) for v in per]
+        out = [DeviceResult(t, stream) for t in torch.split(logits, counts)]
+        if want_embeddings:
+            return out, [DeviceResult(t, stream) for t in torch.split(emb, counts)]
+        return out
 
     def embed(self, samples, framehop_s: float) -> DeviceResult:
         emb, _ = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), True, False)

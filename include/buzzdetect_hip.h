@@ -20,6 +20,8 @@
  *                                                            embedders/yamnet_k2/embedder.py:27-37
  *                                                            embedders/yamnet/embedder.py:33-44
  *   bd_predict               <- ModelGeneralV3.predict       models/model_general_v3/model.py:18-31
+ *   bd_predict_batch         <- WorkerInferer.process_chunk over several queued chunks
+ *                                                            src/inference/worker.py:71-92, src/analyze.py:218-253
  *   bd_stage_tap             <- (test hook) any intermediate activation of yamnet()
  *                                                            embedders/yamnet/yamnet.py:96-103
  *
@@ -136,6 +138,20 @@ BD_API int bd_embed(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_
 BD_API int bd_predict(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples,
                int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
                float* emb_dev, float* logits_dev, void* stream);
+
+/* Several chunks in one launch set: the analyze-side batching of src/analyze.py:218-253 +
+   src/inference/worker.py:71-74 (the reference calls predict once per chunk; here windows of up to 64 chunks
+   share every kernel launch).  pcm_dev holds the chunks back to back, chunk c has chunk_samples[c] samples
+   (host array) and is padded on its own exactly as in a
+   single-chunk call (hazard H1), so the rows equal those of n_chunks separate bd_predict calls, bit for bit.
+   Outputs are [sum of windows][1024] / [sum of windows][n_classes]; either may be NULL. */
+BD_API int64_t bd_batch_num_windows(const int64_t* chunk_samples, int32_t n_chunks, int32_t hop_samples,
+                                    int32_t patch_step, int64_t* per_chunk_windows /* may be NULL */);
+BD_API int64_t bd_batch_workspace_bytes(bd_handle h, const int64_t* chunk_samples, int32_t n_chunks,
+                                        int32_t hop_samples, int32_t patch_step);
+BD_API int bd_predict_batch(bd_handle h, const float* pcm_dev, const int64_t* chunk_samples, int32_t n_chunks,
+                            int32_t hop_samples, int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
+                            float* emb_dev, float* logits_dev, void* stream);
 
 /* Test hook: run the path up to CNN stage `stage` (0 = conv1 output, 2k-1 / 2k = depthwise /
    pointwise output of layer k+1) for the first `windows` windows and copy that NHWC activation

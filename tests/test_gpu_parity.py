@@ -345,3 +345,49 @@ def test_config3_ten_minute_chunk(engine, weights_bundle, hop_prop, expect):
         assert np.abs(got[j] - ref).max() < TOL_LOGITS, j
     sub = engine.predict(xd[5 * hop: 5 * hop + 15600 + 3 * hop], 0.96 * hop_prop).numpy()
     assert np.array_equal(sub[:3], got[5:8])
+
+
+@pytest.mark.parametrize("hop_prop", [1.0, 0.5])
+def test_predict_batch_equals_per_chunk_calls(engine, hop_prop):
+    """bd_predict_batch: windows of several chunks share every launch, each chunk keeps its own zero padding
+    (hazard H1) -> rows identical, bit for bit, to one bd_predict per chunk.  Ragged lengths incl. tiny chunks."""
+    lengths = [3_194_880, 15_600, 1, 0, 23_360, 100_001, 7, 3_194_879, 15_601, 640_000]
+    chunks = [O.synthetic_audio(max(n, 1), seed=900 + i)[:n] for i, n in enumerate(lengths)]
+    singles = [engine.predict(c, 0.96 * hop_prop).numpy() for c in chunks]
+    batch, embs = engine.predict_batch(chunks, 0.96 * hop_prop, want_embeddings=True)
+    assert len(batch) == len(chunks)
+    hop = int(15360 * hop_prop)
+    for n, one, many in zip(lengths, singles, batch):
+        assert many.shape == one.shape == (O.num_windows(n, hop), 13)
+        assert np.array_equal(many.numpy(), one)
+    assert sum(len(e) for e in embs) == sum(s.shape[0] for s in singles)
+    # different pass sizes must not matter either
+    engine.set_group_windows(100)
+    try:
+        again = engine.predict_batch(chunks, 0.96 * hop_prop)
+        for one, many in zip(singles, again):
+            assert np.array_equal(many.numpy(), one)
+    finally:
+        engine.set_group_windows(0)
+
+
+def test_predict_batch_argument_errors(engine):
+    from buzzdetect_amd._lib import BuzzdetectHipError
+    with pytest.raises(ValueError):
+        engine.predict_batch([], 0.96)
+    with pytest.raises(ValueError):
+        engine.predict_batch([np.zeros(10, np.float32)] * 65, 0.96)
+    import torch
+    big = torch.zeros(1 << 24, dtype=torch.float32, device=engine.device)
+    with pytest.raises(BuzzdetectHipError, match="BD_ERANGE"):
+        engine.predict_batch([np.zeros(100, np.float32), big], 0.96)
+
+
+def test_back_to_back_numpy_inputs_do_not_race(engine):
+    """Host staging: many predict() calls on NumPy inputs enqueued without synchronising in between must each
+    see their own samples (the pinned staging buffers are reused only after their copy has completed)."""
+    xs = [O.synthetic_audio(200_000 + 1000 * i, seed=300 + i) for i in range(9)]
+    want = [engine.predict(x, 0.96).numpy() for x in xs]          # synchronised one by one
+    pending = [engine.predict(x, 0.96) for x in xs]                # enqueued back to back
+    for w, p in zip(want, pending):
+        assert np.array_equal(p.numpy(), w)
