@@ -79,8 +79,12 @@ class WavTrack:
     def seek(self, frame: int) -> None:
         self._w.setpos(min(max(frame, 0), self.frames))
 
-    def read(self, n: int) -> np.ndarray:
+    def read(self, n: int, keep_s16: bool = False) -> np.ndarray:
+        """[frames, channels] float32 in [-1, 1); with ``keep_s16`` 16-bit files come back as int16 (the device
+        stage scales by 1/32768 itself, halving the host-to-device bytes)."""
         raw = self._w.readframes(max(n, 0))
+        if self._width == 2 and keep_s16:
+            return np.frombuffer(raw, dtype="<i2").reshape(-1, self.channels)
         if self._width == 2:
             a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
         elif self._width == 4:
@@ -179,14 +183,14 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
             for chunk in chunks:
                 a, b = framing.chunk_sample_range(chunk, track.samplerate)
                 track.seek(a)
-                samples = track.read(b - a)
+                samples = track.read(b - a, keep_s16=True)
                 if samples.shape[0] < b - a:                 # short read: truncate the chunk, finish the file
                     chunk = (chunk[0], round(chunk[0] + samples.shape[0] / track.samplerate, 1))
                     stop = True
                 if samples.shape[0] == 0:
                     break
-                if track.samplerate != 16000 or track.channels > 1:
-                    pcm = eng.resample(samples, track.samplerate, 16000)
+                if track.samplerate != 16000 or track.channels > 1 or samples.dtype == np.int16:
+                    pcm = eng.resample(samples, track.samplerate, 16000)     # also the s16 -> f32 conversion
                 else:
                     pcm = samples[:, 0]
                 batch.append((chunk, pcm))

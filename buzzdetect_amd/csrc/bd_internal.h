@@ -57,8 +57,8 @@ struct SepLayer {
 // ---- launchers (each enqueues exactly one kernel on `stream`) ----
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
                    const FeTables* tables, hipStream_t stream, int variant = 0);
-void launch_resample(const float* in, int64_t n_in, int channels, const float* taps, int half, int up, int down,
-                     float* out, int64_t n_out, hipStream_t stream);
+void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const float* taps, int half, int up,
+                     int down, float* out, int64_t n_out, hipStream_t stream);
 void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
                     hipStream_t stream);
 void launch_conv1(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* w9x32,

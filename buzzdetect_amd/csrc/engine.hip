@@ -521,8 +521,8 @@ int bd_resample_taps(int32_t rate_in, int32_t rate_out, float* taps_host, int64_
     return (int)t.size();
 }
 
-int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels, int32_t rate_in, int32_t rate_out,
-                float* out_dev, void* stream) {
+static int resample_any(bd_handle h, const void* in_dev, bool s16, int64_t n_in, int32_t channels, int32_t rate_in,
+                        int32_t rate_out, float* out_dev, void* stream) {
     if (!h || !out_dev || (!in_dev && n_in > 0)) return fail(BD_EINVAL, "bd_resample: null argument");
     if (n_in < 0 || channels <= 0 || rate_in <= 0 || rate_out <= 0) return fail(BD_EINVAL, "bd_resample: bad size");
     if (misaligned(in_dev) || misaligned(out_dev)) return fail(BD_EINVAL, "bd_resample: pointers need 16-byte alignment");
@@ -542,9 +542,19 @@ int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels
         h->rs_half = half;
     }
     const int64_t n_out = (n_in * up + down - 1) / down;
-    bd::launch_resample(in_dev, n_in, channels, h->d_taps, h->rs_half, up, down, out_dev, n_out, (hipStream_t)stream);
+    bd::launch_resample(in_dev, s16, n_in, channels, h->d_taps, h->rs_half, up, down, out_dev, n_out, (hipStream_t)stream);
     BD_HIP(hipGetLastError());
     return BD_OK;
+}
+
+int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels, int32_t rate_in, int32_t rate_out,
+                float* out_dev, void* stream) {
+    return resample_any(h, in_dev, false, n_in, channels, rate_in, rate_out, out_dev, stream);
+}
+
+int bd_resample_s16(bd_handle h, const int16_t* in_dev, int64_t n_in, int32_t channels, int32_t rate_in,
+                    int32_t rate_out, float* out_dev, void* stream) {
+    return resample_any(h, in_dev, true, n_in, channels, rate_in, rate_out, out_dev, stream);
 }
 
 int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t patch_step, float* patches_dev,

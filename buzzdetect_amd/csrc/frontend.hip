@@ -343,10 +343,13 @@ __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ 
 // 2*half + 1 taps scaled by `up` (the scipy.signal.resample_poly design; the reference's soxr_hq is a
 // different low-pass, so this stage is "parity unpinned" against the reference and pinned against its own
 // CPU restatement).  One thread per output sample, taps walked in increasing input index.
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, long long n_in, int channels,
+__device__ __forceinline__ float pcm_to_float(float v) { return v; }
+__device__ __forceinline__ float pcm_to_float(short v) { return (float)v * (1.0f / 32768.0f); }   // as libsndfile's float read
+
+template <typename T>
+__global__ __launch_bounds__(256) void resample_kernel(const T* __restrict__ in, long long n_in, int channels,
                                                        const float* __restrict__ h, int half, int up, int down,
                                                        float* __restrict__ out, long long n_out) {
-    const float inv_ch = 1.0f / (float)channels;
     for (long long j = blockIdx.x * 256LL + threadIdx.x; j < n_out; j += gridDim.x * 256LL) {
         const long long c = j * down;                       // position on the up-sampled grid
         long long i0 = (c - half + up - 1) / up;            // ceil((c - half) / up), c - half may be negative
@@ -358,30 +361,32 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
         for (long long i = i0; i <= i1; ++i) {
             float m = 0.0f;
             if (channels == 1) {
-                m = in[i];
+                m = pcm_to_float(in[i]);
             } else if (channels == 2) {
-                const float2 v = reinterpret_cast<const float2*>(in)[i];
-                m = (v.x + v.y) * 0.5f;
+                m = (pcm_to_float(in[2 * i]) + pcm_to_float(in[2 * i + 1])) * 0.5f;
             } else {
-                for (int ch = 0; ch < channels; ++ch) m += in[i * channels + ch];
+                for (int ch = 0; ch < channels; ++ch) m += pcm_to_float(in[i * channels + ch]);
                 m = m / (float)channels;
             }
             acc = fmaf(m, h[c - i * up + half], acc);
         }
-        (void)inv_ch;
         out[j] = acc;
     }
 }
 
 }  // namespace
 
-void launch_resample(const float* in, int64_t n_in, int channels, const float* taps, int half, int up, int down,
-                     float* out, int64_t n_out, hipStream_t stream) {
+void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const float* taps, int half, int up,
+                     int down, float* out, int64_t n_out, hipStream_t stream) {
     if (n_out <= 0) return;
     const int64_t blocks = (n_out + 255) / 256;
     const int grid = (int)(blocks < 65536 ? blocks : 65536);
-    hipLaunchKernelGGL(resample_kernel, dim3(grid), dim3(256), 0, stream, in, (long long)n_in, channels, taps, half,
-                       up, down, out, (long long)n_out);
+    if (s16)
+        hipLaunchKernelGGL(resample_kernel<short>, dim3(grid), dim3(256), 0, stream, static_cast<const short*>(in),
+                           (long long)n_in, channels, taps, half, up, down, out, (long long)n_out);
+    else
+        hipLaunchKernelGGL(resample_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in),
+                           (long long)n_in, channels, taps, half, up, down, out, (long long)n_out);
 }
 
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,

@@ -183,12 +183,14 @@ class HipEngine:
 
     # ------------------------------------------------------------------ streamer stage
     def resample(self, samples, rate_in: int, rate_out: int = SAMPLE_RATE) -> torch.Tensor:
-        """[n] or [n, channels] float32 at ``rate_in`` -> mono [m] at ``rate_out`` on the device
-        (np.mean(axis=1) + librosa.resample of src/stream/worker.py:116-128 as one kernel)."""
+        """[n] or [n, channels] float32 — or int16 PCM, scaled by 1/32768 — at ``rate_in`` -> mono float32 [m] at
+        ``rate_out`` on the device (np.mean(axis=1) + librosa.resample of src/stream/worker.py:116-128 as one kernel)."""
+        is_s16 = (samples.dtype == torch.int16) if isinstance(samples, torch.Tensor) else (np.asarray(samples).dtype == np.int16)
+        dt_t, dt_n = (torch.int16, np.int16) if is_s16 else (torch.float32, np.float32)
         if isinstance(samples, torch.Tensor):
-            t = samples.to(self.device, dtype=torch.float32, non_blocking=True)
+            t = samples.to(self.device, dtype=dt_t, non_blocking=True)
         else:
-            t = torch.from_numpy(np.ascontiguousarray(np.asarray(samples), dtype=np.float32)).to(self.device)
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(samples), dtype=dt_n)).to(self.device)
         if t.dim() == 1:
             t = t[:, None]
         if t.dim() != 2:
@@ -197,9 +199,10 @@ class HipEngine:
         n_in, channels = t.shape
         n_out = _lib.check(self._lib.bd_resample_length(n_in, int(rate_in), int(rate_out)))
         out = torch.empty(max(n_out, 1), dtype=torch.float32, device=self.device)[:n_out]
+        fn = self._lib.bd_resample_s16 if is_s16 else self._lib.bd_resample
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.bd_resample(self._handle, t.data_ptr(), n_in, channels, int(rate_in), int(rate_out),
-                                             out.data_ptr(), self._stream().cuda_stream))
+            _lib.check(fn(self._handle, t.data_ptr(), n_in, channels, int(rate_in), int(rate_out),
+                          out.data_ptr(), self._stream().cuda_stream))
         t.record_stream(self._stream())
         return out
 

@@ -124,6 +124,10 @@ BD_API int bd_resample_taps(int32_t rate_in, int32_t rate_out, float* taps_host,
                             int32_t* down, int32_t* half);
 BD_API int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels, int32_t rate_in,
                        int32_t rate_out, float* out_dev, void* stream);
+/* the same from 16-bit PCM (value / 32768, libsndfile's float convention): half the PCIe bytes; with
+   rate_in == rate_out and one channel it is a plain s16 -> f32 conversion on the device */
+BD_API int bd_resample_s16(bd_handle h, const int16_t* in_dev, int64_t n_in, int32_t channels, int32_t rate_in,
+                           int32_t rate_out, float* out_dev, void* stream);
 
 /* logmel_dev[n_frames][64] -> patches_dev[W][96][64], W = 1 + (n_frames - 96) / patch_step. */
 BD_API int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t patch_step,

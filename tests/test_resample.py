@@ -65,3 +65,18 @@ def test_config5_input_48k_stereo_end_to_end(engine, weights_bundle):
                     15360, 96, np.float64)
     assert got.shape == ref.shape == (4, 13)
     assert np.abs(got - ref).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate_in,channels", [(48000, 2), (16000, 1), (32000, 1)])
+def test_device_resample_from_s16(engine, rate_in, channels):
+    """16-bit PCM in (half the PCIe bytes): same result as converting with value / 32768 on the host first."""
+    rng = np.random.default_rng(rate_in + channels)
+    q = rng.integers(-32768, 32767, size=(24000, channels), dtype=np.int16)
+    if channels == 1:
+        q = q[:, 0]
+    got = engine.resample(q, rate_in).cpu().numpy()
+    via_f32 = engine.resample(q.astype(np.float32) / 32768.0, rate_in).cpu().numpy()
+    assert np.array_equal(got, via_f32)
+    want = RO.resample(q.astype(np.float32) / 32768.0, rate_in)
+    assert np.abs(got - want).max() < 2e-6
