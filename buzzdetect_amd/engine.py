@@ -190,7 +190,10 @@ class HipEngine:
         if isinstance(samples, torch.Tensor):
             t = samples.to(self.device, dtype=dt_t, non_blocking=True)
         else:
-            t = torch.from_numpy(np.ascontiguousarray(np.asarray(samples), dtype=dt_n)).to(self.device)
+            a = np.ascontiguousarray(np.asarray(samples), dtype=dt_n)
+            if not a.flags.writeable:                 # e.g. np.frombuffer views: torch wants a writable array
+                a = a.copy()
+            t = torch.from_numpy(a).to(self.device)
         if t.dim() == 1:
             t = t[:, None]
         if t.dim() != 2:
