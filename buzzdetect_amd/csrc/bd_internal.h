@@ -50,6 +50,8 @@ struct SepLayer {
     int pw_variant;      // tile choice for the exact-f32 kernel (0 = by shape)
     const void* pw_whi;  // [cout][cin] f16: high half of pw_wt
     const void* pw_wlo;  // [cout][cin] f16: f16(pw_wt - high)
+    const void* pw_fhi;  // pw_whi in MFMA B-fragment order: [cout/32][cin/16][64 lanes][8]
+    const void* pw_flo;  // pw_wlo, same order
     int pw_variant16;    // tile choice for the split-f16 kernel (0 = by shape)
     int pw_mode;         // 0 = exact f32 MFMA, 1 = split-f16 MFMA (3 products)
 };

@@ -765,9 +765,10 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // BDIR = 1: the consumers do not stage the weights through LDS at all.  With the 1 x 4 consumer layout every
 // wave owns its own WN output columns, so a weight fragment is used by exactly one wave: each lane loads its
 // MFMA B fragments (16 bytes of hi, 16 of lo per k-step and column tile) straight from global/L2 into a
-// double-buffered register set, one stage ahead.
-template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR>
-__global__ __launch_bounds__(512) void sep_ws_kernel(
+// double-buffered register set, one stage ahead.  The engine keeps a copy of the split weights in fragment
+// order, so each of those loads is one contiguous KiB per wave.
+template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS>
+__global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
     float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n,
@@ -824,7 +825,33 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
             xp[j] = X + (size_t)(x_lo + r) * K + lc4 * 4;
         }
         int xtap[LA][9];
+        int xt[(LA + 2) * 3];
         int a_st[LA];
+        if constexpr (VS) {
+            // a thread owns LA vertically adjacent outputs (same column, rows oh0 .. oh0+LA-1) of 4 channels: the
+            // 3 x 3 neighbourhoods overlap, so it reads (LA+2) x 3 slab values instead of LA x 9
+            const int slot = lrow;
+            int wl = 0, g = slot;
+            if (P < BM) {
+                const int G = P / LA;
+                wl = slot / G;
+                g = slot % G;
+            }
+            const int og = g / W, ow = g % W;
+            const int ml0 = wl * P + LA * og * W + ow;
+            const int oh0 = (P >= BM ? (int)(m0 % P) / W : 0) + LA * og;
+            const int xc0 = (int)(m0 + ml0 - x_lo);
+#pragma unroll
+            for (int r = 0; r < LA + 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int ih = oh0 - 1 + r, iw = ow - 1 + c;
+                    const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    xt[r * 3 + c] = (ok ? xc0 + (r - 1) * W + (c - 1) : XPMAX) * 32 + lc4 * 4;
+                }
+#pragma unroll
+            for (int i = 0; i < LA; ++i) a_st[i] = swz64(ml0 + i * W, lc4 >> 1) + (lc4 & 1) * 8;
+        } else
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int ml = lrow + 32 * i;
@@ -867,10 +894,17 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
         v4f wt[9];                                                                                        \
         _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * 32); \
         const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * 32);                                    \
+        v4f xv[(LA + 2) * 3];                                                                             \
+        if constexpr (VS) {                                                                               \
+            _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t)                                      \
+                xv[t] = *reinterpret_cast<const v4f*>(xs_ + xt[t]);                                       \
+        }                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
             v4f a4 = bias4;                                                                               \
             _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                               \
-                const v4f v = *reinterpret_cast<const v4f*>(xs_ + xtap[i][t]);                            \
+                v4f v;                                                                                    \
+                if constexpr (VS) v = xv[i * 3 + t];                                                      \
+                else v = *reinterpret_cast<const v4f*>(xs_ + xtap[i][t]);                                 \
                 a4.x = fmaf(v.x, wt[t].x, a4.x);                                                          \
                 a4.y = fmaf(v.y, wt[t].y, a4.y);                                                          \
                 a4.z = fmaf(v.z, wt[t].z, a4.z);                                                          \
@@ -945,17 +979,17 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
         const _Float16* wph[TN];
         const _Float16* wpl[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const size_t row = (size_t)(n0 + wc * WN + j * 32 + frow) * K + fh * 8;
-            wph[j] = Whi + row;
-            wpl[j] = Wlo + row;
+        for (int j = 0; j < TN; ++j) {        // Whi / Wlo are the fragment-order copies (SepLayer::pw_fhi / pw_flo)
+            const size_t frag = ((size_t)((n0 + wc * WN) / 32 + j) * (K / 16) * 64 + lane) * 8;
+            wph[j] = Whi + frag;
+            wpl[j] = Wlo + frag;
         }
         f16x8 b0h[TN][2], b0l[TN][2], b1h[TN][2], b1l[TN][2];    // fragments of an even / an odd stage
 #define BD_W_LOAD(BH, BL, KOFF)                                                                           \
     {                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s) {    \
-            BH[j][s] = *reinterpret_cast<const f16x8*>(wph[j] + (KOFF) + 16 * s);                         \
-            BL[j][s] = *reinterpret_cast<const f16x8*>(wpl[j] + (KOFF) + 16 * s);                         \
+            BH[j][s] = *reinterpret_cast<const f16x8*>(wph[j] + (KOFF) * 32 + 512 * s);                   \
+            BL[j][s] = *reinterpret_cast<const f16x8*>(wpl[j] + (KOFF) * 32 + 512 * s);                   \
         }                                                                                                 \
     }
 #define BD_W_MFMA(BUF, BH, BL)                                                                            \
@@ -1146,7 +1180,7 @@ __global__ __launch_bounds__(512) void sep_ws_kernel(
     }
 }
 
-template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0>
+template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
                    const SepLayer* next = nullptr) {
     constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (BM + (BDIR ? 0 : BN)) * 64;
@@ -1157,14 +1191,15 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int tiles_n = L.cout / BN;
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
-                       L.dw_b, static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo), L.pw_b,
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
+                       L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
+                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
                        next ? next->dw_b : nullptr, out);
 }
@@ -1721,7 +1756,7 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
     if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;
     if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & 1)) return false;
     const long long M = (long long)windows * P;
-    launch_sep_ws<256, 96, 0, 1>(in, L, out, M, stream, &next);
+    launch_sep_ws<256, 96, 0, 1, 96, 1, 1>(in, L, out, M, stream, &next);
     return true;
 }
 
@@ -1734,16 +1769,20 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     // auto (measured on MI355X): the 12x8, 6x4 and 3x2 maps run best on the wave-specialised kernel with
     // 96-row x 256-column tiles; the 24x16 map (K = 128, only 4 stages per tile) on the same kernel with
     // 64-row x 128-column tiles, small enough for two workgroups per CU
-    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128) variant = 3;
-    if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128) variant = 5;   // layer 4
+    // (variant 7 = weights as register fragments + producers sharing taps vertically; 3 / 5 = the same tiles
+    //  with LDS-staged weights and one output per tap set, kept as tested alternatives)
+    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 7;
+    if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 7;   // layer 4
     if (variant >= 3 && L.cin >= 128) {                            // wave-specialised kernels (BM = 96)
         if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
-            if (variant == 5) launch_sep_ws<128, 96, 0, 0, 64>(in, L, out, M, stream);
+            if (variant == 7) launch_sep_ws<128, 96, 0, 0, 64, 1, 1>(in, L, out, M, stream);
+            else if (variant == 5) launch_sep_ws<128, 96, 0, 0, 64>(in, L, out, M, stream);
             else launch_sep_ws<128, 128>(in, L, out, M, stream);
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
-            if (variant == 6 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1>(in, L, out, M, stream);
+            if (variant == 7 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1>(in, L, out, M, stream);
+            else if (variant == 6 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1>(in, L, out, M, stream);
             else if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
             else if (L.cout % 128 == 0) launch_sep_ws<128, 96>(in, L, out, M, stream);
             else return false;

@@ -324,7 +324,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
     };
     const float* p = w->embedder_blob;
     size_t off_conv1_w, off_conv1_b;
-    size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13], off_pw_hi[13], off_pw_lo[13];
+    size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13], off_pw_hi[13], off_pw_lo[13], off_pw_fhi[13], off_pw_flo[13];
     {
         const int c = kLayerDefs[0][1];
         const float* kern = p;   // [3][3][1][32]
@@ -373,6 +373,25 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
                 hi[i] = h;
                 lo[i] = (_Float16)(wf[i] - (float)h);
             }
+        }
+        // the same halves in MFMA fragment order (v_mfma_f32_32x32x16_f16 B operand): for a 32-channel tile t
+        // and a 16-deep k step q, lane l holds W[32 t + l % 32][16 q + 8 (l / 32) .. + 8], so a wave's fragment
+        // load is 1 KiB contiguous:  frag[((t * K/16 + q) * 64 + l) * 8 + e]
+        off_pw_fhi[l] = reserve((nw + 1) / 2);
+        off_pw_flo[l] = reserve((nw + 1) / 2);
+        {
+            const _Float16* hi = reinterpret_cast<const _Float16*>(host.data() + off_pw_hi[l]);
+            const _Float16* lo = reinterpret_cast<const _Float16*>(host.data() + off_pw_lo[l]);
+            _Float16* fhi = reinterpret_cast<_Float16*>(host.data() + off_pw_fhi[l]);
+            _Float16* flo = reinterpret_cast<_Float16*>(host.data() + off_pw_flo[l]);
+            const int kq = cin / 16;
+            for (int n = 0; n < cout; ++n)
+                for (int k = 0; k < cin; ++k) {
+                    const int lane = (n & 31) + 32 * ((k & 15) >> 3);
+                    const size_t dst = (((size_t)(n >> 5) * kq + (k >> 4)) * 64 + lane) * 8 + (k & 7);
+                    fhi[dst] = hi[(size_t)n * cin + k];
+                    flo[dst] = lo[(size_t)n * cin + k];
+                }
         }
         cin = cout;
     }
@@ -438,6 +457,8 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         L.pw_variant = 0;
         L.pw_whi = e->d_pool + off_pw_hi[l];
         L.pw_wlo = e->d_pool + off_pw_lo[l];
+        L.pw_fhi = e->d_pool + off_pw_fhi[l];
+        L.pw_flo = e->d_pool + off_pw_flo[l];
         L.pw_variant16 = 0;
         L.pw_mode = e->pointwise_mode;
         h = L.h_out;
