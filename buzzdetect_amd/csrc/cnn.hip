@@ -767,13 +767,17 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // MFMA B fragments (16 bytes of hi, 16 of lo per k-step and column tile) straight from global/L2 into a
 // double-buffered register set, one stage ahead.  The engine keeps a copy of the split weights in fragment
 // order, so each of those loads is one contiguous KiB per wave.
-template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS>
+template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD>
 __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
     float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n,
     const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out2) {
     static_assert(BM == 96 || BM == 64, "tile height");
+    static_assert(KS == 1 || (KS == 2 && BDIR == 1), "64-channel stages need the weights out of LDS");
+    static_assert(XD == 0 || (BDIR == 1 && KS == 1 && XPMAX % 32 == 0), "slab DMA is issued by the fragment-loading consumers");
+    constexpr int NX = XD ? 3 : 2 * KS;      // slab / tap buffers: a ring of three when the consumers fill it by DMA
+    constexpr int WS_FLOATS = XD ? 0 : 320;   // depthwise taps + shift of a 32-channel block (XD: all K at once, in Wall)
     constexpr int WN = BN / 4;               // consumer wave tile: BM x WN
     constexpr int TM = BM / 32, TN = WN / 32;
     constexpr int LA = BM / 32;              // depthwise outputs (x4 channels) per producer thread per stage
@@ -782,11 +786,12 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     constexpr int XS_FLOATS = (XPMAX + 1) * 32;   // + the zero row
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* const Xs = reinterpret_cast<float*>(smem_raw);             // [2][XS_FLOATS]
-    float* const Ws = Xs + 2 * XS_FLOATS;                              // [2][10][32]
-    char* const Ah = reinterpret_cast<char*>(Ws + 2 * 320);            // [2][A_BYTES]
-    char* const Al = Ah + 2 * A_BYTES;
-    char* const Bh = Al + 2 * A_BYTES;                                 // [2][B_BYTES]
+    float* const Xs = reinterpret_cast<float*>(smem_raw);             // [2][KS][XS_FLOATS]: a stage is KS blocks of 32 channels
+    float* const Ws = Xs + NX * XS_FLOATS;                             // [NX][10 or 16][32]
+    char* const Ah = reinterpret_cast<char*>(Ws + NX * WS_FLOATS);     // [2][KS][A_BYTES]
+    char* const Al = Ah + 2 * KS * A_BYTES;
+    char* const Bh = Al + 2 * KS * A_BYTES;                            // [2][B_BYTES]
+    float* const Wall = reinterpret_cast<float*>(Bh);                  // XD (weights not in LDS): [10][K] taps + shift
     char* const Bl = Bh + 2 * B_BYTES;
 
     const int tid = threadIdx.x;
@@ -796,27 +801,45 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     const int tile_n = blockIdx.x % tiles_n;
     const long long m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    const int nk = K / 32;                    // >= 4 (launcher)
+    const int nk = K / (32 * KS);             // stages; >= 4 (launcher)
 
+    constexpr size_t TS_PIPE = (size_t)NX * (XPMAX + 1) * 128 + (size_t)NX * WS_FLOATS * 4 + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
+    constexpr size_t TS_TILE = (size_t)BM * (BN + 4) * 4;
+    const size_t ts_pipe_ = TS_PIPE + (XD ? (size_t)40 * K : 0);
+    unsigned* const ts = reinterpret_cast<unsigned*>(smem_raw + (ts_pipe_ > TS_TILE ? ts_pipe_ : TS_TILE));
+    int tsn = 0;
+#define BD_TS(W)                                                                                          \
+    if constexpr (ABL == 1) {                                                                             \
+        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))                                     \
+            ts[((wave >> 2) * 64 + tsn) * 2 + (W)] = (unsigned)__builtin_readcyclecounter();              \
+        if (W) ++tsn;                                                                                     \
+    }
+#define BD_SYNC() { BD_TS(0) __syncthreads(); BD_TS(1) }
+#define BD_PROBE(I)                                                                                       \
+    if constexpr (ABL == 1) {                                                                             \
+        if (blockIdx.x == 0 && lane == 0 && wave == 4 && k == 6)                                          \
+            ts[192 + (I)] = (unsigned)__builtin_readcyclecounter();                                       \
+    }
+    // input slab of this tile: rows [x_lo, x_lo + x_cnt) of X (whole windows, or a band of rows plus its halo rows)
+    const int P = H * W;
+    long long x_lo;
+    int x_cnt;
+    if (P >= BM) {
+        const long long n = m0 / P;
+        const int oh_a = (int)(m0 % P) / W;
+        const int oh_b = oh_a + BM / W;
+        const int r0 = oh_a > 0 ? oh_a - 1 : 0;
+        const int r1 = oh_b < H ? oh_b + 1 : H;
+        x_lo = (n * H + r0) * W;
+        x_cnt = (r1 - r0) * W;
+    } else {
+        x_lo = m0;
+        x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
+    }
     if (wave >= 4) {
         // ================================================================= producers
         const int pt = tid - 256;
         const int lrow = pt >> 3, lc4 = pt & 7;
-        const int P = H * W;
-        long long x_lo;
-        int x_cnt;
-        if (P >= BM) {
-            const long long n = m0 / P;
-            const int oh_a = (int)(m0 % P) / W;
-            const int oh_b = oh_a + BM / W;
-            const int r0 = oh_a > 0 ? oh_a - 1 : 0;
-            const int r1 = oh_b < H ? oh_b + 1 : H;
-            x_lo = (n * H + r0) * W;
-            x_cnt = (r1 - r0) * W;
-        } else {
-            x_lo = m0;
-            x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
-        }
         const float* xp[XL];
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
@@ -870,30 +893,40 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
                 }
             a_st[i] = swz64(ml, lc4 >> 1) + (lc4 & 1) * 8;
         }
-        if (pt < 16) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+        if (pt < 8 * NX) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
         const float* wsrc = pt < 72 ? dw_w + (size_t)(pt >> 3) * K + lc4 * 4 : dw_b + lc4 * 4;
 
-        v4f rx[XL];
-        v4f rw = {0.f, 0.f, 0.f, 0.f};
+        int kch_ = 0;                         // XD: first channel of the block the depthwise works on
+        (void)kch_;
+        v4f rx[KS][XL];
+        v4f rw[KS];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) rw[u] = v4f{0.f, 0.f, 0.f, 0.f};
 #define BD_P_LOAD(KOFF)                                                                                   \
     {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < XL; ++j) rx[j] = *reinterpret_cast<const v4f*>(xp[j] + (KOFF)); \
-        if (pt < 80) rw = *reinterpret_cast<const v4f*>(wsrc + (KOFF));                                   \
+        _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                  \
+            _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                \
+                rx[u][j] = *reinterpret_cast<const v4f*>(xp[j] + (KOFF) + 32 * u);                        \
+            if (pt < 80) rw[u] = *reinterpret_cast<const v4f*>(wsrc + (KOFF) + 32 * u);                   \
+        }                                                                                                 \
     }
 #define BD_P_STORE(XB)                                                                                    \
     {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                    \
-            if (lrow + 32 * j < XPMAX)                                                                    \
-                *reinterpret_cast<v4f*>(Xs + (XB) * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = rx[j];  \
-        if (pt < 80) *reinterpret_cast<v4f*>(Ws + (XB) * 320 + pt * 4) = rw;                              \
+        _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                  \
+            _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                \
+                if (lrow + 32 * j < XPMAX)                                                                \
+                    *reinterpret_cast<v4f*>(Xs + ((XB) * KS + u) * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = rx[u][j]; \
+            if (pt < 80) *reinterpret_cast<v4f*>(Ws + ((XB) * KS + u) * WS_FLOATS + pt * 4) = rw[u];            \
+        }                                                                                                 \
     }
 #define BD_P_DW(XB, AB)                                                                                   \
-    {                                                                                                     \
-        const float* xs_ = Xs + (XB) * XS_FLOATS;                                                         \
-        const float* ws_ = Ws + (XB) * 320 + lc4 * 4;                                                     \
+    _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                      \
+        const float* xs_ = Xs + ((XB) * KS + u) * XS_FLOATS;                                              \
+        const float* ws_ = XD ? Wall + kch_ + lc4 * 4 : Ws + ((XB) * KS + u) * WS_FLOATS + lc4 * 4;       \
+        const int wrow_ = XD ? K : 32;                                                                    \
         v4f wt[9];                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * 32); \
-        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * 32);                                    \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * wrow_); \
+        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * wrow_);                                 \
         v4f xv[(LA + 2) * 3];                                                                             \
         if constexpr (VS) {                                                                               \
             _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t)                                      \
@@ -915,50 +948,148 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
             hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
             lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
             lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
-            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
-            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
+            *reinterpret_cast<f16x4*>(Ah + ((AB) * KS + u) * A_BYTES + a_st[i]) = hi;                     \
+            *reinterpret_cast<f16x4*>(Al + ((AB) * KS + u) * A_BYTES + a_st[i]) = lo;                     \
         }                                                                                                 \
     }
+        if constexpr (XD) {
+            // ---- slabs and taps by LDS-DMA into a ring of three, three stages ahead.  One global_load_lds_dwordx4
+            // moves 8 slab rows (lane l -> row l >> 3, 16-byte chunk l & 7; LDS address = base + 16 l, exactly the
+            // [row][32] layout); the 4 producer waves take the 8-row groups round-robin and a quarter each of the
+            // 16-row tap block (9 taps, the shift, 6 unused).  No VGPRs, no ds_write, and - the point - the slab
+            // has two full stages to arrive: the barrier waits with a COUNTED vmcnt (everything but the newest
+            // stage's DMA), where __syncthreads() would drain to 0 and expose the ~3000-cycle memory latency.
+            // Producers issue no other vector-memory operation, so the count is exact.
+            constexpr int NG = XPMAX / 8, GPW = NG / 4, ND = GPW;
+            const int pw = wave - 4;
+            // LDS-DMA is serialised on M0 (the LDS base): a DMA to a new base waits for the previous one to finish,
+            // ~300 cycles each.  So a wave takes GPW CONSECUTIVE 8-row groups and reaches them through the
+            // instruction's immediate offset, which is added to both addresses - the global pointer is biased
+            // back by the same amount - and M0 is written once per stage.
+            const float* xsrc[GPW];
+#pragma unroll
+            for (int q = 0; q < GPW; ++q) {
+                int row = 8 * (GPW * pw + q) + (lane >> 3);
+                row = row < x_cnt ? row : x_cnt - 1;
+                xsrc[q] = X + (size_t)(x_lo + row) * K + (lane & 7) * 4 - 256 * q;
+            }
+#define BD_X_DMA1(Q, KOFF, XB)                                                                            \
+    if constexpr ((Q) < GPW)                                                                              \
+        __builtin_amdgcn_global_load_lds(                                                                 \
+            (const __attribute__((address_space(1))) void*)(xsrc[(Q) < GPW ? (Q) : 0] + (KOFF)),          \
+            (__attribute__((address_space(3))) void*)(Xs + (XB) * XS_FLOATS + GPW * pw * 256), 16, 1024 * (Q), 0);
+#define BD_X_DMA(KOFF, XB)                                                                                \
+    {                                                                                                     \
+        BD_X_DMA1(0, KOFF, XB)                                                                            \
+        BD_X_DMA1(1, KOFF, XB)                                                                            \
+        BD_X_DMA1(2, KOFF, XB)                                                                            \
+        BD_X_DMA1(3, KOFF, XB)                                                                            \
+    }
+#define BD_P_SYNC(KEEP)                                                                                   \
+    {                                                                                                     \
+        BD_TS(0)                                                                                          \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        asm volatile("" ::: "memory");                                                                    \
+        BD_TS(1)                                                                                          \
+    }
+            // taps + shift of all K channels: [10][K] floats, once (ordinary loads, drained before any DMA is issued)
+            for (int i = pt; i < 10 * (K / 4); i += 256) {
+                const int r = i / (K / 4), c = i % (K / 4);
+                *reinterpret_cast<v4f*>(Wall + (size_t)r * K + c * 4) =
+                    *reinterpret_cast<const v4f*>((r < 9 ? dw_w + (size_t)r * K : dw_b) + c * 4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            BD_X_DMA(0, 0)
+            BD_X_DMA(32, 1)
+            BD_X_DMA(64, 2)
+            BD_P_SYNC(2 * ND)                 // slab 0 has landed, the taps are written
+            BD_P_DW(0, 0)
+            BD_P_SYNC(ND)                     // A[0] written; slab 1 has landed
+            int rs = 1;                       // ring slot of slab k+1
+            int k = 0;
+            for (; k + 3 < nk; ++k) {         // stage k: slab k+3 replaces slab k (consumed during stage k-1)
+                const int r3 = rs == 0 ? 2 : rs - 1;
+                BD_PROBE(0)
+                BD_X_DMA((k + 3) * 32, r3)
+                BD_PROBE(1)
+                BD_PROBE(2)
+                kch_ = (k + 1) * 32;
+                BD_P_DW(rs, (k + 1) & 1)
+                BD_PROBE(3)
+                BD_P_SYNC(ND)                 // slab k+2 has landed, slab k+3 stays in flight
+                rs = rs == 2 ? 0 : rs + 1;
+            }
+            for (; k + 1 < nk; ++k) {         // the last two depthwise stages: nothing left to request
+                kch_ = (k + 1) * 32;
+                BD_P_DW(rs, (k + 1) & 1)
+                BD_P_SYNC(0)
+                rs = rs == 2 ? 0 : rs + 1;
+            }
+            BD_P_SYNC(0)                      // consumers' last MFMA stage
+#undef BD_X_DMA
+#undef BD_X_DMA1
+#undef BD_P_SYNC
+        } else {
         // prologue: slabs 0 and 1 resident, slab 2 in flight, A[0] computed.  All three loads are issued
         // before the first store so the workgroup pays the HBM latency once, not three times.
         {
-            v4f r0[XL], r1[XL];
-            v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+            v4f r0[KS][XL], r1[KS][XL];
+            v4f w0[KS], w1[KS];
 #pragma unroll
-            for (int j = 0; j < XL; ++j) r0[j] = *reinterpret_cast<const v4f*>(xp[j]);
-            if (pt < 80) w0 = *reinterpret_cast<const v4f*>(wsrc);
+            for (int u = 0; u < KS; ++u) {
+                w0[u] = v4f{0.f, 0.f, 0.f, 0.f};
+                w1[u] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < XL; ++j) r1[j] = *reinterpret_cast<const v4f*>(xp[j] + 32);
-            if (pt < 80) w1 = *reinterpret_cast<const v4f*>(wsrc + 32);
-            BD_P_LOAD(64)
+                for (int j = 0; j < XL; ++j) r0[u][j] = *reinterpret_cast<const v4f*>(xp[j] + 32 * u);
+                if (pt < 80) w0[u] = *reinterpret_cast<const v4f*>(wsrc + 32 * u);
+            }
 #pragma unroll
-            for (int j = 0; j < XL; ++j)
-                if (lrow + 32 * j < XPMAX) {
-                    *reinterpret_cast<v4f*>(Xs + (lrow + 32 * j) * 32 + lc4 * 4) = r0[j];
-                    *reinterpret_cast<v4f*>(Xs + XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = r1[j];
+            for (int u = 0; u < KS; ++u) {
+#pragma unroll
+                for (int j = 0; j < XL; ++j) r1[u][j] = *reinterpret_cast<const v4f*>(xp[j] + 32 * KS + 32 * u);
+                if (pt < 80) w1[u] = *reinterpret_cast<const v4f*>(wsrc + 32 * KS + 32 * u);
+            }
+            BD_P_LOAD(64 * KS)
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+#pragma unroll
+                for (int j = 0; j < XL; ++j)
+                    if (lrow + 32 * j < XPMAX) {
+                        *reinterpret_cast<v4f*>(Xs + u * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = r0[u][j];
+                        *reinterpret_cast<v4f*>(Xs + (KS + u) * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = r1[u][j];
+                    }
+                if (pt < 80) {
+                    *reinterpret_cast<v4f*>(Ws + u * WS_FLOATS + pt * 4) = w0[u];
+                    *reinterpret_cast<v4f*>(Ws + (KS + u) * WS_FLOATS + pt * 4) = w1[u];
                 }
-            if (pt < 80) {
-                *reinterpret_cast<v4f*>(Ws + pt * 4) = w0;
-                *reinterpret_cast<v4f*>(Ws + 320 + pt * 4) = w1;
             }
         }
-        __syncthreads();
+        BD_SYNC()
         BD_P_DW(0, 0)
-        __syncthreads();
+        BD_SYNC()
         int k = 0;
         for (; k + 3 < nk; ++k) {             // stage k: everything in range
+            BD_PROBE(0)
             BD_P_STORE(k & 1)                 // slab k+2 (loaded during stage k-1)
-            BD_P_LOAD((k + 3) * 32)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            BD_PROBE(1)
+            BD_P_LOAD((k + 3) * 32 * KS)
+            BD_PROBE(2)
             BD_P_DW((k + 1) & 1, (k + 1) & 1)
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            BD_PROBE(3)
+            BD_SYNC()
         }
         BD_P_STORE(k & 1)                     // k = nk-3: last slab (nk-1) goes in, nothing left to load
         BD_P_DW((k + 1) & 1, (k + 1) & 1)
-        __syncthreads();
+        BD_SYNC()
         ++k;                                  // k = nk-2: depthwise of the last slab
         BD_P_DW((k + 1) & 1, (k + 1) & 1)
-        __syncthreads();
-        __syncthreads();                      // k = nk-1: consumers' last MFMA stage
+        BD_SYNC()
+        BD_SYNC()                      // k = nk-1: consumers' last MFMA stage
+        }
 #undef BD_P_LOAD
 #undef BD_P_STORE
 #undef BD_P_DW
@@ -1008,23 +1139,26 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
             }                                                                                             \
         }                                                                                                 \
     }
+        // sub-stage t = 32 channels; its A block is ring slot t % (2 KS), its fragments b0 (t even) / b1 (t odd);
+        // the workgroup barrier closes a stage, i.e. every KS sub-stages
+        const int T = K / 32;                 // even, >= 4 KS
         BD_W_LOAD(b0h, b0l, 0)
         BD_W_LOAD(b1h, b1l, 32)
-        __syncthreads();
-        __syncthreads();
-        int k = 0;
-        for (; k + 2 < nk; k += 2) {          // nk is even and >= 4
-            BD_W_MFMA(0, b0h, b0l)
-            BD_W_LOAD(b0h, b0l, (k + 2) * 32)
-            __syncthreads();
-            BD_W_MFMA(1, b1h, b1l)
-            BD_W_LOAD(b1h, b1l, (k + 3) * 32)
-            __syncthreads();
+        BD_SYNC()
+        BD_SYNC()
+        int t = 0;
+        for (; t + 2 < T; t += 2) {
+            BD_W_MFMA(t & (2 * KS - 1), b0h, b0l)
+            BD_W_LOAD(b0h, b0l, (t + 2) * 32)
+            if constexpr (KS == 1) BD_SYNC()
+            BD_W_MFMA((t + 1) & (2 * KS - 1), b1h, b1l)
+            BD_W_LOAD(b1h, b1l, (t + 3) * 32)
+            BD_SYNC()
         }
-        BD_W_MFMA(0, b0h, b0l)                // stage nk-2
-        __syncthreads();
-        BD_W_MFMA(1, b1h, b1l)                // stage nk-1
-        __syncthreads();
+        BD_W_MFMA(t & (2 * KS - 1), b0h, b0l)
+        if constexpr (KS == 1) BD_SYNC()
+        BD_W_MFMA((t + 1) & (2 * KS - 1), b1h, b1l)
+        BD_SYNC()
 #undef BD_W_LOAD
 #undef BD_W_MFMA
     } else {
@@ -1178,26 +1312,66 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
                     *reinterpret_cast<const v4f*>(Ct + ml * (BN + 4) + c4 * 4);
         }
     }
+    if constexpr (ABL == 1) {
+        __syncthreads();
+        if (blockIdx.x == 0 && tid < 256) reinterpret_cast<unsigned*>(out2)[tid] = ts[tid];
+    }
 }
 
-template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0>
+template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0, int KS = 1, int XD = 0>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
                    const SepLayer* next = nullptr) {
-    constexpr size_t lds_pipe = 2u * (XPMAX + 1) * 128 + 2u * 1280 + 2u * 2u * (BM + (BDIR ? 0 : BN)) * 64;
+    constexpr size_t lds_pipe0 = (XD ? 3u : 2u * KS) * (XPMAX + 1) * 128 + (XD ? 0u : 2u * KS * 1280) + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
+    const size_t lds_pipe = lds_pipe0 + (XD ? (size_t)40 * L.cin : 0);   // XD: + taps and shift of all input channels
     constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4;
-    constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
+    const size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
+    constexpr size_t lds_pipe_max = lds_pipe0 + (XD ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
+    constexpr size_t lds_max = lds_pipe_max > lds_tile ? lds_pipe_max : lds_tile;
     static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max + (ABL == 1 ? 1024 : 0));
         attr_set = true;
     }
     const int tiles_n = L.cout / BN;
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
+    if constexpr (ABL == 0 && BDIR == 1 && VS == 1 && NDW == 0 && BM == 96) {
+        if (getenv("BD_WS_TRACE") && L.cin == 512) {
+            launch_sep_ws<BN, XPMAX, 1, NDW, BM, BDIR, VS, KS, XD>(X, L, out, M, stream, next);
+            return;
+        }
+    }
+    if constexpr (ABL == 1) {
+        static unsigned* dbg = nullptr;
+        static int shots = 0;
+        if (!dbg) (void)hipMalloc(&dbg, 1024);
+        (void)hipMemsetAsync(dbg, 0, 1024, stream);
+        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, L.dw_w,
+                       L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
+                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
+                       out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, nullptr, nullptr, reinterpret_cast<float*>(dbg));
+        (void)hipStreamSynchronize(stream);
+        unsigned h[256];
+        (void)hipMemcpy(h, dbg, 1024, hipMemcpyDeviceToHost);
+        if (++shots == 10) {
+            for (int role = 0; role < 2; ++role) {
+                fprintf(stderr, "[trace] %s: work / wait cycles per barrier:", role ? "producer" : "consumer");
+                for (int i = 0; i < 24; ++i) {
+                    const unsigned arr = h[(role * 64 + i) * 2], lv = h[(role * 64 + i) * 2 + 1];
+                    const unsigned prev = i ? h[(role * 64 + i - 1) * 2 + 1] : arr;
+                    if (!arr && !lv) break;
+                    fprintf(stderr, " %u/%u", arr - prev, lv - arr);
+                }
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "[trace] producer stage 6: store %u, load-issue %u, depthwise %u\n", h[193] - h[192], h[194] - h[193], h[195] - h[194]);
+        }
+        return;
+    }
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
                        static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
@@ -1756,7 +1930,7 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
     if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;
     if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & 1)) return false;
     const long long M = (long long)windows * P;
-    launch_sep_ws<256, 96, 0, 1, 96, 1, 1>(in, L, out, M, stream, &next);
+    launch_sep_ws<256, 96, 0, 1, 96, 1, 1, 1, 1>(in, L, out, M, stream, &next);
     return true;
 }
 
@@ -1769,19 +1943,23 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     // auto (measured on MI355X): the 12x8, 6x4 and 3x2 maps run best on the wave-specialised kernel with
     // 96-row x 256-column tiles; the 24x16 map (K = 128, only 4 stages per tile) on the same kernel with
     // 64-row x 128-column tiles, small enough for two workgroups per CU
-    // (variant 7 = weights as register fragments + producers sharing taps vertically; 3 / 5 = the same tiles
-    //  with LDS-staged weights and one output per tap set, kept as tested alternatives)
-    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 7;
-    if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 7;   // layer 4
+    // (variant 9 = weights as register fragments, producers sharing taps vertically, input slab by LDS-DMA into
+    //  a ring of three; 7 = the same with register-staged slabs; 8 = 7 with 64-channel stages; 3 / 5 = the same
+    //  tiles with LDS-staged weights and one output per tap set - all kept as tested alternatives)
+    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;
+    if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;   // layer 4
     if (variant >= 3 && L.cin >= 128) {                            // wave-specialised kernels (BM = 96)
         if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
-            if (variant == 7) launch_sep_ws<128, 96, 0, 0, 64, 1, 1>(in, L, out, M, stream);
+            if (variant == 9) launch_sep_ws<128, 96, 0, 0, 64, 1, 1, 1, 1>(in, L, out, M, stream);
+            else if (variant >= 7) launch_sep_ws<128, 96, 0, 0, 64, 1, 1>(in, L, out, M, stream);
             else if (variant == 5) launch_sep_ws<128, 96, 0, 0, 64>(in, L, out, M, stream);
             else launch_sep_ws<128, 128>(in, L, out, M, stream);
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
-            if (variant == 7 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1>(in, L, out, M, stream);
+            if (variant == 9 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
+            else if (variant == 8 && L.cout % 256 == 0 && L.cin % 256 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 2>(in, L, out, M, stream);
+            else if (variant >= 7 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1>(in, L, out, M, stream);
             else if (variant == 6 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1>(in, L, out, M, stream);
             else if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
             else if (L.cout % 128 == 0) launch_sep_ws<128, 96>(in, L, out, M, stream);
