@@ -70,7 +70,10 @@ def slot_plan(launches):
         if launches[pw_slot] > 0:
             if launches[dw_slot] > 0 or (stride == 2 and layer >= 3):
                 # (a stride-2 layer without a depthwise launch: the previous kernel applied it)
-                plan[pw_slot] = (f"pw{layer}", "pointwise_f16x3_kernel", pw[0], pw[1])
+                # (engine rule, cnn.hip launch_pointwise_ws: K >= 128 and N % 256 == 0 run on the wave-specialised
+                #  kernel with pass-through producers; the others on the plain split-f16 GEMM kernel)
+                fam = "sep_ws_kernel" if (c >= 128 and c % 64 == 0 and cout % 256 == 0) else "pointwise_f16x3_kernel"
+                plan[pw_slot] = (f"pw{layer}", fam, pw[0], pw[1])
                 if launches[dw_slot] == 0 and layer >= 5 and (pw_slot - 2) in plan:
                     nm, fam, nb, fl = plan[pw_slot - 2]
                     # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own

@@ -767,7 +767,7 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // MFMA B fragments (16 bytes of hi, 16 of lo per k-step and column tile) straight from global/L2 into a
 // double-buffered register set, one stage ahead.  The engine keeps a copy of the split weights in fragment
 // order, so each of those loads is one contiguous KiB per wave.
-template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD>
+template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD, int PWO>
 __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
@@ -776,7 +776,8 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     static_assert(BM == 96 || BM == 64, "tile height");
     static_assert(KS == 1 || (KS == 2 && BDIR == 1), "64-channel stages need the weights out of LDS");
     static_assert(XD == 0 || (BDIR == 1 && KS == 1 && XPMAX % 32 == 0), "slab DMA is issued by the fragment-loading consumers");
-    constexpr int NX = XD ? 3 : 2 * KS;      // slab / tap buffers: a ring of three when the consumers fill it by DMA
+    static_assert(PWO == 0 || (XD == 1 && NDW == 0 && XPMAX == BM), "pointwise-only tiles use the DMA pipeline");
+    constexpr int NX = XD ? 3 : 2 * KS;      // slab / tap buffers: a ring of three when the producers fill it by DMA
     constexpr int WS_FLOATS = XD ? 0 : 320;   // depthwise taps + shift of a 32-channel block (XD: all K at once, in Wall)
     constexpr int WN = BN / 4;               // consumer wave tile: BM x WN
     constexpr int TM = BM / 32, TN = WN / 32;
@@ -805,9 +806,11 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
 
     constexpr size_t TS_PIPE = (size_t)NX * (XPMAX + 1) * 128 + (size_t)NX * WS_FLOATS * 4 + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
     constexpr size_t TS_TILE = (size_t)BM * (BN + 4) * 4;
-    const size_t ts_pipe_ = TS_PIPE + (XD ? (size_t)40 * K : 0);
+    const size_t ts_pipe_ = TS_PIPE + (XD && !PWO ? (size_t)40 * K : 0);
     unsigned* const ts = reinterpret_cast<unsigned*>(smem_raw + (ts_pipe_ > TS_TILE ? ts_pipe_ : TS_TILE));
     int tsn = 0;
+    const unsigned ts_wall0 = ABL == 1 ? (unsigned)wall_clock64() : 0u;
+    (void)ts_wall0;
 #define BD_TS(W)                                                                                          \
     if constexpr (ABL == 1) {                                                                             \
         if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))                                     \
@@ -824,7 +827,10 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     const int P = H * W;
     long long x_lo;
     int x_cnt;
-    if (P >= BM) {
+    if (PWO) {                                // no depthwise: the slab is the tile's own rows
+        x_lo = m0;
+        x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
+    } else if (P >= BM) {
         const long long n = m0 / P;
         const int oh_a = (int)(m0 % P) / W;
         const int oh_b = oh_a + BM / W;
@@ -938,10 +944,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
                 v4f v;                                                                                    \
                 if constexpr (VS) v = xv[i * 3 + t];                                                      \
                 else v = *reinterpret_cast<const v4f*>(xs_ + xtap[i][t]);                                 \
-                a4.x = fmaf(v.x, wt[t].x, a4.x);                                                          \
-                a4.y = fmaf(v.y, wt[t].y, a4.y);                                                          \
-                a4.z = fmaf(v.z, wt[t].z, a4.z);                                                          \
-                a4.w = fmaf(v.w, wt[t].w, a4.w);                                                          \
+                a4 = __builtin_elementwise_fma(v, wt[t], a4);      /* v_pk_fma_f32: two IEEE fmas per issue */ \
             }                                                                                             \
             a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
             f16x4 hi, lo;                                                                                 \
@@ -995,17 +998,31 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
         BD_TS(1)                                                                                          \
     }
             // taps + shift of all K channels: [10][K] floats, once (ordinary loads, drained before any DMA is issued)
-            for (int i = pt; i < 10 * (K / 4); i += 256) {
+            for (int i = pt; !PWO && i < 10 * (K / 4); i += 256) {
                 const int r = i / (K / 4), c = i % (K / 4);
                 *reinterpret_cast<v4f*>(Wall + (size_t)r * K + c * 4) =
                     *reinterpret_cast<const v4f*>((r < 9 ? dw_w + (size_t)r * K : dw_b) + c * 4);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // PWO: the A tile is the slab itself, split into f16 hi + lo (rows lrow + 32 i, channels 4 lc4 ..)
+#define BD_P_CVT(XB, AB)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                      \
+        const v4f a4 = *reinterpret_cast<const v4f*>(Xs + (XB) * XS_FLOATS + (lrow + 32 * i) * 32 + lc4 * 4); \
+        f16x4 hi, lo;                                                                                     \
+        hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;   \
+        lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);                 \
+        lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);                 \
+        const int st_ = swz64(lrow + 32 * i, lc4 >> 1) + (lc4 & 1) * 8;                                   \
+        *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + st_) = hi;                                        \
+        *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + st_) = lo;                                        \
+    }
+#define BD_P_WORK(XB, AB)                                                                                 \
+    if constexpr (PWO) { BD_P_CVT(XB, AB) } else { BD_P_DW(XB, AB) }
             BD_X_DMA(0, 0)
             BD_X_DMA(32, 1)
             BD_X_DMA(64, 2)
             BD_P_SYNC(2 * ND)                 // slab 0 has landed, the taps are written
-            BD_P_DW(0, 0)
+            BD_P_WORK(0, 0)
             BD_P_SYNC(ND)                     // A[0] written; slab 1 has landed
             int rs = 1;                       // ring slot of slab k+1
             int k = 0;
@@ -1016,14 +1033,14 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
                 BD_PROBE(1)
                 BD_PROBE(2)
                 kch_ = (k + 1) * 32;
-                BD_P_DW(rs, (k + 1) & 1)
+                BD_P_WORK(rs, (k + 1) & 1)
                 BD_PROBE(3)
                 BD_P_SYNC(ND)                 // slab k+2 has landed, slab k+3 stays in flight
                 rs = rs == 2 ? 0 : rs + 1;
             }
             for (; k + 1 < nk; ++k) {         // the last two depthwise stages: nothing left to request
                 kch_ = (k + 1) * 32;
-                BD_P_DW(rs, (k + 1) & 1)
+                BD_P_WORK(rs, (k + 1) & 1)
                 BD_P_SYNC(0)
                 rs = rs == 2 ? 0 : rs + 1;
             }
@@ -1031,6 +1048,8 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
 #undef BD_X_DMA
 #undef BD_X_DMA1
 #undef BD_P_SYNC
+#undef BD_P_WORK
+#undef BD_P_CVT
         } else {
         // prologue: slabs 0 and 1 resident, slab 2 in flight, A[0] computed.  All three loads are issued
         // before the first store so the workgroup pays the HBM latency once, not three times.
@@ -1315,48 +1334,54 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     if constexpr (ABL == 1) {
         __syncthreads();
         if (blockIdx.x == 0 && tid < 256) reinterpret_cast<unsigned*>(out2)[tid] = ts[tid];
+        if (tid == 0 && blockIdx.x < 1024) {       // wall clock (100 MHz) at block start / end
+            reinterpret_cast<unsigned*>(out2)[256 + 2 * blockIdx.x] = ts_wall0;
+            reinterpret_cast<unsigned*>(out2)[257 + 2 * blockIdx.x] = (unsigned)wall_clock64();
+        }
     }
 }
 
-template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0, int KS = 1, int XD = 0>
+template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0, int KS = 1, int XD = 0, int PWO = 0>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
                    const SepLayer* next = nullptr) {
     constexpr size_t lds_pipe0 = (XD ? 3u : 2u * KS) * (XPMAX + 1) * 128 + (XD ? 0u : 2u * KS * 1280) + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
-    const size_t lds_pipe = lds_pipe0 + (XD ? (size_t)40 * L.cin : 0);   // XD: + taps and shift of all input channels
+    const size_t lds_pipe = lds_pipe0 + (XD && !PWO ? (size_t)40 * L.cin : 0);   // XD: + taps and shift of all input channels
     constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4;
     const size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
-    constexpr size_t lds_pipe_max = lds_pipe0 + (XD ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
+    constexpr size_t lds_pipe_max = lds_pipe0 + (XD && !PWO ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
     constexpr size_t lds_max = lds_pipe_max > lds_tile ? lds_pipe_max : lds_tile;
     static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max + (ABL == 1 ? 1024 : 0));
         attr_set = true;
     }
     const int tiles_n = L.cout / BN;
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
     if constexpr (ABL == 0 && BDIR == 1 && VS == 1 && NDW == 0 && BM == 96) {
-        if (getenv("BD_WS_TRACE") && L.cin == 512) {
-            launch_sep_ws<BN, XPMAX, 1, NDW, BM, BDIR, VS, KS, XD>(X, L, out, M, stream, next);
+        // developer aid: BD_WS_TRACE=1 traces a 512-channel fused layer, =2 the 256-channel pointwise of layer 7
+        const char* tr = getenv("BD_WS_TRACE");
+        if (tr && ((tr[0] == '1' && !PWO && L.cin == 512) || (tr[0] == '2' && PWO && L.cin == 256))) {
+            launch_sep_ws<BN, XPMAX, 1, NDW, BM, BDIR, VS, KS, XD, PWO>(X, L, out, M, stream, next);
             return;
         }
     }
     if constexpr (ABL == 1) {
         static unsigned* dbg = nullptr;
         static int shots = 0;
-        if (!dbg) (void)hipMalloc(&dbg, 1024);
-        (void)hipMemsetAsync(dbg, 0, 1024, stream);
-        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, L.dw_w,
+        if (!dbg) (void)hipMalloc(&dbg, 1024 + 8192);
+        (void)hipMemsetAsync(dbg, 0, 1024 + 8192, stream);
+        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
                        static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, nullptr, nullptr, reinterpret_cast<float*>(dbg));
         (void)hipStreamSynchronize(stream);
-        unsigned h[256];
-        (void)hipMemcpy(h, dbg, 1024, hipMemcpyDeviceToHost);
-        if (++shots == 10) {
+        static unsigned h[256 + 2048];
+        (void)hipMemcpy(h, dbg, 1024 + 8192, hipMemcpyDeviceToHost);
+        if (++shots == (PWO ? 3 : 10)) {
             for (int role = 0; role < 2; ++role) {
                 fprintf(stderr, "[trace] %s: work / wait cycles per barrier:", role ? "producer" : "consumer");
                 for (int i = 0; i < 24; ++i) {
@@ -1367,11 +1392,27 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
                 }
                 fprintf(stderr, "\n");
             }
+            {
+                const int nb = tiles < 1024 ? (int)tiles : 1024;
+                unsigned t0 = ~0u, t1 = 0, dmin = ~0u, dmax = 0, smax = 0;
+                double dsum = 0;
+                for (int b = 0; b < nb; ++b) t0 = h[256 + 2 * b] < t0 ? h[256 + 2 * b] : t0;
+                for (int b = 0; b < nb; ++b) {
+                    const unsigned st = h[256 + 2 * b] - t0, en = h[257 + 2 * b] - t0, d = en - st;
+                    t1 = en > t1 ? en : t1;
+                    dmin = d < dmin ? d : dmin;
+                    dmax = d > dmax ? d : dmax;
+                    smax = st > smax ? st : smax;
+                    dsum += d;
+                }
+                fprintf(stderr, "[trace] %d blocks (10 ns ticks): last start %u, kernel span %u, block duration min %u avg %.0f max %u; block 0: start %u dur %u\n",
+                        nb, smax, t1, dmin, dsum / nb, dmax, h[256] - t0, h[257] - h[256]);
+            }
             fprintf(stderr, "[trace] producer stage 6: store %u, load-issue %u, depthwise %u\n", h[193] - h[192], h[194] - h[193], h[195] - h[194]);
         }
         return;
     }
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
                        static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
@@ -1914,7 +1955,18 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
     return 0;
 }
 
+// Pointwise 1x1 convolution on the wave-specialised kernel: the producers only split the input rows into
+// f16 hi + lo (no depthwise).  For the stride-2 layers, whose depthwise runs as its own kernel or in the
+// previous layer's epilogue.  Same products in the same order as pointwise_f16x3_kernel: bit-identical.
+bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
+    if (rows <= 0 || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0) return false;
+    // (96 x 128 tiles with two workgroups per CU measured the same: 33.1 vs 32.6 us on layer 7)
+    launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
+    return true;
+}
+
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
+    if (L.pw_mode == 1 && (L.pw_variant16 == 0 || L.pw_variant16 == 10) && launch_pointwise_ws(in, out, rows, L, stream)) return;
     if (L.pw_mode == 1)
         launch_pointwise_f16x3_variant(in, L.pw_whi, L.pw_wlo, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant16,
                                        stream);

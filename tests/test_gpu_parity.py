@@ -324,6 +324,32 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
         engine.set_fusion(True, True)
 
 
+@pytest.mark.parametrize("windows", [1, 3, 37, 130])
+def test_pointwise_on_wave_specialised_kernel_bit_identical_to_gemm_kernel(engine, windows):
+    """The 1x1 convolutions of layers 5-14 run (unfused path) on the wave-specialised kernel with pass-through
+    producers; the plain split-f16 GEMM kernel (tile variant 1) must give the same bits, partial tiles included."""
+    x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=100 + windows)
+    engine.set_pointwise_mode("f16x3")
+    stages = (8, 10, 12, 16, 24, 26)
+    try:
+        engine.set_fusion(False, False)
+        for layer in range(5, 15):
+            engine.set_pointwise_variant(layer, 1)
+        plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in stages}
+        plain_logits = engine.predict(x, 0.96).numpy()
+        for layer in range(5, 15):
+            engine.set_pointwise_variant(layer, 0)
+        for st, ref in plain.items():
+            assert np.array_equal(engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy(), ref), st
+        assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
+        engine.set_fusion(True, True)            # default path: layers 5, 7, 13 use it after a depthwise
+        assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
+    finally:
+        for layer in range(5, 15):
+            engine.set_pointwise_variant(layer, 0)
+        engine.set_fusion(True, True)
+
+
 @pytest.mark.parametrize("hop_prop,expect", [(1.0, 625), (0.5, 1249)])
 def test_config3_ten_minute_chunk(engine, weights_bundle, hop_prop, expect):
     """BASELINE config 3: a 600.0 s chunk (9 600 000 samples) of a 24 h recording, yamnet_k2 at whole and half hop:
