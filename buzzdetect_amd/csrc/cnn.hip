@@ -1673,63 +1673,71 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
     __syncthreads();
 
     // ---- B: conv1 rows r0 - 1 .. r0 + 5 ----
+    // (consecutive conv1 rows share a log-mel row: a rolling window reads 45 values instead of 63; the four
+    //  channels of a tap are two packed fmas)
     const int c4 = tid & 7;
     const int col = tid >> 3;
     {
-        float4 wt[9];
+        v4f wt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(c1_w + t * 32)[c4];
-        const float4 bias = reinterpret_cast<const float4*>(c1_b)[c4];
-#pragma unroll
-        for (int i = 0; i < C1R; ++i) {
-            const int c1r = r0 - 1 + i;
-            float4 acc = bias;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const float* row = &s_lm[2 * i + kh][2 * col];
-                const bool ok = 2 * c1r + kh < BD_PATCH_FRAMES;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    if (!ok) continue;
-                    const float v = row[kw];
-                    const float4 w = wt[kh * 3 + kw];
-                    acc.x = fmaf(v, w.x, acc.x);
-                    acc.y = fmaf(v, w.y, acc.y);
-                    acc.z = fmaf(v, w.z, acc.z);
-                    acc.w = fmaf(v, w.w, acc.w);
-                }
-            }
-            const bool valid = c1r >= 0 && c1r < 48;
-            float4 r4;
-            r4.x = valid ? fmaxf(acc.x, 0.0f) : 0.0f;
-            r4.y = valid ? fmaxf(acc.y, 0.0f) : 0.0f;
-            r4.z = valid ? fmaxf(acc.z, 0.0f) : 0.0f;
-            r4.w = valid ? fmaxf(acc.w, 0.0f) : 0.0f;
-            *reinterpret_cast<float4*>(&s_c1[i][col + 1][c4 * 4]) = r4;
-        }
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(c1_w + t * 32 + c4 * 4);
+        const v4f bias = *reinterpret_cast<const v4f*>(c1_b + c4 * 4);
+        // a tap row past the patch (log-mel row 96: SAME padding) is skipped, as conv1_kernel does; only the
+        // last row block of a window can meet one, so the check lives in its own copy of the loop
+        // (as a per-tap condition the compiler turns it into 252 selects)
+#define BD_STEM3_CONV1(CHECK)                                                                             \
+    {                                                                                                     \
+        float lm[3][3];                                                                                   \
+        _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[0][kw] = s_lm[0][2 * col + kw];               \
+        _Pragma("unroll") for (int i = 0; i < C1R; ++i) {                                                 \
+            const int c1r = r0 - 1 + i;                                                                   \
+            _Pragma("unroll") for (int kh = 1; kh < 3; ++kh)                                              \
+                _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[kh][kw] = s_lm[2 * i + kh][2 * col + kw]; \
+            v4f acc = bias;                                                                               \
+            _Pragma("unroll") for (int kh = 0; kh < 3; ++kh) {                                            \
+                if (CHECK && 2 * c1r + kh >= BD_PATCH_FRAMES) continue;                                   \
+                _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                        \
+                    const float v = lm[kh][kw];                                                           \
+                    acc = __builtin_elementwise_fma(v4f{v, v, v, v}, wt[kh * 3 + kw], acc);               \
+                }                                                                                         \
+            }                                                                                             \
+            const bool valid = c1r >= 0 && c1r < 48;                                                      \
+            v4f r4;                                                                                       \
+            r4.x = valid ? fmaxf(acc.x, 0.0f) : 0.0f;                                                     \
+            r4.y = valid ? fmaxf(acc.y, 0.0f) : 0.0f;                                                     \
+            r4.z = valid ? fmaxf(acc.z, 0.0f) : 0.0f;                                                     \
+            r4.w = valid ? fmaxf(acc.w, 0.0f) : 0.0f;                                                     \
+            *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = r4;                                      \
+            _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[0][kw] = lm[2][kw];                       \
+        }                                                                                                 \
+    }
+        if (2 * (r0 + C1R - 2) + 2 >= BD_PATCH_FRAMES) BD_STEM3_CONV1(true)
+        else BD_STEM3_CONV1(false)
+#undef BD_STEM3_CONV1
     }
     __syncthreads();
 
     // ---- C: depthwise 2 for rows r0 .. r0 + 4 -> split-f16 A tile [160][32] ----
+    // (rolling window over the conv1 band: 21 LDS reads instead of 45)
     {
-        float4 wt[9];
+        v4f wt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(dw2_w + t * 32)[c4];
-        const float4 bias = reinterpret_cast<const float4*>(dw2_b)[c4];
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(dw2_w + t * 32 + c4 * 4);
+        const v4f bias = *reinterpret_cast<const v4f*>(dw2_b + c4 * 4);
+        v4f cv[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) cv[kh][kw] = *reinterpret_cast<const v4f*>(&s_c1[kh][col + kw][c4 * 4]);
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
-            float4 acc = bias;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) cv[2][kw] = *reinterpret_cast<const v4f*>(&s_c1[r + 2][col + kw][c4 * 4]);
+            v4f acc = bias;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float4 v = *reinterpret_cast<const float4*>(&s_c1[r + kh][col + kw][c4 * 4]);
-                    const float4 w = wt[kh * 3 + kw];
-                    acc.x = fmaf(v.x, w.x, acc.x);
-                    acc.y = fmaf(v.y, w.y, acc.y);
-                    acc.z = fmaf(v.z, w.z, acc.z);
-                    acc.w = fmaf(v.w, w.w, acc.w);
-                }
+                for (int kw = 0; kw < 3; ++kw) acc = __builtin_elementwise_fma(cv[kh][kw], wt[kh * 3 + kw], acc);
             acc.x = fmaxf(acc.x, 0.0f);
             acc.y = fmaxf(acc.y, 0.0f);
             acc.z = fmaxf(acc.z, 0.0f);
@@ -1741,6 +1749,11 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
             const int off = swz64(r * 32 + col, c4 >> 1) + (c4 & 1) * 8;
             *reinterpret_cast<f16x4*>(s_ah + off) = hi;
             *reinterpret_cast<f16x4*>(s_al + off) = lo;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                cv[0][kw] = cv[1][kw];
+                cv[1][kw] = cv[2][kw];
+            }
         }
     }
     __syncthreads();
@@ -1795,25 +1808,22 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
     for (int it = 0; it < 2; ++it) {
         const int id = tid + 256 * it;              // 512 tasks: o (2) x ow (16) x c4 (16)
         const int c16 = id & 15, ow = (id >> 4) & 15, o = id >> 8;
-        float4 acc = reinterpret_cast<const float4*>(dw3_b)[c16];
+        v4f acc = *reinterpret_cast<const v4f*>(dw3_b + c16 * 4);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int pc = 2 * ow + kw;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pc < 32) v = *reinterpret_cast<const float4*>(P + ((2 * o + kh) * 32 + pc) * PW + c16 * 4);
-                const float4 w = reinterpret_cast<const float4*>(dw3_w + (kh * 3 + kw) * 64)[c16];
-                acc.x = fmaf(v.x, w.x, acc.x);
-                acc.y = fmaf(v.y, w.y, acc.y);
-                acc.z = fmaf(v.z, w.z, acc.z);
-                acc.w = fmaf(v.w, w.w, acc.w);
+                v4f v = {0.f, 0.f, 0.f, 0.f};
+                if (pc < 32) v = *reinterpret_cast<const v4f*>(P + ((2 * o + kh) * 32 + pc) * PW + c16 * 4);
+                const v4f w = *reinterpret_cast<const v4f*>(dw3_w + (kh * 3 + kw) * 64 + c16 * 4);
+                acc = __builtin_elementwise_fma(v, w, acc);
             }
         acc.x = fmaxf(acc.x, 0.0f);
         acc.y = fmaxf(acc.y, 0.0f);
         acc.z = fmaxf(acc.z, 0.0f);
         acc.w = fmaxf(acc.w, 0.0f);
-        reinterpret_cast<float4*>(dst + ((size_t)o * 16 + ow) * 64)[c16] = acc;
+        *reinterpret_cast<v4f*>(dst + ((size_t)o * 16 + ow) * 64 + c16 * 4) = acc;
     }
 }
 

@@ -32,6 +32,15 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// Bank swizzle of the 256-entry float2 FFT tile.  The Stockham passes write with strides 4, 16 and 64 (index =
+// 4 l + r, 16 g + k + 4 r, 64 q + k + 16 r) and read contiguously; unswizzled, the strided ds_write_b64 are
+// 4-way bank-conflicted per half-wave and the kernel is LDS-bound.  XOR-ing the slot's low five bits with two
+// parities of index bits 5..7 makes every write and every contiguous read conflict-free (searched exhaustively
+// over the GF(2) maps of those bits; the mirrored read of the real-FFT split keeps a 2-way conflict).
+// Because only low bits change, each access pattern is "per-lane base ^ small constant".
+__device__ __forceinline__ constexpr int zsw_mask(int b5, int b6, int b7) { return ((b5 ^ b6) * 21) ^ ((b5 ^ b7) * 10); }
+__device__ __forceinline__ int zsw(int i) { return i ^ zsw_mask((i >> 5) & 1, (i >> 6) & 1, (i >> 7) & 1); }
+
 // forward DFT-4 of (u0..u3) -> (X0..X3) in place
 __device__ __forceinline__ void dft4(float2& u0, float2& u1, float2& u2, float2& u3) {
     const float2 a = make_float2(u0.x + u2.x, u0.y + u2.y);
@@ -44,7 +53,7 @@ __device__ __forceinline__ void dft4(float2& u0, float2& u1, float2& u2, float2&
     u3 = make_float2(b.x - d.x, b.y - d.y);
 }
 
-__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ pcm, long long n_valid,
+__global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm, long long n_valid,
                                                      long long n_frames, float* __restrict__ out,
                                                      const FeTables* __restrict__ tab) {
     __shared__ __attribute__((aligned(16))) float s_pcm[kGroupSamples];
@@ -76,6 +85,15 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
     float2 tws[4];                        // real-FFT split twiddles exp(-2 pi i k / 512), k = lane + 64 r
 #pragma unroll
     for (int r = 0; r < 4; ++r) tws[r] = tab->tw512[lane + 64 * r];
+    // swizzled tile indices: contiguous accesses lane + 64 r, pass-1 / p=4 / p=16 write bases, mirrored reads
+    const int zi_lin = lane ^ ((lane >> 5) * 31);                    // (zi_lin ^ zsw_mask(0, r & 1, r >> 1)) + 64 r
+    const int zi_w1 = zsw(4 * lane);                                 // ^ r
+    const int zi_w4 = zsw(((lane & ~3) << 2) + (lane & 3));          // ^ 4 r
+    const int zi_w16 = zsw(((lane & ~15) << 2) + (lane & 15));       // ^ 16 r ^ (r >= 2 ? 31 : 0)
+    int zi_mir[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zi_mir[r] = zsw((256 - (lane + 64 * r)) & 255);
+#define BD_ZLIN(R) ((zi_lin ^ zsw_mask(0, (R) & 1, (R) >> 1)) + 64 * (R))
     const int band_start = tab->band_start[lane];
     const int band_len = tab->band_len[lane];
     float bw[kMelTaps];                   // the band's mel weights (zero past band_len)
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             }
             dft4(u[0], u[1], u[2], u[3]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[4 * lane + r] = u[r];
+            for (int r = 0; r < 4; ++r) z[zi_w1 ^ r] = u[r];
             wave_lds_sync();
 
             // ---- passes 2..4 (p = 4, 16, 64) ----
@@ -124,16 +142,17 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                 int pi = 0;
 #pragma unroll
                 for (int p = 4; p <= 64; p *= 4, ++pi) {
-                    const int k = lane & (p - 1);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) u[r] = z[lane + 64 * r];
+                    for (int r = 0; r < 4; ++r) u[r] = z[BD_ZLIN(r)];
                     u[1] = cmul(u[1], tw[pi][0]);
                     u[2] = cmul(u[2], tw[pi][1]);
                     u[3] = cmul(u[3], tw[pi][2]);
                     dft4(u[0], u[1], u[2], u[3]);
-                    const int j0 = ((lane - k) << 2) + k;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) z[j0 + p * r] = u[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = p == 4 ? (zi_w4 ^ (4 * r)) : p == 16 ? (zi_w16 ^ (16 * r) ^ ((r >> 1) * 31)) : BD_ZLIN(r);
+                        z[j] = u[r];
+                    }
                     wave_lds_sync();
                 }
             }
@@ -142,8 +161,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = lane + 64 * r;
-                const float2 zk = z[k];
-                const float2 zm = z[(256 - k) & 255];
+                const float2 zk = z[BD_ZLIN(r)];
+                const float2 zm = z[zi_mir[r]];
                 const float ex = 0.5f * (zk.x + zm.x);
                 const float ey = 0.5f * (zk.y - zm.y);
                 const float ox = 0.5f * (zk.y + zm.y);    // O = -i/2 * (Zk - conj(Zm))
@@ -169,6 +188,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
             wave_lds_sync();   // mag / z reads of this frame retire before the next frame overwrites them
         }
     }
+#undef BD_ZLIN
 }
 
 // ---------------------------------------------------------------------------------------------------
