@@ -67,7 +67,11 @@ def slot_plan(launches):
                                  conv1[1] + stem_flops + dw[1])
             else:
                 plan[dw_slot] = (f"dw{layer}", "depthwise_kernel", dw[0], dw[1])
-        if launches[pw_slot] > 0:
+        if layer == 3 and launches[pw_slot] > 0 and launches[dw_slot] == 0 and launches[1] == 0 and launches[3] == 0:
+            # layers 1-3 in one kernel (stem3_kernel<true>): log-mel patch in, layer-3 output out
+            plan[pw_slot] = ("stem(1-3)", "stem3_kernel", 96 * 64 * 4 + ho * wo * cout * 4,
+                             conv1[1] + stem_flops + dw[1] + pw[1])
+        elif launches[pw_slot] > 0:
             if launches[dw_slot] > 0 or (stride == 2 and layer >= 3):
                 # (a stride-2 layer without a depthwise launch: the previous kernel applied it)
                 # (engine rule, cnn.hip launch_pointwise_ws: K >= 128 and N % 256 == 0 run on the wave-specialised

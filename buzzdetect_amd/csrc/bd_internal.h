@@ -81,6 +81,9 @@ void launch_stem(const float* logmel, int patch_step, const WindowMap& map, int 
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
+void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                  const float* c1_b,
+                  const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
                       int n_classes, float* emb, float* logits, hipStream_t stream);
 

@@ -1611,14 +1611,21 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ log
 //   C  depthwise 2 (5 rows) -> split-f16 A tile   D  [160][32] x [32][64] on the matrix cores
 //   E  bias + ReLU -> f32 tile P[160][64] in LDS (rows past the map's edge are the zero padding)
 //   F  depthwise 3 (stride 2, SAME = pad 0 before / 1 after) on P -> HBM, [2][16][64] per workgroup
+//   PW3 = true additionally runs layer 3's pointwise convolution on the two depthwise rows, so neither the
+//   layer-2 output nor the layer-3 depthwise output (100 MB per 1024 windows, written and read back) touch HBM:
+//   F' depthwise 3 -> split-f16 A tile [32][64] in LDS   G  [32][64] x [64][128] on the matrix cores (wave w:
+//   columns 32 w .. 32 w + 31, weights as register fragments from the fragment-order copy)   H  bias + ReLU -> HBM
 // Arithmetic order per element equals conv1_kernel / depthwise_kernel / pointwise_f16x3_kernel.
-__global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ logmel, int patch_step,
+template <bool PW3>
+__global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__ logmel, int patch_step,
                                                     const WindowMap map, int w0,
                                                     const float* __restrict__ c1_w, const float* __restrict__ c1_b,
                                                     const float* __restrict__ dw2_w, const float* __restrict__ dw2_b,
                                                     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
                                                     const float* __restrict__ pw_b, const float* __restrict__ dw3_w,
-                                                    const float* __restrict__ dw3_b, float* __restrict__ out) {
+                                                    const float* __restrict__ dw3_b, float* __restrict__ out,
+                                                    const _Float16* __restrict__ W3fhi, const _Float16* __restrict__ W3flo,
+                                                    const float* __restrict__ pw3_b) {
     constexpr int R2 = 5;                       // layer-2 rows in the tile
     constexpr int C1R = R2 + 2;                 // conv1 rows incl. halo: 7
     constexpr int LMR = 2 * C1R + 1;            // log-mel rows: 15
@@ -1629,7 +1636,11 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
     constexpr int OFF_C1 = 0;
     constexpr int OFF_AH = OFF_C1 + C1R * 34 * 32 * 4;              // 30464
     constexpr int OFF_AL = OFF_AH + BM * 64;                        // 40704
-    constexpr int LDS_BYTES = OFF_AL + BM * 64;                     // 50944; P (43520 B) aliases from 0
+    constexpr int P_BYTES = BM * PW * 4;                            // 43520
+    constexpr int OFF_A3H = P_BYTES;                                // PW3: layer-3 A tile, [2 halves of 32 k][32 rows][64 B]
+    constexpr int OFF_A3L = OFF_A3H + 2 * 32 * 64;
+    constexpr int LDS_BYTES = PW3 ? OFF_A3L + 2 * 32 * 64 : OFF_AL + BM * 64;   // 51712 / 50944; P aliases from 0
+    static_assert(OFF_AL + BM * 64 <= LDS_BYTES, "pipeline buffers must fit");
     static_assert(LMR * 68 * 4 <= 2 * BM * 64, "log-mel band must fit in the A tile it aliases");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     float (*s_lm)[68] = reinterpret_cast<float (*)[68]>(smem + OFF_AH);
@@ -1655,6 +1666,16 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
             const int koff = (2 * s2 + (lane >> 5)) * 8;
             wbh[s2] = *reinterpret_cast<const f16x8*>(Whi + wrow * 32 + koff);
             wbl[s2] = *reinterpret_cast<const f16x8*>(Wlo + wrow * 32 + koff);
+        }
+    }
+
+    f16x8 w3h[4], w3l[4];                       // PW3: this lane's layer-3 weight fragments, k16 steps 0..3
+    if constexpr (PW3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t f = ((size_t)(wave * 4 + q) * 64 + lane) * 8;
+            w3h[q] = *reinterpret_cast<const f16x8*>(W3fhi + f);
+            w3l[q] = *reinterpret_cast<const f16x8*>(W3flo + f);
         }
     }
 
@@ -1823,7 +1844,43 @@ __global__ __launch_bounds__(256) void stem3_kernel(const float* __restrict__ lo
         acc.y = fmaxf(acc.y, 0.0f);
         acc.z = fmaxf(acc.z, 0.0f);
         acc.w = fmaxf(acc.w, 0.0f);
-        *reinterpret_cast<v4f*>(dst + ((size_t)o * 16 + ow) * 64 + c16 * 4) = acc;
+        if constexpr (PW3) {
+            f16x4 hi, lo;
+            hi[0] = (_Float16)acc.x; hi[1] = (_Float16)acc.y; hi[2] = (_Float16)acc.z; hi[3] = (_Float16)acc.w;
+            lo[0] = (_Float16)(acc.x - (float)hi[0]); lo[1] = (_Float16)(acc.y - (float)hi[1]);
+            lo[2] = (_Float16)(acc.z - (float)hi[2]); lo[3] = (_Float16)(acc.w - (float)hi[3]);
+            const int c = c16 & 7;
+            const int off = (c16 >> 3) * 32 * 64 + swz64(o * 16 + ow, c >> 1) + (c & 1) * 8;
+            *reinterpret_cast<f16x4*>(smem + OFF_A3H + off) = hi;
+            *reinterpret_cast<f16x4*>(smem + OFF_A3L + off) = lo;
+        } else {
+            *reinterpret_cast<v4f*>(dst + ((size_t)o * 16 + ow) * 64 + c16 * 4) = acc;
+        }
+    }
+    if constexpr (PW3) {
+        __syncthreads();
+        // ---- G: [32][64] x [64][128], one 32 x 32 tile per wave ----
+        f32x16 acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = (q >> 1) * 32 * 64 + swz64(frow, 2 * (q & 1) + fh);
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(smem + OFF_A3H + off);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(smem + OFF_A3L + off);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w3h[q], acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3l[q], acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3h[q], acc3, 0, 0, 0);
+        }
+        // ---- H: bias + ReLU, [32][128] block of the layer-3 output (rows are consecutive NHWC positions) ----
+        float* dst3 = out + (((size_t)win * 24 + 2 * ob) * 16) * 128;
+        const int n = 32 * wave + frow;
+        const float b = pw3_b[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 4 * fh + (r & 3) + 8 * (r >> 2);
+            dst3[(size_t)m * 128 + n] = fmaxf(acc3[r] + b, 0.0f);
+        }
     }
 }
 
@@ -2054,9 +2111,19 @@ void launch_stem(const float* logmel, int patch_step, const WindowMap& map, int 
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-    hipLaunchKernelGGL(stem3_kernel, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w, c1_b,
-                       L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out);
+    hipLaunchKernelGGL(stem3_kernel<false>, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
+                       c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out, nullptr, nullptr, nullptr);
+}
+
+// Layers 1-3 complete: out = [windows][24][16][128], the layer-3 output.
+void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                  const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
+    if (windows <= 0) return;
+    hipLaunchKernelGGL(stem3_kernel<true>, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
+                       c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out,
+                       static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_b);
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,

@@ -54,6 +54,7 @@ struct bd_engine {
     bool fuse_stem = true;            // layers 1-2 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
     bool fuse_stem3 = true;           // the stem also applies layer 3's depthwise (needs fuse_stem)
+    bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     int sep_variant = 0;
     float* d_pool = nullptr;          // one allocation for every folded tensor
@@ -686,7 +687,16 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
         const bool fuse_stem3 = fuse_stem && e->fuse_stem3 && (stop_stage < 0 || stop_stage >= 4);
         bool skip_dw3 = false;
         int skip_dw_layer = -1;      // loop index of a layer whose depthwise the previous kernel already applied
-        if (fuse_stem3) {
+        if (fuse_stem3 && e->fuse_stem4) {
+            {
+                Scope sc(e, stream, 5);      // timed in the slot of pointwise 3 (slots 1-4 stay empty)
+                bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, e->sep[0], e->sep[1], buf_a, stream);
+            }
+            last = buf_a;
+            last_floats = (int64_t)gw * 24 * 16 * 128;
+            stopped = stop_stage == 4;
+            first_layer = 2;
+        } else if (fuse_stem3) {
             {
                 Scope sc(e, stream, 4);      // timed in the slot of depthwise 3 (slots 1-3 stay empty)
                 bd::launch_stem3(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, e->sep[0], e->sep[1], buf_b, stream);
@@ -850,6 +860,7 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
+    h->fuse_stem4 = stem >= 3;
     h->fuse_sep = separable != 0;
     h->fuse_next_dw = separable == 1;
     h->sep_variant = separable > 1 ? separable : 0;

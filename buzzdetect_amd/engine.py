@@ -122,9 +122,9 @@ class HipEngine:
         _lib.check(self._lib.bd_set_frontend_variant(self._handle, int(variant)))
 
     def set_fusion(self, stem=True, separable=True) -> None:
-        """Fused stem kernel (True/2 = incl. layer 3's depthwise, 1 = layers 1-2 only, False = off) and
-        fused depthwise+pointwise kernels (True / variant number / False)."""
-        stem_code = 2 if stem is True else int(stem)
+        """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, 1 = layers 1-2 only,
+        False = off) and fused depthwise+pointwise kernels (True / variant number / False)."""
+        stem_code = 3 if stem is True else int(stem)
         _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))
 
     def set_pointwise_variant(self, layer: int, variant: int) -> None:

@@ -182,8 +182,10 @@ BD_API int bd_set_frontend_variant(bd_handle h, int32_t variant);
 
 /* Kernel fusion in mode 1 (both on by default; 0 = one kernel per op, the layout the stage taps use):
    stem == 1       layers 1-2 (conv, depthwise, pointwise) as one kernel, timed in profile slot 3;
-   stem == 2       (default) that kernel also applies layer 3's stride-2 depthwise and writes only its
+   stem == 2       that kernel also applies layer 3's stride-2 depthwise and writes only its
                    output (the 402 MB layer-2 tensor never reaches HBM); timed in profile slot 4;
+   stem >= 3       (default) ... and layer 3's pointwise convolution: layers 1-3 are one kernel that
+                   reads log-mel patches and writes the [24][16][128] layer-3 output; profile slot 5;
    separable != 0  stride-1 layers 4, 6, 8-12, 14: depthwise computed inside the pointwise GEMM, timed
                    in the layer's pointwise slot (>= 2: explicit kernel variants, tuning only).  With 1
                    (default) layers 6 and 12 also apply the NEXT layer's stride-2 depthwise in their

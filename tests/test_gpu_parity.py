@@ -284,8 +284,8 @@ def test_pointwise_gemm_every_tile_variant(mode, m, k, n):
 
 
 def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
-    """Layers 1-2 as one kernel (stem mode 1) and layers 1-2 + depthwise 3 as one kernel (mode 2, default)
-    must reproduce conv1 -> depthwise -> pointwise -> depthwise launch by launch."""
+    """Layers 1-2 as one kernel (stem mode 1), layers 1-2 + depthwise 3 (mode 2) and layers 1-3 complete (mode 3,
+    default) must reproduce conv1 -> depthwise -> pointwise -> depthwise -> pointwise launch by launch."""
     x = O.synthetic_audio(HOP * 37 + 1234, seed=55)
     engine.set_pointwise_mode("f16x3")
     try:
@@ -294,7 +294,7 @@ def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
         plain_pw3 = engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy()
         plain = engine.predict(x, 0.96).numpy()
         plain_half = engine.predict(x, 0.48).numpy()      # overlapping windows read shared log-mel rows
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             engine.set_fusion(mode, False)
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy(), plain_pw2), mode
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy(), plain_pw3), mode
