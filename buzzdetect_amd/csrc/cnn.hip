@@ -818,6 +818,11 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
         if (W) ++tsn;                                                                                     \
     }
 #define BD_SYNC() { BD_TS(0) __syncthreads(); BD_TS(1) }
+#define BD_PROBE2(I)                                                                                      \
+    if constexpr (ABL == 1) {                                                                             \
+        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))                                     \
+            ts[200 + (I)] = (unsigned)__builtin_readcyclecounter();                                       \
+    }
 #define BD_PROBE(I)                                                                                       \
     if constexpr (ABL == 1) {                                                                             \
         if (blockIdx.x == 0 && lane == 0 && wave == 4 && k == 6)                                          \
@@ -831,8 +836,10 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
         x_lo = m0;
         x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
     } else if (P >= BM) {
-        const long long n = m0 / P;
-        const int oh_a = (int)(m0 % P) / W;
+        // (32-bit arithmetic: the launcher guarantees M < 2^31, and 64-bit division is a ~1000-cycle routine)
+        const unsigned m0u = (unsigned)m0;
+        const long long n = m0u / (unsigned)P;
+        const int oh_a = (int)(m0u % (unsigned)P) / W;
         const int oh_b = oh_a + BM / W;
         const int r0 = oh_a > 0 ? oh_a - 1 : 0;
         const int r1 = oh_b < H ? oh_b + 1 : H;
@@ -844,6 +851,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     }
     if (wave >= 4) {
         // ================================================================= producers
+        BD_PROBE2(0)
         const int pt = tid - 256;
         const int lrow = pt >> 3, lc4 = pt & 7;
         const float* xp[XL];
@@ -859,16 +867,19 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
         if constexpr (VS) {
             // a thread owns LA vertically adjacent outputs (same column, rows oh0 .. oh0+LA-1) of 4 channels: the
             // 3 x 3 neighbourhoods overlap, so it reads (LA+2) x 3 slab values instead of LA x 9
+            // (W and the groups per window G = P / LA are powers of two - checked by the launcher - so this index
+            //  arithmetic is shifts; as divisions it was a visible part of the ~1900-cycle table set-up)
             const int slot = lrow;
+            const int lw = 31 - __builtin_clz(W);
             int wl = 0, g = slot;
             if (P < BM) {
-                const int G = P / LA;
-                wl = slot / G;
-                g = slot % G;
+                const int lg = 31 - __builtin_clz(P / LA);
+                wl = slot >> lg;
+                g = slot & ((1 << lg) - 1);
             }
-            const int og = g / W, ow = g % W;
+            const int og = g >> lw, ow = g & (W - 1);
             const int ml0 = wl * P + LA * og * W + ow;
-            const int oh0 = (P >= BM ? (int)(m0 % P) / W : 0) + LA * og;
+            const int oh0 = (P >= BM ? (int)((unsigned)m0 % (unsigned)P) / W : 0) + LA * og;
             const int xc0 = (int)(m0 + ml0 - x_lo);
 #pragma unroll
             for (int r = 0; r < LA + 2; ++r)
@@ -886,7 +897,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
             const int ml = lrow + 32 * i;
             long long m = m0 + ml;
             m = m < M ? m : M - 1;
-            const int q = (int)(m % P);
+            const int q = (int)((unsigned)m % (unsigned)P);
             const int oh = q / W, ow = q % W;
             const int xc = (int)(m - x_lo);
 #pragma unroll
@@ -997,13 +1008,6 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
         asm volatile("" ::: "memory");                                                                    \
         BD_TS(1)                                                                                          \
     }
-            // taps + shift of all K channels: [10][K] floats, once (ordinary loads, drained before any DMA is issued)
-            for (int i = pt; !PWO && i < 10 * (K / 4); i += 256) {
-                const int r = i / (K / 4), c = i % (K / 4);
-                *reinterpret_cast<v4f*>(Wall + (size_t)r * K + c * 4) =
-                    *reinterpret_cast<const v4f*>((r < 9 ? dw_w + (size_t)r * K : dw_b) + c * 4);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // PWO: the A tile is the slab itself, split into f16 hi + lo (rows lrow + 32 i, channels 4 lc4 ..)
 #define BD_P_CVT(XB, AB)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                      \
@@ -1018,11 +1022,36 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     }
 #define BD_P_WORK(XB, AB)                                                                                 \
     if constexpr (PWO) { BD_P_CVT(XB, AB) } else { BD_P_DW(XB, AB) }
+            BD_PROBE2(1)
+            // first the three slab requests, then the taps + shift of all K channels ([10][K] floats, ordinary loads):
+            // the compiler drains vmcnt before the first tap is written to LDS, which also covers the slabs - one
+            // memory round trip for the whole prologue instead of two
             BD_X_DMA(0, 0)
             BD_X_DMA(32, 1)
             BD_X_DMA(64, 2)
+            BD_PROBE2(2)
+            if constexpr (!PWO) {
+                // dw_w is [9][K] contiguous, dw_b [K]: as float4 items i < 9 K / 4 resp. the rest, Wall has the same
+                // flat layout.  All loads are issued before the first write (a plain loop made five serial round trips).
+                constexpr int TI = 10;            // items per thread at K = 1024
+                const int n_w = 9 * (K / 4), n_all = 10 * (K / 4);
+                v4f tw_[TI];
+#pragma unroll
+                for (int j = 0; j < TI; ++j) {
+                    const int i = pt + 256 * j;
+                    if (i < n_all) tw_[j] = *reinterpret_cast<const v4f*>(i < n_w ? dw_w + 4 * (size_t)i : dw_b + 4 * (size_t)(i - n_w));
+                }
+#pragma unroll
+                for (int j = 0; j < TI; ++j) {
+                    const int i = pt + 256 * j;
+                    if (i < n_all) *reinterpret_cast<v4f*>(Wall + 4 * (size_t)i) = tw_[j];
+                }
+            }
+            BD_PROBE2(3)
             BD_P_SYNC(2 * ND)                 // slab 0 has landed, the taps are written
+            BD_PROBE2(4)
             BD_P_WORK(0, 0)
+            BD_PROBE2(5)
             BD_P_SYNC(ND)                     // A[0] written; slab 1 has landed
             int rs = 1;                       // ring slot of slab k+1
             int k = 0;
@@ -1114,6 +1143,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
 #undef BD_P_DW
     } else {
     // ===================================================================== consumers
+    BD_PROBE2(8)
     const int wc = wave;                      // column block of this wave
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1314,7 +1344,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
             acc.y = fmaxf(acc.y, 0.0f);
             acc.z = fmaxf(acc.z, 0.0f);
             acc.w = fmaxf(acc.w, 0.0f);
-            const long long row2 = (m0 / P + wl) * P2 + pos2;
+            const long long row2 = (long long)((unsigned)m0 / (unsigned)P + wl) * P2 + pos2;
             *reinterpret_cast<v4f*>(out2 + (size_t)row2 * N + n0 + c4 * 4) = acc;
         }
     } else {
@@ -1408,6 +1438,8 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
                 fprintf(stderr, "[trace] %d blocks (10 ns ticks): last start %u, kernel span %u, block duration min %u avg %.0f max %u; block 0: start %u dur %u\n",
                         nb, smax, t1, dmin, dsum / nb, dmax, h[256] - t0, h[257] - h[256]);
             }
+            fprintf(stderr, "[trace] producer prologue (cycles since entry): tables %u, DMA issued %u, taps written %u, barrier passed %u, first depthwise done %u; consumer entry offset %d\n",
+                    h[201] - h[200], h[202] - h[200], h[203] - h[200], h[204] - h[200], h[205] - h[200], (int)(h[208] - h[200]));
             fprintf(stderr, "[trace] producer stage 6: store %u, load-issue %u, depthwise %u\n", h[193] - h[192], h[194] - h[193], h[195] - h[194]);
         }
         return;
@@ -2026,7 +2058,7 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 // f16 hi + lo (no depthwise).  For the stride-2 layers, whose depthwise runs as its own kernel or in the
 // previous layer's epilogue.  Same products in the same order as pointwise_f16x3_kernel: bit-identical.
 bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
-    if (rows <= 0 || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0) return false;
+    if (rows <= 0 || rows >= (1LL << 31) || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0) return false;
     // (96 x 128 tiles with two workgroups per CU measured the same: 33.1 vs 32.6 us on layer 7)
     launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
     return true;
@@ -2047,8 +2079,9 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
                                     hipStream_t stream) {
     const int P = L.h_out * L.w_out;
     if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;
-    if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & 1)) return false;
+    if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & (L.w_out - 1)) || L.h_out % 3) return false;
     const long long M = (long long)windows * P;
+    if (M >= (1LL << 31)) return false;       // the kernel's tile arithmetic is 32-bit
     launch_sep_ws<256, 96, 0, 1, 96, 1, 1, 1, 1>(in, L, out, M, stream, &next);
     return true;
 }
@@ -2058,7 +2091,10 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
                             hipStream_t stream) {
     if (L.stride != 1 || windows <= 0 || L.cin < 64) return false;
     const long long M = (long long)windows * L.h_out * L.w_out;
+    if (M >= (1LL << 31)) return false;       // the kernels' tile arithmetic is 32-bit
     const int P = L.h_out * L.w_out;
+    // ... and the wave-specialised kernel's index arithmetic assumes power-of-two widths and rows in threes
+    const bool ws_shape = (L.w_out & (L.w_out - 1)) == 0 && (P > 96 || L.h_out % 3 == 0);
     // auto (measured on MI355X): the 12x8, 6x4 and 3x2 maps run best on the wave-specialised kernel with
     // 96-row x 256-column tiles; the 24x16 map (K = 128, only 4 stages per tile) on the same kernel with
     // 64-row x 128-column tiles, small enough for two workgroups per CU
@@ -2067,7 +2103,7 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     //  tiles with LDS-staged weights and one output per tap set - all kept as tested alternatives)
     if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;
     if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;   // layer 4
-    if (variant >= 3 && L.cin >= 128) {                            // wave-specialised kernels (BM = 96)
+    if (variant >= 3 && L.cin >= 128 && ws_shape) {                // wave-specialised kernels (BM = 96)
         if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
             if (variant == 9) launch_sep_ws<128, 96, 0, 0, 64, 1, 1, 1, 1>(in, L, out, M, stream);
             else if (variant >= 7) launch_sep_ws<128, 96, 0, 0, 64, 1, 1>(in, L, out, M, stream);
