@@ -45,7 +45,7 @@ _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 
         (1, 512), (1, 512), (2, 1024), (1, 1024))
 
 
-def slot_plan(launches):
+def slot_plan(launches, pool_fused=True):
     """Map the 29 profile slots to (slot name, kernel family, per-window algorithmic bytes, per-window flops)
     for the launches that actually happened (fused kernels are timed in the pointwise slot of their layer)."""
     plan = {0: ("frontend", "logmel_kernel", FRONTEND_BYTES_PER_WINDOW, 0)}
@@ -87,9 +87,15 @@ def slot_plan(launches):
                                  conv1[1] + dw[1] + pw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
                 fam = "sep_ws_kernel"     # every fused stride-1 layer runs the wave-specialised kernel by default
-                plan[pw_slot] = (f"sep{layer}", fam, (h * w * c + ho * wo * cout) * 4, dw[1] + pw[1])
+                if layer == 14 and pool_fused:    # the average pool rides in the epilogue: [1024] out per window
+                    plan[pw_slot] = ("sep14+pool", fam, (h * w * c + cout) * 4, dw[1] + pw[1] + ho * wo * cout)
+                else:
+                    plan[pw_slot] = (f"sep{layer}", fam, (h * w * c + ho * wo * cout) * 4, dw[1] + pw[1])
         h, w, c = ho, wo, cout
-    plan[28] = ("pool_head", "pool_head_kernel", (6 * 1024 + 13) * 4, 2 * 1024 * 13)
+    if pool_fused and 27 in plan and plan[27][0] == "sep14+pool":
+        plan[28] = ("head", "pool_head_kernel", (1024 + 13) * 4, 2 * 1024 * 13)
+    else:
+        plan[28] = ("pool_head", "pool_head_kernel", (6 * 1024 + 13) * 4, 2 * 1024 * 13)
     return plan
 
 
@@ -290,14 +296,14 @@ def main() -> None:
                        "timing": "value from K clean steps; per-kernel HIP-event times from a second identical K-step region"},
         }
         if events_on and launches.sum() > 0 and args.per_slot:
-            for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches).items()):
+            for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches, pool_fused=args.sep_variant is None).items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
                 log(f"slot {slot:2d} {nm:10s} {fam:24s} {us:8.1f} us  {nb * WINDOWS_PER_BATCH / us / 1e6:6.2f} TB/s  "
                     f"{fl * WINDOWS_PER_BATCH / us / 1e6:7.1f} TFLOP/s")
         if events_on and launches.sum() > 0:
             out["ms_per_step_with_kernel_events"] = round(1e3 * elapsed_events / args.steps, 4)
             fams = {}
-            for slot, (nm, fam, nb, fl) in slot_plan(launches).items():
+            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant is None).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                 f["ms"] += ms[slot]
                 f["launches"] += int(launches[slot])

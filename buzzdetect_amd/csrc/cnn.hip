@@ -760,6 +760,7 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // unfused kernels: results are bit-identical.
 // (ABL is a leftover template slot of the timing ablations used while tuning - no loads / no depthwise /
 //  no MFMA / one role idle / no store; their results are in DESIGN.md.  Always 0.)
+// NDW = 2: the tile is not written either; its windows are average-pooled and only [windows][N] goes to out2.
 // NDW = 1: the tile (whole windows) is not written; the NEXT layer's stride-2 depthwise (taps ndw_w, shift
 // ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS and only that result goes to out2.
 // BDIR = 1: the consumers do not stage the weights through LDS at all.  With the 1 x 4 consumer layout every
@@ -1313,7 +1314,22 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     }   // consumers
 
     __syncthreads();
-    if (NDW) {
+    if constexpr (NDW == 2) {
+        // ---- global average pool (yamnet.py:104): mean over the P positions of every whole window of the tile, summed
+        // in position order and divided by P exactly as pool_head_kernel does; out2 = [windows][N] ----
+        const float* Ct = reinterpret_cast<const float*>(smem_raw);
+        constexpr int C4 = BN / 4;
+        const int wins = BM / P;
+        for (int id = tid; id < wins * C4; id += 512) {
+            const int c4 = id % C4, wl = id / C4;
+            if (m0 + (long long)wl * P >= M) continue;
+            v4f s4 = *reinterpret_cast<const v4f*>(Ct + (wl * P) * (BN + 4) + c4 * 4);
+            for (int q = 1; q < P; ++q) s4 += *reinterpret_cast<const v4f*>(Ct + (wl * P + q) * (BN + 4) + c4 * 4);
+            const float fp = (float)P;
+            s4.x /= fp; s4.y /= fp; s4.z /= fp; s4.w /= fp;
+            *reinterpret_cast<v4f*>(out2 + (size_t)((unsigned)m0 / (unsigned)P + wl) * N + n0 + c4 * 4) = s4;
+        }
+    } else if (NDW) {
         // ---- next layer's depthwise (stride 2) on the tile: windows are whole, so every tap is in LDS ----
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
         constexpr int C4 = BN / 4;
@@ -1917,6 +1933,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
 }
 
 // --------------------------------------------------------------------------- pool + head
+template <int POOL>   // 6: act = [window][6][1024] is pooled here; 1: act = [window][1024] is already the pooled embedding
 __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ act,
                                                         const float* __restrict__ head_wt,
                                                         const float* __restrict__ head_b, int n_classes,
@@ -1927,29 +1944,44 @@ __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict_
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const size_t win = blockIdx.x;
-    const float4* src = reinterpret_cast<const float4*>(act + win * 6 * BD_EMBEDDING_SIZE);
+    const float4* src = reinterpret_cast<const float4*>(act + win * POOL * BD_EMBEDDING_SIZE);
     float4 s = src[tid];
+    if constexpr (POOL > 1) {
 #pragma unroll
-    for (int p = 1; p < 6; ++p) {
-        const float4 v = src[p * (BD_EMBEDDING_SIZE / 4) + tid];
-        s.x += v.x;
-        s.y += v.y;
-        s.z += v.z;
-        s.w += v.w;
+        for (int p = 1; p < POOL; ++p) {
+            const float4 v = src[p * (BD_EMBEDDING_SIZE / 4) + tid];
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        s.x /= (float)POOL;
+        s.y /= (float)POOL;
+        s.z /= (float)POOL;
+        s.w /= (float)POOL;
+        if (emb) reinterpret_cast<float4*>(emb + win * BD_EMBEDDING_SIZE)[tid] = s;
     }
-    s.x /= 6.0f;
-    s.y /= 6.0f;
-    s.z /= 6.0f;
-    s.w /= 6.0f;
-    if (emb) reinterpret_cast<float4*>(emb + win * BD_EMBEDDING_SIZE)[tid] = s;
     if (!logits) return;
 
-    for (int c = 0; c < n_classes; ++c) {
-        const float4 w = reinterpret_cast<const float4*>(head_wt + (size_t)c * BD_EMBEDDING_SIZE)[tid];
-        float p = fmaf(s.x, w.x, fmaf(s.y, w.y, fmaf(s.z, w.z, s.w * w.w)));
+    // classes in groups of 16: all weight rows of a group are in flight together and the 16 butterflies are
+    // independent (one class at a time was a chain of 13 dependent L2 round trips, 13 us for 4 MB of input)
+    for (int c0 = 0; c0 < n_classes; c0 += 16) {
+        float4 w[16];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-        if (lane == 0) s_part[wave][c] = p;
+        for (int j = 0; j < 16; ++j) {
+            const int c = c0 + j < n_classes ? c0 + j : n_classes - 1;
+            w[j] = reinterpret_cast<const float4*>(head_wt + (size_t)c * BD_EMBEDDING_SIZE)[tid];
+        }
+        float p[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) p[j] = fmaf(s.x, w[j].x, fmaf(s.y, w[j].y, fmaf(s.z, w[j].z, s.w * w[j].w)));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) p[j] += __shfl_xor(p[j], o, 64);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (lane == 0 && c0 + j < n_classes) s_part[wave][c0 + j] = p[j];
     }
     __syncthreads();
     if (tid < n_classes)
@@ -2165,8 +2197,28 @@ void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
                       int n_classes, float* emb, float* logits, hipStream_t stream) {
     if (windows <= 0) return;
-    hipLaunchKernelGGL(pool_head_kernel, dim3(windows), dim3(256), 0, stream, act, head_wt, head_b,
+    hipLaunchKernelGGL(pool_head_kernel<6>, dim3(windows), dim3(256), 0, stream, act, head_wt, head_b,
                        n_classes, emb, logits);
+}
+
+// Dense head on embeddings that are already pooled: pooled = [windows][1024].
+void launch_head(const float* pooled, int windows, const float* head_wt, const float* head_b, int n_classes,
+                 float* logits, hipStream_t stream) {
+    if (windows <= 0 || !logits) return;
+    hipLaunchKernelGGL(pool_head_kernel<1>, dim3(windows), dim3(256), 0, stream, pooled, head_wt, head_b,
+                       n_classes, static_cast<float*>(nullptr), logits);
+}
+
+// Last layer (3x2 map): fused depthwise+pointwise with the global average pool in the epilogue;
+// pooled = [windows][L.cout].
+bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream) {
+    const int P = L.h_out * L.w_out;
+    if (L.stride != 1 || windows <= 0 || P != 6 || L.w_out != 2 || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0)
+        return false;
+    const long long M = (long long)windows * P;
+    if (M >= (1LL << 31)) return false;
+    launch_sep_ws<256, 96, 0, 2, 96, 1, 1, 1, 1>(in, L, pooled, M, stream);
+    return true;
 }
 
 }  // namespace bd

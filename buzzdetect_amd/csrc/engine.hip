@@ -721,8 +721,24 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             last_floats = (int64_t)gw * 48 * 32 * 32;
             stopped = stop_stage == 0;
         }
+        bool pooled_done = false;    // the last layer's kernel already produced the pooled embeddings
         for (int l = first_layer; l < 13 && !stopped; ++l) {
             const bd::SepLayer& L = e->sep[l];
+            // last layer: the global average pool rides in the fused kernel's epilogue; only [windows][1024] is
+            // written (into the caller's embedding buffer if there is one, else into buf_b)
+            if (l == 12 && e->fuse_sep && e->fuse_next_dw && e->pointwise_mode == 1 && e->sep_variant <= 1 &&
+                stop_stage < 0 && skip_dw_layer != l) {
+                float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
+                if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream)) {
+                    if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                    if (logits) {
+                        Scope sc(e, stream, 28);
+                        bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
+                    }
+                    pooled_done = true;
+                    break;
+                }
+            }
             // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
             // ... and when the NEXT layer is a stride-2 one, its depthwise is applied in that kernel's epilogue
             // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
@@ -769,7 +785,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             BD_HIP(hipMemcpyAsync(tap_out, last, last_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
             break;
         }
-        {
+        if (!pooled_done) {
             Scope sc(e, stream, 28);
             bd::launch_pool_head(buf_a, gw, e->head_wt, e->head_b, e->n_classes,
                                  emb ? emb + w0 * BD_EMBEDDING_SIZE : nullptr,

@@ -342,8 +342,10 @@ def test_pointwise_on_wave_specialised_kernel_bit_identical_to_gemm_kernel(engin
         for st, ref in plain.items():
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy(), ref), st
         assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
-        engine.set_fusion(True, True)            # default path: layers 5, 7, 13 use it after a depthwise
-        assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
+        plain_emb = engine.embed(x, 0.96).numpy()
+        engine.set_fusion(True, True)            # default path: layers 5, 7, 13 use it after a depthwise, and the
+        assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)    # last layer pools in its epilogue
+        assert np.array_equal(engine.embed(x, 0.96).numpy(), plain_emb)
     finally:
         for layer in range(5, 15):
             engine.set_pointwise_variant(layer, 0)
