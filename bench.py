@@ -177,6 +177,7 @@ def main() -> None:
                     help="analyzer streams per GPU: steps are dealt round-robin to this many engines, each on "
                          "its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253)")
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable-layer kernel variant (tuning)")
+    ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
     ap.add_argument("--frontend-variant", type=int, default=None, help="front-end FFT formulation (tuning)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     args = ap.parse_args()
@@ -211,6 +212,9 @@ def main() -> None:
             e.set_group_windows(args.group_windows)
         if args.sep_variant is not None:
             e.set_fusion(True, args.sep_variant)
+        if args.pw_variant is not None:
+            for layer in range(5, 15):
+                e.set_pointwise_variant(layer, args.pw_variant)
         if args.frontend_variant is not None:
             e.set_frontend_variant(args.frontend_variant)
     framehop_s = FRAMELENGTH_S * HOP_PROP

@@ -1378,6 +1378,8 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
         }
     }
     if constexpr (ABL == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's stores have left the wave
+        BD_PROBE2(9)
         __syncthreads();
         if (blockIdx.x == 0 && tid < 256) reinterpret_cast<unsigned*>(out2)[tid] = ts[tid];
         if (tid == 0 && blockIdx.x < 1024) {       // wall clock (100 MHz) at block start / end
@@ -1456,6 +1458,8 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
             }
             fprintf(stderr, "[trace] producer prologue (cycles since entry): tables %u, DMA issued %u, taps written %u, barrier passed %u, first depthwise done %u; consumer entry offset %d\n",
                     h[201] - h[200], h[202] - h[200], h[203] - h[200], h[204] - h[200], h[205] - h[200], (int)(h[208] - h[200]));
+            fprintf(stderr, "[trace] consumer wave: entry -> end of its stores %u cycles (block 0 wall clock %u x 10 ns => %.2f GHz)\n",
+                    h[209] - h[208], h[257] - h[256], (h[209] - h[208]) / (10.0 * (h[257] - h[256])));
             fprintf(stderr, "[trace] producer stage 6: store %u, load-issue %u, depthwise %u\n", h[193] - h[192], h[194] - h[193], h[195] - h[194]);
         }
         return;
@@ -1465,6 +1469,357 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
                        static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
                        next ? next->dw_b : nullptr, out);
+}
+
+// --------------------------------------------------------------------------- persistent wave-specialised kernel
+// sep_ws_kernel (weights as register fragments, vertical tap sharing, slab ring by LDS-DMA, counted waits) as a
+// PERSISTENT workgroup: one workgroup per CU slot walks tiles b, b + G, b + 2 G ...  A tile of the one-shot kernel
+// spends ~18 % of its life in the prologue (kernel entry, tap loads, first slab round trip, first depthwise) and
+// ~8 % in the epilogue while the rest of the CU idles; for the 4-stage tiles of layer 4 that is half of the time.
+// Here the producer pipeline never stops at a tile boundary: during the last three stages of a tile it requests
+// the first three slabs of the next one, and during the last stage it computes the next tile's first A block.
+// The depthwise taps are loaded once per workgroup.  The output tile goes to HBM through a separate 32-row f32
+// chunk in LDS (three passes for 96 rows), so the epilogue no longer overwrites the pipeline buffers.
+// Covers the plain instantiations (no next-layer depthwise / pooling in the epilogue); arithmetic order is that of
+// sep_ws_kernel, results are bit-identical.  PWO = 1: pointwise only (producers split the slab rows to f16 hi + lo).
+template <int BN, int XPMAX, int BM, int PWO>
+__global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_kernel(
+    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
+    float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n, int tiles) {
+    static_assert((BM == 96 || BM == 64) && XPMAX % 32 == 0, "tile shape");
+    constexpr bool BAND = BM == 64;           // tile = band of rows inside one window (+ halo rows); else whole windows
+    constexpr int WN = BN / 4, TM = BM / 32, TN = WN / 32, LA = BM / 32;
+    constexpr int XS_FLOATS = (XPMAX + 1) * 32;
+    constexpr int A_BYTES = BM * 64;
+    constexpr int NG = XPMAX / 8, GPW = NG / 4, ND = GPW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* const Xs = reinterpret_cast<float*>(smem_raw);              // [3][XS_FLOATS] slab ring (+ a zero row each)
+    char* const Ah = reinterpret_cast<char*>(Xs + 3 * XS_FLOATS);      // [2][A_BYTES]
+    char* const Al = Ah + 2 * A_BYTES;
+    float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K] depthwise taps + shift (not PWO)
+    float* const Cc = Wall + (PWO ? 0 : 10 * K);                       // [32][BN + 4] output chunk
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = K / 32;                    // even, >= 4 (launcher)
+    const int P = H * W;
+    const int G = gridDim.x;
+    const int t_first = blockIdx.x;           // < tiles (launcher)
+
+    if (wave >= 4) {
+        // ================================================================= producers
+        const int pt = tid - 256;
+        const int lrow = pt >> 3, lc4 = pt & 7;
+        const int pw = wave - 4;
+        // tile-independent part of the position map: slot -> (window in tile, row group, column)
+        const int lw = 31 - __builtin_clz(W);
+        int wl = 0, g = lrow;
+        if (P < BM) {
+            const int lg = 31 - __builtin_clz(P / LA);
+            wl = lrow >> lg;
+            g = lrow & ((1 << lg) - 1);
+        }
+        const int og = g >> lw, ow = g & (W - 1);
+        const int ml0 = wl * P + LA * og * W + ow;
+        int a_st[LA];
+#pragma unroll
+        for (int i = 0; i < LA; ++i) a_st[i] = swz64(PWO ? lrow + 32 * i : ml0 + i * W, lc4 >> 1) + (lc4 & 1) * 8;
+        // tap table of a tile whose first row is row oh_a of its window (0 for whole-window tiles)
+        int xt_a[(LA + 2) * 3];
+#define BP_MAKE_XT(XT, OH_A)                                                                              \
+    {                                                                                                     \
+        const int oh0_ = (OH_A) + LA * og;                                                                \
+        const int xc0_ = ml0 + (BAND && (OH_A) > 0 ? W : 0);                                              \
+        _Pragma("unroll") for (int r = 0; r < LA + 2; ++r) _Pragma("unroll") for (int c = 0; c < 3; ++c) { \
+            const int ih = oh0_ - 1 + r, iw = ow - 1 + c;                                                 \
+            const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;                                       \
+            XT[r * 3 + c] = (ok ? xc0_ + (r - 1) * W + (c - 1) : XPMAX) * 32 + lc4 * 4;                   \
+        }                                                                                                 \
+    }
+        const float* xs_a[GPW];
+        // slab source pointers of tile T (rows past the slab's end re-read its last row; never used)
+#define BP_GEOM(T, XSRC, OH_A)                                                                            \
+    {                                                                                                     \
+        const unsigned m0_ = (unsigned)((T) / tiles_n) * BM;                                              \
+        long long x_lo_;                                                                                  \
+        int x_cnt_;                                                                                       \
+        if (PWO || !BAND) {                                                                               \
+            x_lo_ = m0_;                                                                                  \
+            x_cnt_ = (int)((M - m0_) < BM ? (M - m0_) : BM);                                              \
+            OH_A = 0;                                                                                     \
+        } else {                                                                                          \
+            const unsigned n_ = m0_ / (unsigned)P;                                                        \
+            OH_A = (int)(m0_ % (unsigned)P) / W;                                                          \
+            const int oh_b_ = OH_A + BM / W;                                                              \
+            const int r0_ = OH_A > 0 ? OH_A - 1 : 0;                                                      \
+            const int r1_ = oh_b_ < H ? oh_b_ + 1 : H;                                                    \
+            x_lo_ = ((long long)n_ * H + r0_) * W;                                                        \
+            x_cnt_ = (r1_ - r0_) * W;                                                                     \
+        }                                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < GPW; ++q) {                                                 \
+            int row = 8 * (GPW * pw + q) + (lane >> 3);                                                   \
+            row = row < x_cnt_ ? row : x_cnt_ - 1;                                                        \
+            XSRC[q] = X + (size_t)(x_lo_ + row) * K + (lane & 7) * 4 - 256 * q;                           \
+        }                                                                                                 \
+    }
+#define BP_DMA1(Q, XSRC, KOFF, XB)                                                                        \
+    if constexpr ((Q) < GPW)                                                                              \
+        __builtin_amdgcn_global_load_lds(                                                                 \
+            (const __attribute__((address_space(1))) void*)(XSRC[(Q) < GPW ? (Q) : 0] + (KOFF)),          \
+            (__attribute__((address_space(3))) void*)(Xs + (XB) * XS_FLOATS + GPW * pw * 256), 16, 1024 * (Q), 0);
+#define BP_DMA(XSRC, KOFF, XB) { BP_DMA1(0, XSRC, KOFF, XB) BP_DMA1(1, XSRC, KOFF, XB) BP_DMA1(2, XSRC, KOFF, XB) BP_DMA1(3, XSRC, KOFF, XB) }
+#define BP_SYNC(KEEP)                                                                                     \
+    {                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        asm volatile("" ::: "memory");                                                                    \
+    }
+        // depthwise (or plain split) of ring slot XB, channels KCH .. KCH + 31, into A block AB
+#define BP_WORK(XB, AB, XT, KCH)                                                                          \
+    if constexpr (PWO) {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
+            const v4f a4 = *reinterpret_cast<const v4f*>(Xs + (XB) * XS_FLOATS + (lrow + 32 * i) * 32 + lc4 * 4); \
+            f16x4 hi, lo;                                                                                 \
+            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
+            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
+            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
+            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
+            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
+        }                                                                                                 \
+    } else {                                                                                              \
+        const float* xs_ = Xs + (XB) * XS_FLOATS;                                                         \
+        const float* ws_ = Wall + (KCH) + lc4 * 4;                                                        \
+        v4f wt[9];                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * K); \
+        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * K);                                     \
+        v4f xv[(LA + 2) * 3];                                                                             \
+        _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t) xv[t] = *reinterpret_cast<const v4f*>(xs_ + XT[t]); \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
+            v4f a4 = bias4;                                                                               \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) a4 = __builtin_elementwise_fma(xv[i * 3 + t], wt[t], a4); \
+            a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
+            f16x4 hi, lo;                                                                                 \
+            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
+            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
+            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
+            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
+            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
+        }                                                                                                 \
+    }
+        // output rows of chunk I of tile (M0T, N0T): all 8 waves, 16 bytes per lane
+#define BP_STORE_CHUNK(I, M0T, N0T)                                                                       \
+    {                                                                                                     \
+        constexpr int C4_ = BN / 4;                                                                       \
+        _Pragma("unroll") for (int it = 0; it < 32 * C4_ / 512; ++it) {                                   \
+            const int id = tid + 512 * it;                                                                \
+            const int ml = id / C4_, c4_ = id % C4_;                                                      \
+            const long long m = (long long)(M0T) + 32 * (I) + ml;                                         \
+            if (m < M)                                                                                    \
+                *reinterpret_cast<v4f*>(Cout + (size_t)m * N + (N0T) + c4_ * 4) =                         \
+                    *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);                          \
+        }                                                                                                 \
+    }
+        if (pt < 24) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+        int oh_a = 0;
+        BP_GEOM(t_first, xs_a, oh_a)
+        BP_DMA(xs_a, 0, 0)
+        BP_DMA(xs_a, 32, 1)
+        BP_DMA(xs_a, 64, 2)
+        if constexpr (!PWO) {
+            constexpr int TI = 10;
+            const int n_w = 9 * (K / 4), n_all = 10 * (K / 4);
+            v4f tw_[TI];
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                const int i = pt + 256 * j;
+                if (i < n_all) tw_[j] = *reinterpret_cast<const v4f*>(i < n_w ? dw_w + 4 * (size_t)i : dw_b + 4 * (size_t)(i - n_w));
+            }
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                const int i = pt + 256 * j;
+                if (i < n_all) *reinterpret_cast<v4f*>(Wall + 4 * (size_t)i) = tw_[j];
+            }
+            BP_MAKE_XT(xt_a, oh_a)
+        }
+        BP_SYNC(2 * ND)                       // slab 0 has landed, the taps are written
+        BP_WORK(0, 0, xt_a, 0)
+        BP_SYNC(ND)                           // A[0] written; slab 1 has landed
+        int rs = 1;                           // ring slot of the slab that the next stage's depthwise reads
+        for (int t = t_first; t < tiles; t += G) {
+            const bool has_next = t + G < tiles;
+            for (int k = 0; k < nk; ++k) {
+                // from stage nk-3 on every request is for the next tile: its geometry replaces this tile's
+                if (k == nk - 3 && has_next) BP_GEOM(t + G, xs_a, oh_a)
+                const int r3 = rs == 0 ? 2 : rs - 1;          // slot of the slab consumed during the previous stage
+                const bool issued = k + 3 < nk || has_next;
+                if (issued) BP_DMA(xs_a, (k + 3 < nk ? k + 3 : k + 3 - nk) * 32, r3)
+                if (k + 1 < nk) {
+                    BP_WORK(rs, (k + 1) & 1, xt_a, (k + 1) * 32)
+                } else if (has_next) {        // the next tile's first A block, during this tile's last MFMA stage
+                    if constexpr (!PWO && BAND) BP_MAKE_XT(xt_a, oh_a)
+                    BP_WORK(rs, 0, xt_a, 0)
+                }
+                if (issued) BP_SYNC(ND) else BP_SYNC(0)
+                rs = rs == 2 ? 0 : rs + 1;
+            }
+            // ---- epilogue: the consumers fill the chunk, everybody stores it ----
+            const unsigned m0t = (unsigned)(t / tiles_n) * BM;
+            const int n0t = (t % tiles_n) * BN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                __syncthreads();
+                BP_STORE_CHUNK(i, m0t, n0t)
+                __syncthreads();
+            }
+        }
+    } else {
+        // ================================================================= consumers
+        const int wc = wave;
+        const int frow = lane & 31, fh = lane >> 5;
+        f16x8 b0h[TN][2], b0l[TN][2], b1h[TN][2], b1l[TN][2];
+        const _Float16* wph[TN];
+        const _Float16* wpl[TN];
+#define BP_WPTR(N0T)                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                      \
+        const size_t frag = ((size_t)(((N0T) + wc * WN) / 32 + j) * (K / 16) * 64 + lane) * 8;            \
+        wph[j] = Wfhi + frag;                                                                             \
+        wpl[j] = Wflo + frag;                                                                             \
+    }
+#define BP_W_LOAD(BH, BL, KOFF)                                                                           \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s) {    \
+            BH[j][s] = *reinterpret_cast<const f16x8*>(wph[j] + (KOFF) * 32 + 512 * s);                   \
+            BL[j][s] = *reinterpret_cast<const f16x8*>(wpl[j] + (KOFF) * 32 + 512 * s);                   \
+        }                                                                                                 \
+    }
+#define BP_W_MFMA(BUF, BH, BL)                                                                            \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
+            f16x8 ah[TM], al[TM];                                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
+                const int off = (BUF) * A_BYTES + swz64(i * 32 + frow, 2 * s + fh);                       \
+                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
+                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
+            }                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], BH[j][s], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BL[j][s], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BH[j][s], acc[i][j], 0, 0, 0);  \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+        BP_WPTR((t_first % tiles_n) * BN)
+        BP_W_LOAD(b0h, b0l, 0)
+        BP_W_LOAD(b1h, b1l, 32)
+        __syncthreads();
+        __syncthreads();
+        for (int t = t_first; t < tiles; t += G) {
+            const unsigned m0t = (unsigned)(t / tiles_n) * BM;
+            const int n0t = (t % tiles_n) * BN;
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            int k = 0;
+            for (; k + 2 < nk; k += 2) {
+                BP_W_MFMA(0, b0h, b0l)
+                BP_W_LOAD(b0h, b0l, (k + 2) * 32)
+                __syncthreads();
+                BP_W_MFMA(1, b1h, b1l)
+                BP_W_LOAD(b1h, b1l, (k + 3) * 32)
+                __syncthreads();
+            }
+            BP_W_MFMA(0, b0h, b0l)
+            __syncthreads();
+            BP_W_MFMA(1, b1h, b1l)
+            if (t + G < tiles) {              // the next tile's first two fragment sets, in flight during the epilogue
+                BP_WPTR(((t + G) % tiles_n) * BN)
+                BP_W_LOAD(b0h, b0l, 0)
+                BP_W_LOAD(b1h, b1l, 32)
+            }
+            __syncthreads();
+            // ---- epilogue: bias + ReLU, 32 rows at a time through the chunk ----
+            float bias_[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bias_[j] = pw_b[n0t + wc * WN + j * 32 + frow];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = wc * WN + j * 32 + frow;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = 4 * fh + (r & 3) + 8 * (r >> 2);
+                        Cc[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + bias_[j], 0.0f);
+                    }
+                }
+                __syncthreads();
+                BP_STORE_CHUNK(i, m0t, n0t)
+                __syncthreads();
+            }
+        }
+    }
+#undef BP_MAKE_XT
+#undef BP_GEOM
+#undef BP_DMA1
+#undef BP_DMA
+#undef BP_SYNC
+#undef BP_WORK
+#undef BP_STORE_CHUNK
+#undef BP_WPTR
+#undef BP_W_LOAD
+#undef BP_W_MFMA
+}
+
+// compute units of the current device (cached per device)
+static int device_cus() {
+    static int cus_dev[64] = {0};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    int& c = cus_dev[dev_ & 63];
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        (void)hipGetDeviceProperties(&prop, dev_);
+        c = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return c;
+}
+
+// Should a launch with this many tiles use the persistent kernel?  Measured on one box (1024-window batches):
+// one analyzer stream 1.181 M windows/s persistent vs 1.155 M one-shot, but with two streams (the default way to
+// run, bench.py and the reference's analyzers_gpu) 1.25 M vs 1.27 M - a persistent workgroup holds 136 KB of LDS
+// per CU for the whole launch, so the other stream's workgroups cannot slip into the gaps, which are exactly what
+// it removes on its own.  So: off unless asked for (BD_PERSISTENT=1, or explicit kernel variant 11).
+static bool persistent_pays(long long tiles) {
+    static const bool on = getenv("BD_PERSISTENT") != nullptr;
+    return on && tiles > device_cus();
+}
+
+template <int BN, int XPMAX, int BM, int PWO>
+void launch_sep_wsp(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
+    const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * BM * 64 + (PWO ? 0 : (size_t)40 * L.cin) + 32u * (BN + 4) * 4;
+    constexpr size_t lds_max = 3u * (XPMAX + 1) * 128 + 4u * BM * 64 + (PWO ? 0u : 40u * 1024u) + 32u * (BN + 4) * 4;
+    static bool attr_set_dev[64] = {false};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set_dev[dev_ & 63]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_wsp_kernel<BN, XPMAX, BM, PWO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        attr_set_dev[dev_ & 63] = true;
+    }
+    const int tiles_n = L.cout / BN;
+    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    const long long slots = (long long)device_cus() * ((BM == 64 && BN == 128) ? 2 : 1);
+    const int grid = (int)(tiles < slots ? tiles : slots);
+    hipLaunchKernelGGL((sep_wsp_kernel<BN, XPMAX, BM, PWO>), dim3((unsigned)grid), dim3(512), lds, stream, X, L.dw_w, L.dw_b,
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
+                       L.cout, L.cin, L.h_out, L.w_out, tiles_n, (int)tiles);
 }
 
 // --------------------------------------------------------------------------- fused stem
@@ -2092,12 +2447,14 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
     if (rows <= 0 || rows >= (1LL << 31) || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0) return false;
     // (96 x 128 tiles with two workgroups per CU measured the same: 33.1 vs 32.6 us on layer 7)
-    launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
+    const bool persistent = L.pw_variant16 == 11 || (L.pw_variant16 == 0 && persistent_pays(((rows + 95) / 96) * (L.cout / 256)));
+    if (persistent) launch_sep_wsp<256, 96, 96, 1>(in, L, out, rows, stream);
+    else launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
     return true;
 }
 
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
-    if (L.pw_mode == 1 && (L.pw_variant16 == 0 || L.pw_variant16 == 10) && launch_pointwise_ws(in, out, rows, L, stream)) return;
+    if (L.pw_mode == 1 && (L.pw_variant16 == 0 || L.pw_variant16 >= 10) && launch_pointwise_ws(in, out, rows, L, stream)) return;
     if (L.pw_mode == 1)
         launch_pointwise_f16x3_variant(in, L.pw_whi, L.pw_wlo, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant16,
                                        stream);
@@ -2133,18 +2490,23 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     // (variant 9 = weights as register fragments, producers sharing taps vertically, input slab by LDS-DMA into
     //  a ring of three; 7 = the same with register-staged slabs; 8 = 7 with 64-channel stages; 3 / 5 = the same
     //  tiles with LDS-staged weights and one output per tap set - all kept as tested alternatives)
-    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;
+    // (11 = variant 9 as a persistent workgroup: -5..-15 % per launch when a workgroup gets more than one tile,
+    //  neutral at one tile per CU; the 64-row layer-4 form spills under its 128-VGPR cap; see persistent_pays)
+    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0)
+        variant = persistent_pays(((M + 95) / 96) * (L.cout / 256)) ? 11 : 9;
     if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;   // layer 4
     if (variant >= 3 && L.cin >= 128 && ws_shape) {                // wave-specialised kernels (BM = 96)
         if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
-            if (variant == 9) launch_sep_ws<128, 96, 0, 0, 64, 1, 1, 1, 1>(in, L, out, M, stream);
+            if (variant == 11) launch_sep_wsp<128, 96, 64, 0>(in, L, out, M, stream);
+            else if (variant == 9) launch_sep_ws<128, 96, 0, 0, 64, 1, 1, 1, 1>(in, L, out, M, stream);
             else if (variant >= 7) launch_sep_ws<128, 96, 0, 0, 64, 1, 1>(in, L, out, M, stream);
             else if (variant == 5) launch_sep_ws<128, 96, 0, 0, 64>(in, L, out, M, stream);
             else launch_sep_ws<128, 128>(in, L, out, M, stream);
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
-            if (variant == 9 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
+            if (variant == 11 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_wsp<256, 96, 96, 0>(in, L, out, M, stream);
+            else if (variant == 9 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
             else if (variant == 8 && L.cout % 256 == 0 && L.cin % 256 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 2>(in, L, out, M, stream);
             else if (variant >= 7 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1>(in, L, out, M, stream);
             else if (variant == 6 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1>(in, L, out, M, stream);

@@ -311,7 +311,7 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+        for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11):
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
@@ -337,11 +337,14 @@ def test_pointwise_on_wave_specialised_kernel_bit_identical_to_gemm_kernel(engin
             engine.set_pointwise_variant(layer, 1)
         plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in stages}
         plain_logits = engine.predict(x, 0.96).numpy()
+        for variant in (0, 10, 11):              # auto, one-shot and persistent wave-specialised kernel
+            for layer in range(5, 15):
+                engine.set_pointwise_variant(layer, variant)
+            for st, ref in plain.items():
+                assert np.array_equal(engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy(), ref), (variant, st)
+            assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits), variant
         for layer in range(5, 15):
             engine.set_pointwise_variant(layer, 0)
-        for st, ref in plain.items():
-            assert np.array_equal(engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy(), ref), st
-        assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
         plain_emb = engine.embed(x, 0.96).numpy()
         engine.set_fusion(True, True)            # default path: layers 5, 7, 13 use it after a depthwise, and the
         assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)    # last layer pools in its epilogue
