@@ -747,6 +747,23 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
                        L.pw_b, out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n);
 }
 
+// Workgroup (or persistent tile index) -> (row tile, column tile).  Workgroups go to the 8 XCDs round-robin by ID
+// (measured: FETCH_SIZE of a K = N = 512 layer is 53.5 MiB per launch when its two column tiles are IDs b, b+1 /
+// b+2 / b+4 apart and 32.6 MiB when they are 8, 16, 32 or 64 apart), each XCD has its own L2, and the column tiles
+// of one row tile read the same input slab.  IDs b and b + 8 - same XCD, dispatched together - are therefore made
+// the column tiles of one row tile, so the second read of the slab is an L2 hit instead of an HBM fetch.
+__device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned tn, unsigned& tile_m, unsigned& tile_n) {
+    const unsigned full = tiles_m & ~7u;                         // row tiles covered by whole groups of 8
+    if (tn > 1 && b < full * tn) {
+        tile_n = (b >> 3) % tn;
+        tile_m = (b / (8 * tn)) * 8 + (b & 7);
+    } else {
+        const unsigned r = tn > 1 ? b - full * tn : b;
+        tile_m = (tn > 1 ? full : 0) + r / tn;
+        tile_n = r % tn;
+    }
+}
+
 // --------------------------------------------------------------------------- fused separable layer, wave-specialised
 // Same computation as sep_s1_kernel, restructured for the CU: a workgroup is 8 waves; waves 4-7 are
 // PRODUCERS (stage the f32 input slab, run the depthwise on the VALU, write the split-f16 A tile of
@@ -799,10 +816,10 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long tile_m = blockIdx.x / tiles_n;
-    const int tile_n = blockIdx.x % tiles_n;
-    const long long m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
+    unsigned tile_m, tile_n;
+    tile_of(blockIdx.x, (unsigned)((M + BM - 1) / BM), (unsigned)tiles_n, tile_m, tile_n);
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = (int)tile_n * BN;
     const int nk = K / (32 * KS);             // stages; >= 4 (launcher)
 
     constexpr size_t TS_PIPE = (size_t)NX * (XPMAX + 1) * 128 + (size_t)NX * WS_FLOATS * 4 + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
@@ -1507,6 +1524,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
     const int P = H * W;
     const int G = gridDim.x;
     const int t_first = blockIdx.x;           // < tiles (launcher)
+    const unsigned tiles_m = (unsigned)((M + BM - 1) / BM);
 
     if (wave >= 4) {
         // ================================================================= producers
@@ -1542,7 +1560,9 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
         // slab source pointers of tile T (rows past the slab's end re-read its last row; never used)
 #define BP_GEOM(T, XSRC, OH_A)                                                                            \
     {                                                                                                     \
-        const unsigned m0_ = (unsigned)((T) / tiles_n) * BM;                                              \
+        unsigned tm_, tn_;                                                                                \
+        tile_of((unsigned)(T), tiles_m, (unsigned)tiles_n, tm_, tn_);                                     \
+        const unsigned m0_ = tm_ * BM;                                                                    \
         long long x_lo_;                                                                                  \
         int x_cnt_;                                                                                       \
         if (PWO || !BAND) {                                                                               \
@@ -1666,8 +1686,10 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
                 rs = rs == 2 ? 0 : rs + 1;
             }
             // ---- epilogue: the consumers fill the chunk, everybody stores it ----
-            const unsigned m0t = (unsigned)(t / tiles_n) * BM;
-            const int n0t = (t % tiles_n) * BN;
+            unsigned tm_t, tn_t;
+            tile_of((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
+            const unsigned m0t = tm_t * BM;
+            const int n0t = (int)tn_t * BN;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 __syncthreads();
@@ -1711,14 +1733,20 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
             }                                                                                             \
         }                                                                                                 \
     }
-        BP_WPTR((t_first % tiles_n) * BN)
+        {
+            unsigned tm0_, tn0_;
+            tile_of((unsigned)t_first, tiles_m, (unsigned)tiles_n, tm0_, tn0_);
+            BP_WPTR((int)tn0_ * BN)
+        }
         BP_W_LOAD(b0h, b0l, 0)
         BP_W_LOAD(b1h, b1l, 32)
         __syncthreads();
         __syncthreads();
         for (int t = t_first; t < tiles; t += G) {
-            const unsigned m0t = (unsigned)(t / tiles_n) * BM;
-            const int n0t = (t % tiles_n) * BN;
+            unsigned tm_t, tn_t;
+            tile_of((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
+            const unsigned m0t = tm_t * BM;
+            const int n0t = (int)tn_t * BN;
             f32x16 acc[TM][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1739,7 +1767,9 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
             __syncthreads();
             BP_W_MFMA(1, b1h, b1l)
             if (t + G < tiles) {              // the next tile's first two fragment sets, in flight during the epilogue
-                BP_WPTR(((t + G) % tiles_n) * BN)
+                unsigned tmn_, tnn_;
+                tile_of((unsigned)(t + G), tiles_m, (unsigned)tiles_n, tmn_, tnn_);
+                BP_WPTR((int)tnn_ * BN)
                 BP_W_LOAD(b0h, b0l, 0)
                 BP_W_LOAD(b1h, b1l, 32)
             }
