@@ -752,7 +752,17 @@ void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipS
 // b+2 / b+4 apart and 32.6 MiB when they are 8, 16, 32 or 64 apart), each XCD has its own L2, and the column tiles
 // of one row tile read the same input slab.  IDs b and b + 8 - same XCD, dispatched together - are therefore made
 // the column tiles of one row tile, so the second read of the slab is an L2 hit instead of an HBM fetch.
+// BAND (row tiles are bands of one window that overlap their neighbours by halo rows, a single column tile): every
+// XCD takes a contiguous run of row tiles instead, so IDs b and b + 8 are ADJACENT bands and the halo rows they
+// both read are fetched once.
+template <bool BAND>
 __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned tn, unsigned& tile_m, unsigned& tile_n) {
+    if (BAND && tn == 1) {
+        const unsigned per = tiles_m >> 3;
+        tile_n = 0;
+        tile_m = b < per * 8 ? (b & 7) * per + (b >> 3) : b;
+        return;
+    }
     const unsigned full = tiles_m & ~7u;                         // row tiles covered by whole groups of 8
     if (tn > 1 && b < full * tn) {
         tile_n = (b >> 3) % tn;
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned tile_m, tile_n;
-    tile_of(blockIdx.x, (unsigned)((M + BM - 1) / BM), (unsigned)tiles_n, tile_m, tile_n);
+    tile_of<(BM == 64)>(blockIdx.x, (unsigned)((M + BM - 1) / BM), (unsigned)tiles_n, tile_m, tile_n);
     const long long m0 = (long long)tile_m * BM;
     const int n0 = (int)tile_n * BN;
     const int nk = K / (32 * KS);             // stages; >= 4 (launcher)
@@ -1561,7 +1571,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
 #define BP_GEOM(T, XSRC, OH_A)                                                                            \
     {                                                                                                     \
         unsigned tm_, tn_;                                                                                \
-        tile_of((unsigned)(T), tiles_m, (unsigned)tiles_n, tm_, tn_);                                     \
+        tile_of<BAND>((unsigned)(T), tiles_m, (unsigned)tiles_n, tm_, tn_);                                     \
         const unsigned m0_ = tm_ * BM;                                                                    \
         long long x_lo_;                                                                                  \
         int x_cnt_;                                                                                       \
@@ -1687,7 +1697,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
             }
             // ---- epilogue: the consumers fill the chunk, everybody stores it ----
             unsigned tm_t, tn_t;
-            tile_of((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
+            tile_of<(BM == 64)>((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
             const unsigned m0t = tm_t * BM;
             const int n0t = (int)tn_t * BN;
 #pragma unroll
@@ -1735,7 +1745,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
     }
         {
             unsigned tm0_, tn0_;
-            tile_of((unsigned)t_first, tiles_m, (unsigned)tiles_n, tm0_, tn0_);
+            tile_of<(BM == 64)>((unsigned)t_first, tiles_m, (unsigned)tiles_n, tm0_, tn0_);
             BP_WPTR((int)tn0_ * BN)
         }
         BP_W_LOAD(b0h, b0l, 0)
@@ -1744,7 +1754,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
         __syncthreads();
         for (int t = t_first; t < tiles; t += G) {
             unsigned tm_t, tn_t;
-            tile_of((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
+            tile_of<(BM == 64)>((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
             const unsigned m0t = tm_t * BM;
             const int n0t = (int)tn_t * BN;
             f32x16 acc[TM][TN];
@@ -1768,7 +1778,7 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_
             BP_W_MFMA(1, b1h, b1l)
             if (t + G < tiles) {              // the next tile's first two fragment sets, in flight during the epilogue
                 unsigned tmn_, tnn_;
-                tile_of((unsigned)(t + G), tiles_m, (unsigned)tiles_n, tmn_, tnn_);
+                tile_of<(BM == 64)>((unsigned)(t + G), tiles_m, (unsigned)tiles_n, tmn_, tnn_);
                 BP_WPTR((int)tnn_ * BN)
                 BP_W_LOAD(b0h, b0l, 0)
                 BP_W_LOAD(b1h, b1l, 32)
