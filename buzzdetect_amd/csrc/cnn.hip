@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
     const int c4n = C >> 2;
     const int owg = OW / OWB;
     const long long total = (long long)windows * OH * owg * c4n;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    // workgroups go to the XCDs round-robin by ID: give every XCD a contiguous run of the index space, so that
+    // IDs b and b + 8 (same L2, dispatched together) are neighbours and the input rows they share are fetched once
+    const unsigned per_ = gridDim.x >> 3;
+    const unsigned bid = blockIdx.x < per_ * 8 ? (blockIdx.x & 7) * per_ + (blockIdx.x >> 3) : blockIdx.x;
+    for (long long i = bid * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
         const int c4 = (int)(i % c4n);
         long long t = i / c4n;
         const int og = (int)(t % owg);
