@@ -336,11 +336,11 @@ def main() -> None:
                                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}
             try:      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
-                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_1p2M.json")) as f:
+                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_1p3M.json")) as f:
                     pmc = json.load(f)["per_kernel_family"].get(dom)
                 if pmc:
                     out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic_1p2M.json ((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch)"
+                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic_1p3M.json ((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch)"
             except (OSError, ValueError, KeyError):
                 pass
             out["roofline"].update({"avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
