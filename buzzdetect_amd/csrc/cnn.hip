@@ -2072,7 +2072,9 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                                                     const float* __restrict__ pw_b, const float* __restrict__ dw3_w,
                                                     const float* __restrict__ dw3_b, float* __restrict__ out,
                                                     const _Float16* __restrict__ W3fhi, const _Float16* __restrict__ W3flo,
-                                                    const float* __restrict__ pw3_b) {
+                                                    const float* __restrict__ pw3_b, unsigned* __restrict__ dbg) {
+#define ST_TS(I) if (dbg && blockIdx.x == 5 && blockIdx.y == 7 && threadIdx.x == 0) dbg[I] = (unsigned)__builtin_readcyclecounter();
+    ST_TS(0)
     constexpr int R2 = 5;                       // layer-2 rows in the tile
     constexpr int C1R = R2 + 2;                 // conv1 rows incl. halo: 7
     constexpr int LMR = 2 * C1R + 1;            // log-mel rows: 15
@@ -2126,6 +2128,14 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
 
+    // every phase's weights are requested one phase ahead (a phase used to begin with a global round trip)
+    const int c4 = tid & 7;
+    const int col = tid >> 3;
+    v4f c1wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) c1wt[t] = *reinterpret_cast<const v4f*>(c1_w + t * 32 + c4 * 4);
+    const v4f c1bias = *reinterpret_cast<const v4f*>(c1_b + c4 * 4);
+    ST_TS(1)
     // ---- A: log-mel rows 2 (r0 - 1) .. +14, zero halo columns of the conv1 band ----
     for (int i = tid; i < LMR * 17; i += 256) {
         const int j = i / 17, q = i % 17;
@@ -2139,17 +2149,18 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    ST_TS(2)
 
     // ---- B: conv1 rows r0 - 1 .. r0 + 5 ----
     // (consecutive conv1 rows share a log-mel row: a rolling window reads 45 values instead of 63; the four
     //  channels of a tap are two packed fmas)
-    const int c4 = tid & 7;
-    const int col = tid >> 3;
-    {
-        v4f wt[9];
+    v4f d2wt[9];                                // depthwise-2 taps: in flight during the conv1 phase
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(c1_w + t * 32 + c4 * 4);
-        const v4f bias = *reinterpret_cast<const v4f*>(c1_b + c4 * 4);
+    for (int t = 0; t < 9; ++t) d2wt[t] = *reinterpret_cast<const v4f*>(dw2_w + t * 32 + c4 * 4);
+    const v4f d2bias = *reinterpret_cast<const v4f*>(dw2_b + c4 * 4);
+    {
+        const v4f (&wt)[9] = c1wt;
+        const v4f bias = c1bias;
         // a tap row past the patch (log-mel row 96: SAME padding) is skipped, as conv1_kernel does; only the
         // last row block of a window can meet one, so the check lives in its own copy of the loop
         // (as a per-tap condition the compiler turns it into 252 selects)
@@ -2184,14 +2195,13 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
 #undef BD_STEM3_CONV1
     }
     __syncthreads();
+    ST_TS(3)
 
     // ---- C: depthwise 2 for rows r0 .. r0 + 4 -> split-f16 A tile [160][32] ----
     // (rolling window over the conv1 band: 21 LDS reads instead of 45)
     {
-        v4f wt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(dw2_w + t * 32 + c4 * 4);
-        const v4f bias = *reinterpret_cast<const v4f*>(dw2_b + c4 * 4);
+        const v4f (&wt)[9] = d2wt;
+        const v4f bias = d2bias;
         v4f cv[3][3];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -2225,7 +2235,12 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
     __syncthreads();
+    ST_TS(4)
 
+    v4f d3wt[9];                                // depthwise-3 taps (channels 4 (tid & 15) ..): in flight during D and E
+#pragma unroll
+    for (int t = 0; t < 9; ++t) d3wt[t] = *reinterpret_cast<const v4f*>(dw3_w + t * 64 + (tid & 15) * 4);
+    const v4f d3bias = *reinterpret_cast<const v4f*>(dw3_b + (tid & 15) * 4);
     // ---- D: GEMM.  Waves (wr, wc): column tile wc; row tiles wr, wr + 2 and, for wr == 0, 4 ----
     const int wr = wave >> 1, wc = wave & 1;
     const int frow = lane & 31, fh = lane >> 5;
@@ -2250,6 +2265,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
     __syncthreads();   // every wave is done with the A tile, the conv band and the log-mel band: P may overwrite them
+    ST_TS(5)
 
     // ---- E: bias + ReLU -> P; layer-2 rows past row 47 are the depthwise's zero padding ----
     {
@@ -2269,6 +2285,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
     __syncthreads();
+    ST_TS(6)
 
     // ---- F: depthwise 3, stride 2: out[o][ow][c] from P rows 2o + kh, columns 2ow + kw (column 32 = padding) ----
     float* dst = out + (((size_t)win * 24 + 2 * ob) * 16) * 64;
@@ -2276,7 +2293,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
     for (int it = 0; it < 2; ++it) {
         const int id = tid + 256 * it;              // 512 tasks: o (2) x ow (16) x c4 (16)
         const int c16 = id & 15, ow = (id >> 4) & 15, o = id >> 8;
-        v4f acc = *reinterpret_cast<const v4f*>(dw3_b + c16 * 4);
+        v4f acc = d3bias;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -2284,8 +2301,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                 const int pc = 2 * ow + kw;
                 v4f v = {0.f, 0.f, 0.f, 0.f};
                 if (pc < 32) v = *reinterpret_cast<const v4f*>(P + ((2 * o + kh) * 32 + pc) * PW + c16 * 4);
-                const v4f w = *reinterpret_cast<const v4f*>(dw3_w + (kh * 3 + kw) * 64 + c16 * 4);
-                acc = __builtin_elementwise_fma(v, w, acc);
+                acc = __builtin_elementwise_fma(v, d3wt[kh * 3 + kw], acc);
             }
         acc.x = fmaxf(acc.x, 0.0f);
         acc.y = fmaxf(acc.y, 0.0f);
@@ -2306,6 +2322,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
     }
     if constexpr (PW3) {
         __syncthreads();
+        ST_TS(7)
         // ---- G: [32][64] x [64][128], one 32 x 32 tile per wave ----
         f32x16 acc3;
 #pragma unroll
@@ -2319,6 +2336,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3l[q], acc3, 0, 0, 0);
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3h[q], acc3, 0, 0, 0);
         }
+        ST_TS(8)
         // ---- H: bias + ReLU, [32][128] block of the layer-3 output (rows are consecutive NHWC positions) ----
         float* dst3 = out + (((size_t)win * 24 + 2 * ob) * 16) * 128;
         const int n = 32 * wave + frow;
@@ -2328,7 +2346,10 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             const int m = 4 * fh + (r & 3) + 8 * (r >> 2);
             dst3[(size_t)m * 128 + n] = fmaxf(acc3[r] + b, 0.0f);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ST_TS(9)
     }
+#undef ST_TS
 }
 
 // --------------------------------------------------------------------------- pool + head
@@ -2587,17 +2608,28 @@ void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int
     if (windows <= 0) return;
     hipLaunchKernelGGL(stem3_kernel<false>, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
                        c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out, nullptr, nullptr, nullptr);
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out, nullptr, nullptr, nullptr, nullptr);
 }
 
 // Layers 1-3 complete: out = [windows][24][16][128], the layer-3 output.
 void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;
+    static unsigned* dbg = nullptr;          // developer aid: BD_STEM_TRACE=1 prints a phase-level clock trace
+    static int shots = 0;
+    if (!dbg && getenv("BD_STEM_TRACE")) (void)hipMalloc(&dbg, 64);
     hipLaunchKernelGGL(stem3_kernel<true>, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
                        c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
                        static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out,
-                       static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_b);
+                       static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_b, dbg);
+    if (dbg) {
+        (void)hipStreamSynchronize(stream);
+        unsigned h[16];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        if (++shots == 4)
+            fprintf(stderr, "[trace] stem (layers 1-3), one workgroup, cycles: weights+setup %u | A log-mel band %u | B conv1 %u | C depthwise2 %u | D gemm2 %u | E tile %u | F depthwise3 %u | G gemm3 %u | H store %u | total %u\n",
+                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[9] - h[8], h[9] - h[0]);
+    }
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
