@@ -791,6 +791,10 @@ __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned t
 // unfused kernels: results are bit-identical.
 // (ABL is a leftover template slot of the timing ablations used while tuning - no loads / no depthwise /
 //  no MFMA / one role idle / no store; their results are in DESIGN.md.  Always 0.)
+// NDW = 3: band tiles of the 24x16 map that OVERLAP: a tile computes 6 rows (BM = 96) but advances 4, so it holds the
+// five rows its two output rows of the next layer's stride-2 depthwise need; that depthwise is applied in the
+// epilogue and only its [2][8][N] result is written (the 24x16 output and the stand-alone depthwise disappear,
+// at the price of computing every other row pair twice).
 // NDW = 2: the tile is not written either; its windows are average-pooled and only [windows][N] goes to out2.
 // NDW = 1: the tile (whole windows) is not written; the NEXT layer's stride-2 depthwise (taps ndw_w, shift
 // ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS and only that result goes to out2.
@@ -800,7 +804,7 @@ __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned t
 // double-buffered register set, one stage ahead.  The engine keeps a copy of the split weights in fragment
 // order, so each of those loads is one contiguous KiB per wave.
 template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD, int PWO>
-__global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_kernel(
+__global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
     float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n,
@@ -809,6 +813,8 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     static_assert(KS == 1 || (KS == 2 && BDIR == 1), "64-channel stages need the weights out of LDS");
     static_assert(XD == 0 || (BDIR == 1 && KS == 1 && XPMAX % 32 == 0), "slab DMA is issued by the fragment-loading consumers");
     static_assert(PWO == 0 || (XD == 1 && NDW == 0 && XPMAX == BM), "pointwise-only tiles use the DMA pipeline");
+    static_assert(NDW != 3 || (BM == 96 && XPMAX == 128 && BN == 128), "overlapping band tiles: 6 rows of 16, 128 channels");
+    constexpr int TSTEP = NDW == 3 ? 64 : BM; // rows a tile advances (NDW = 3: 4 of its 6 rows)
     constexpr int NX = XD ? 3 : 2 * KS;      // slab / tap buffers: a ring of three when the producers fill it by DMA
     constexpr int WS_FLOATS = XD ? 0 : 320;   // depthwise taps + shift of a 32-channel block (XD: all K at once, in Wall)
     constexpr int WN = BN / 4;               // consumer wave tile: BM x WN
@@ -831,8 +837,8 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned tile_m, tile_n;
-    tile_of<(BM == 64)>(blockIdx.x, (unsigned)((M + BM - 1) / BM), (unsigned)tiles_n, tile_m, tile_n);
-    const long long m0 = (long long)tile_m * BM;
+    tile_of<(BM == 64 || NDW == 3)>(blockIdx.x, (unsigned)((M + TSTEP - 1) / TSTEP), (unsigned)tiles_n, tile_m, tile_n);
+    const long long m0 = (long long)tile_m * TSTEP;
     const int n0 = (int)tile_n * BN;
     const int nk = K / (32 * KS);             // stages; >= 4 (launcher)
 
@@ -1345,7 +1351,39 @@ __global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_ws_k
     }   // consumers
 
     __syncthreads();
-    if constexpr (NDW == 2) {
+    if constexpr (NDW == 3) {
+        // ---- next layer's depthwise (stride 2, SAME = pad 0 before / 1 after) on rows oh_a .. oh_a+4 of the tile:
+        // output rows oh_a/2 and oh_a/2 + 1, 8 columns, C4 channel quads = 512 tasks, one per thread; taps in
+        // (kh, kw) order with zeros outside the map, exactly as depthwise_kernel does ----
+        const float* Ct = reinterpret_cast<const float*>(smem_raw);
+        constexpr int C4 = BN / 4;
+        static_assert(2 * 8 * C4 == 512, "one task per thread");
+        const unsigned m0u = (unsigned)m0;
+        const unsigned n_ = m0u / (unsigned)P;
+        const int oh_a = (int)(m0u % (unsigned)P) / W;
+        const int c4 = tid % C4, q = tid / C4;
+        const int ow2 = q & 7, ol = q >> 3;
+        v4f acc = *reinterpret_cast<const v4f*>(ndw_b + n0 + c4 * 4);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ihl = 2 * ol + kh, iw = 2 * ow2 + kw;
+                v4f v = {0.f, 0.f, 0.f, 0.f};
+                if (oh_a + ihl < H && iw < W) v = *reinterpret_cast<const v4f*>(Ct + (ihl * W + iw) * (BN + 4) + c4 * 4);
+                const v4f w = *reinterpret_cast<const v4f*>(ndw_w + (size_t)(kh * 3 + kw) * N + n0 + c4 * 4);
+                acc.x = fmaf(v.x, w.x, acc.x);
+                acc.y = fmaf(v.y, w.y, acc.y);
+                acc.z = fmaf(v.z, w.z, acc.z);
+                acc.w = fmaf(v.w, w.w, acc.w);
+            }
+        acc.x = fmaxf(acc.x, 0.0f);
+        acc.y = fmaxf(acc.y, 0.0f);
+        acc.z = fmaxf(acc.z, 0.0f);
+        acc.w = fmaxf(acc.w, 0.0f);
+        const size_t row2 = ((size_t)n_ * (H / 2) + oh_a / 2 + ol) * (W / 2) + ow2;
+        *reinterpret_cast<v4f*>(out2 + row2 * N + n0 + c4 * 4) = acc;
+    } else if constexpr (NDW == 2) {
         // ---- global average pool (yamnet.py:104): mean over the P positions of every whole window of the tile, summed
         // in position order and divided by P exactly as pool_head_kernel does; out2 = [windows][N] ----
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
@@ -1438,8 +1476,9 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max + (ABL == 1 ? 1024 : 0));
         attr_set = true;
     }
+    constexpr int TSTEP = NDW == 3 ? 64 : BM;
     const int tiles_n = L.cout / BN;
-    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    const long long tiles = ((M + TSTEP - 1) / TSTEP) * tiles_n;
     if constexpr (ABL == 0 && BDIR == 1 && VS == 1 && NDW == 0 && BM == 96) {
         // developer aid: BD_WS_TRACE=1 traces a 512-channel fused layer, =2 the 256-channel pointwise of layer 7
         const char* tr = getenv("BD_WS_TRACE");
@@ -2532,6 +2571,11 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     hipStream_t stream) {
     const int P = L.h_out * L.w_out;
+    if (L.stride == 1 && next.stride == 2 && windows > 0 && P == 384 && L.w_out == 16 && L.cin >= 128 && L.cin % 64 == 0 &&
+        L.cout == 128 && next.cin == 128) {       // layer 4 + depthwise 5: overlapping 6-row band tiles
+        launch_sep_ws<128, 128, 0, 3, 96, 1, 1, 1, 1>(in, L, out, (long long)windows * P, stream, &next);
+        return true;
+    }
     if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;
     if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & (L.w_out - 1)) || L.h_out % 3) return false;
     const long long M = (long long)windows * P;

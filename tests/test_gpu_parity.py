@@ -349,6 +349,8 @@ def test_pointwise_on_wave_specialised_kernel_bit_identical_to_gemm_kernel(engin
         engine.set_fusion(True, True)            # default path: layers 5, 7, 13 use it after a depthwise, and the
         assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)    # last layer pools in its epilogue
         assert np.array_equal(engine.embed(x, 0.96).numpy(), plain_emb)
+        for st, ref in plain.items():            # ... layers 4, 6, 12 apply the next layer's depthwise in theirs
+            assert np.array_equal(engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy(), ref), ("default", st)
     finally:
         for layer in range(5, 15):
             engine.set_pointwise_variant(layer, 0)
