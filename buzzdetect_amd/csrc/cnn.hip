@@ -1905,6 +1905,253 @@ void launch_sep_wsp(const float* X, const SepLayer& L, float* out, long long M, 
                        L.cout, L.cin, L.h_out, L.w_out, tiles_n, (int)tiles);
 }
 
+// --------------------------------------------------------------------------- 12-wave form for N = 512
+// sep_ws_kernel computes the depthwise of a row tile once per 256-column tile, i.e. twice on the K = N = 512 layers,
+// and is bound by that producer work.  Here a workgroup is 12 waves: waves 8-11 are the producers (unchanged:
+// slab ring by LDS-DMA, vertical tap sharing, counted waits), waves 0-7 the consumers, each owning 96 x 64 of a
+// 96 x 512 tile - the depthwise runs once per row tile and every SIMD carries two MFMA waves and one VALU wave.
+// Twelve waves per CU leave 168 registers per wave, 96 of them accumulators: A fragments are read per 32-row tile
+// and weight fragments per 16-deep k step, double-buffered.  The output goes out in three 32-row chunks.
+// Plain instantiation only (no epilogue fusion); same products in the same order: bit-identical.
+template <int XPMAX>
+__global__ __launch_bounds__(768, 3) void sep_w12_kernel(
+    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
+    float* __restrict__ Cout, long long M, int K, int H, int W) {
+    constexpr int BM = 96, BN = 512, N = 512;
+    constexpr int TM = 3, TN = 2, LA = 3;
+    constexpr int XS_FLOATS = (XPMAX + 1) * 32;
+    constexpr int A_BYTES = BM * 64;
+    constexpr int NG = XPMAX / 8, GPW = NG / 4, ND = GPW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* const Xs = reinterpret_cast<float*>(smem_raw);              // [3][XS_FLOATS]
+    char* const Ah = reinterpret_cast<char*>(Xs + 3 * XS_FLOATS);      // [2][A_BYTES]
+    char* const Al = Ah + 2 * A_BYTES;
+    float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K]
+    float* const Cc = Wall + 10 * K;                                   // [32][BN + 4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = K / 32;                    // even, >= 4
+    const int P = H * W;                      // whole windows: P divides BM
+    const unsigned m0u = blockIdx.x * (unsigned)BM;
+    const long long m0 = m0u;
+    const int x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
+
+    if (wave >= 8) {
+        // ================================================================= producers (as sep_ws_kernel, XD + VS)
+        const int pt = tid - 512;
+        const int lrow = pt >> 3, lc4 = pt & 7;
+        const int pw = wave - 8;
+        const int lw = 31 - __builtin_clz(W);
+        int wl = 0, g = lrow;
+        if (P < BM) {
+            const int lg = 31 - __builtin_clz(P / LA);
+            wl = lrow >> lg;
+            g = lrow & ((1 << lg) - 1);
+        }
+        const int og = g >> lw, ow = g & (W - 1);
+        const int ml0 = wl * P + LA * og * W + ow;
+        int xt[(LA + 2) * 3], a_st[LA];
+#pragma unroll
+        for (int r = 0; r < LA + 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ih = LA * og - 1 + r, iw = ow - 1 + c;
+                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                xt[r * 3 + c] = (ok ? ml0 + (r - 1) * W + (c - 1) : XPMAX) * 32 + lc4 * 4;
+            }
+#pragma unroll
+        for (int i = 0; i < LA; ++i) a_st[i] = swz64(ml0 + i * W, lc4 >> 1) + (lc4 & 1) * 8;
+        const float* xsrc[GPW];
+#pragma unroll
+        for (int q = 0; q < GPW; ++q) {
+            int row = 8 * (GPW * pw + q) + (lane >> 3);
+            row = row < x_cnt ? row : x_cnt - 1;
+            xsrc[q] = X + (size_t)(m0 + row) * K + (lane & 7) * 4 - 256 * q;
+        }
+#define W12_DMA1(Q, KOFF, XB)                                                                             \
+    if constexpr ((Q) < GPW)                                                                              \
+        __builtin_amdgcn_global_load_lds(                                                                 \
+            (const __attribute__((address_space(1))) void*)(xsrc[(Q) < GPW ? (Q) : 0] + (KOFF)),          \
+            (__attribute__((address_space(3))) void*)(Xs + (XB) * XS_FLOATS + GPW * pw * 256), 16, 1024 * (Q), 0);
+#define W12_DMA(KOFF, XB) { W12_DMA1(0, KOFF, XB) W12_DMA1(1, KOFF, XB) W12_DMA1(2, KOFF, XB) W12_DMA1(3, KOFF, XB) }
+#define W12_PSYNC(KEEP)                                                                                   \
+    {                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        asm volatile("" ::: "memory");                                                                    \
+    }
+#define W12_DW(XB, AB, KCH)                                                                               \
+    {                                                                                                     \
+        const float* xs_ = Xs + (XB) * XS_FLOATS;                                                         \
+        const float* ws_ = Wall + (KCH) + lc4 * 4;                                                        \
+        v4f wt[9];                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * K); \
+        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * K);                                     \
+        v4f xv[(LA + 2) * 3];                                                                             \
+        _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t) xv[t] = *reinterpret_cast<const v4f*>(xs_ + xt[t]); \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
+            v4f a4 = bias4;                                                                               \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) a4 = __builtin_elementwise_fma(xv[i * 3 + t], wt[t], a4); \
+            a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
+            f16x4 hi, lo;                                                                                 \
+            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
+            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
+            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
+            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
+            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
+        }                                                                                                 \
+    }
+        if (pt < 24) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+        W12_DMA(0, 0)
+        W12_DMA(32, 1)
+        W12_DMA(64, 2)
+        {
+            constexpr int TI = 10;
+            const int n_w = 9 * (K / 4), n_all = 10 * (K / 4);
+            v4f tw_[TI];
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                const int i = pt + 256 * j;
+                if (i < n_all) tw_[j] = *reinterpret_cast<const v4f*>(i < n_w ? dw_w + 4 * (size_t)i : dw_b + 4 * (size_t)(i - n_w));
+            }
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                const int i = pt + 256 * j;
+                if (i < n_all) *reinterpret_cast<v4f*>(Wall + 4 * (size_t)i) = tw_[j];
+            }
+        }
+        W12_PSYNC(2 * ND)
+        W12_DW(0, 0, 0)
+        W12_PSYNC(ND)
+        int rs = 1;
+        int k = 0;
+        for (; k + 3 < nk; ++k) {
+            const int r3 = rs == 0 ? 2 : rs - 1;
+            W12_DMA((k + 3) * 32, r3)
+            W12_DW(rs, (k + 1) & 1, (k + 1) * 32)
+            W12_PSYNC(ND)
+            rs = rs == 2 ? 0 : rs + 1;
+        }
+        for (; k + 1 < nk; ++k) {
+            W12_DW(rs, (k + 1) & 1, (k + 1) * 32)
+            W12_PSYNC(0)
+            rs = rs == 2 ? 0 : rs + 1;
+        }
+        W12_PSYNC(0)                          // consumers' last MFMA stage
+#undef W12_DMA1
+#undef W12_DMA
+#undef W12_PSYNC
+#undef W12_DW
+    } else {
+        // ================================================================= consumers: wave wc owns columns 64 wc ..
+        const int wc = wave;
+        const int frow = lane & 31, fh = lane >> 5;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        // fragment base: column tile 2 wc + j, k16 step q -> + (j * (K/16) + q) * 512 halves
+        const _Float16* const wbh = Wfhi + ((size_t)(2 * wc) * (K / 16) * 64 + lane) * 8;
+        const _Float16* const wbl = Wflo + ((size_t)(2 * wc) * (K / 16) * 64 + lane) * 8;
+        const int jstep = (K / 16) * 512;     // halves between the two column tiles
+        f16x8 bh0[TN], bl0[TN], bh1[TN], bl1[TN];     // fragments of an even / an odd k16 step
+#define W12_BLOAD(BH, BL, Q)                                                                              \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                  \
+            BH[j] = *reinterpret_cast<const f16x8*>(wbh + j * jstep + (Q) * 512);                         \
+            BL[j] = *reinterpret_cast<const f16x8*>(wbl + j * jstep + (Q) * 512);                         \
+        }                                                                                                 \
+    }
+#define W12_MFMA(ABUF, S, BH, BL)                                                                         \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
+            const int off = (ABUF) * A_BYTES + swz64(i * 32 + frow, 2 * (S) + fh);                        \
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(Ah + off);                                   \
+            const f16x8 al = *reinterpret_cast<const f16x8*>(Al + off);                                   \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, BH[j], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BL[j], acc[i][j], 0, 0, 0);        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BH[j], acc[i][j], 0, 0, 0);        \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+        W12_BLOAD(bh0, bl0, 0)
+        W12_BLOAD(bh1, bl1, 1)
+        __syncthreads();
+        __syncthreads();
+        const int nq = K / 16;                // k16 steps, two per stage
+        for (int kk = 0; kk < nk; ++kk) {
+            W12_MFMA(kk & 1, 0, bh0, bl0)
+            if (2 * kk + 2 < nq) W12_BLOAD(bh0, bl0, 2 * kk + 2)
+            W12_MFMA(kk & 1, 1, bh1, bl1)
+            if (2 * kk + 3 < nq) W12_BLOAD(bh1, bl1, 2 * kk + 3)
+            __syncthreads();
+        }
+#undef W12_BLOAD
+#undef W12_MFMA
+        // ---- epilogue, consumer part: bias + ReLU, 32 rows at a time through the chunk ----
+        float bias_[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bias_[j] = pw_b[64 * wc + j * 32 + frow];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = 64 * wc + j * 32 + frow;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = 4 * fh + (r & 3) + 8 * (r >> 2);
+                    Cc[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + bias_[j], 0.0f);
+                }
+            }
+            __syncthreads();
+            for (int id = tid; id < 32 * (BN / 4); id += 768) {
+                const int ml = id / (BN / 4), c4_ = id % (BN / 4);
+                const long long m = m0 + 32 * i + ml;
+                if (m < M) *reinterpret_cast<v4f*>(Cout + (size_t)m * N + c4_ * 4) = *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---- epilogue, producer part: help store the three chunks ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __syncthreads();
+        for (int id = tid; id < 32 * (BN / 4); id += 768) {
+            const int ml = id / (BN / 4), c4_ = id % (BN / 4);
+            const long long m = m0 + 32 * i + ml;
+            if (m < M) *reinterpret_cast<v4f*>(Cout + (size_t)m * N + c4_ * 4) = *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);
+        }
+        __syncthreads();
+    }
+}
+
+template <int XPMAX>
+void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
+    const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + (size_t)40 * L.cin + 32u * (512 + 4) * 4;
+    constexpr size_t lds_max = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + 40u * 512u + 32u * (512 + 4) * 4;
+    static bool attr_set_dev[64] = {false};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set_dev[dev_ & 63]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        attr_set_dev[dev_ & 63] = true;
+    }
+    const long long tiles = (M + 95) / 96;
+    hipLaunchKernelGGL((sep_w12_kernel<XPMAX>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
+                       L.cin, L.h_out, L.w_out);
+}
+
 // --------------------------------------------------------------------------- fused stem
 // Layers 1-2 in one kernel: Conv2D 3x3 s2 (1->32) -> depthwise 3x3 s1 -> pointwise 32->64, each with
 // its folded BatchNorm + ReLU (yamnet.py:77-79).  Unfused these three launches move 1.2 GB per 1024
@@ -2603,6 +2850,8 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     //  neutral at one tile per CU; the 64-row layer-4 form spills under its 128-VGPR cap; see persistent_pays)
     if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0)
         variant = persistent_pays(((M + 95) / 96) * (L.cout / 256)) ? 11 : 9;
+    // 512 -> 512 channels: the 12-wave kernel computes the depthwise once per row tile instead of once per 256 columns
+    if (variant == 9 && L.cout == 512 && L.cin <= 512 && P <= 96 && !getenv("BD_NO_W12")) variant = 12;
     if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;   // layer 4
     if (variant >= 3 && L.cin >= 128 && ws_shape) {                // wave-specialised kernels (BM = 96)
         if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
@@ -2614,7 +2863,8 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
             return true;
         }
         if (P == 96 || P == 24 || P == 6) {
-            if (variant == 11 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_wsp<256, 96, 96, 0>(in, L, out, M, stream);
+            if (variant == 12 && L.cout == 512 && L.cin % 64 == 0 && L.cin <= 512 && P <= 96) launch_sep_w12<96>(in, L, out, M, stream);
+            else if (variant == 11 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_wsp<256, 96, 96, 0>(in, L, out, M, stream);
             else if (variant == 9 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
             else if (variant == 8 && L.cout % 256 == 0 && L.cin % 256 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 2>(in, L, out, M, stream);
             else if (variant >= 7 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1>(in, L, out, M, stream);

@@ -311,7 +311,7 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11):
+        for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12):
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
