@@ -1913,11 +1913,11 @@ void launch_sep_wsp(const float* X, const SepLayer& L, float* out, long long M, 
 // Twelve waves per CU leave 168 registers per wave, 96 of them accumulators: A fragments are read per 32-row tile
 // and weight fragments per 16-deep k step, double-buffered.  The output goes out in three 32-row chunks.
 // Plain instantiation only (no epilogue fusion); same products in the same order: bit-identical.
-template <int XPMAX>
+template <int XPMAX, bool TRACE>
 __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
-    float* __restrict__ Cout, long long M, int K, int H, int W) {
+    float* __restrict__ Cout, long long M, int K, int H, int W, unsigned* __restrict__ dbg) {
     constexpr int BM = 96, BN = 512, N = 512;
     constexpr int TM = 3, TN = 2, LA = 3;
     constexpr int XS_FLOATS = (XPMAX + 1) * 32;
@@ -1938,6 +1938,14 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
     const unsigned m0u = blockIdx.x * (unsigned)BM;
     const long long m0 = m0u;
     const int x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
+    // developer aid (BD_WS_TRACE=3): cycles before / inside every barrier for wave 0 (consumer) and wave 8 (producer)
+    int tsn = 0;
+#define W12_TS(WH)                                                                                        \
+    if constexpr (TRACE) {                                                                                \
+        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 8) && tsn < 32)                         \
+            dbg[((wave >> 3) * 32 + tsn) * 2 + (WH)] = (unsigned)__builtin_readcyclecounter();            \
+        if (WH) ++tsn;                                                                                    \
+    }
 
     if (wave >= 8) {
         // ================================================================= producers (as sep_ws_kernel, XD + VS)
@@ -1979,10 +1987,12 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
 #define W12_DMA(KOFF, XB) { W12_DMA1(0, KOFF, XB) W12_DMA1(1, KOFF, XB) W12_DMA1(2, KOFF, XB) W12_DMA1(3, KOFF, XB) }
 #define W12_PSYNC(KEEP)                                                                                   \
     {                                                                                                     \
+        W12_TS(0)                                                                                         \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
         __builtin_amdgcn_s_barrier();                                                                     \
         asm volatile("" ::: "memory");                                                                    \
+        W12_TS(1)                                                                                         \
     }
 #define W12_DW(XB, AB, KCH)                                                                               \
     {                                                                                                     \
@@ -2069,33 +2079,48 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
             BL[j] = *reinterpret_cast<const f16x8*>(wbl + j * jstep + (Q) * 512);                         \
         }                                                                                                 \
     }
-#define W12_MFMA(ABUF, S, BH, BL)                                                                         \
+        // One stage = 6 steps (k16 step s = 0, 1 x row tile i = 0..2) of 6 MFMAs each.  The A fragments of step t+1
+        // are requested before the MFMAs of step t are issued: with the LDS queue this busy (8 consumer waves read the
+        // whole A tile, 4 producer waves their taps) a fragment read just before its use waits several hundred cycles.
+#define W12_ALOAD(AH, AL, ABUF, S, I)                                                                     \
     {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
-            const int off = (ABUF) * A_BYTES + swz64(i * 32 + frow, 2 * (S) + fh);                        \
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(Ah + off);                                   \
-            const f16x8 al = *reinterpret_cast<const f16x8*>(Al + off);                                   \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, BH[j], acc[i][j], 0, 0, 0);        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BL[j], acc[i][j], 0, 0, 0);        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BH[j], acc[i][j], 0, 0, 0);        \
-            }                                                                                             \
-        }                                                                                                 \
+        const int off = (ABUF) * A_BYTES + swz64((I) * 32 + frow, 2 * (S) + fh);                          \
+        AH = *reinterpret_cast<const f16x8*>(Ah + off);                                                   \
+        AL = *reinterpret_cast<const f16x8*>(Al + off);                                                   \
+    }
+#define W12_STEP(I, AH, AL, BH, BL)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                      \
+        acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH[j], acc[I][j], 0, 0, 0);                \
+        acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL[j], acc[I][j], 0, 0, 0);                \
+        acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH[j], acc[I][j], 0, 0, 0);                \
     }
         W12_BLOAD(bh0, bl0, 0)
         W12_BLOAD(bh1, bl1, 1)
-        __syncthreads();
-        __syncthreads();
+        W12_TS(0) __syncthreads(); W12_TS(1)
+        W12_TS(0) __syncthreads(); W12_TS(1)
         const int nq = K / 16;                // k16 steps, two per stage
         for (int kk = 0; kk < nk; ++kk) {
-            W12_MFMA(kk & 1, 0, bh0, bl0)
+            const int ab = kk & 1;
+            f16x8 ah0, al0, ah1, al1;
+            W12_ALOAD(ah0, al0, ab, 0, 0)
+            W12_ALOAD(ah1, al1, ab, 0, 1)
+            W12_STEP(0, ah0, al0, bh0, bl0)
+            W12_ALOAD(ah0, al0, ab, 0, 2)
+            W12_STEP(1, ah1, al1, bh0, bl0)
+            W12_ALOAD(ah1, al1, ab, 1, 0)
+            W12_STEP(2, ah0, al0, bh0, bl0)
             if (2 * kk + 2 < nq) W12_BLOAD(bh0, bl0, 2 * kk + 2)
-            W12_MFMA(kk & 1, 1, bh1, bl1)
+            W12_ALOAD(ah0, al0, ab, 1, 1)
+            W12_STEP(0, ah1, al1, bh1, bl1)
+            W12_ALOAD(ah1, al1, ab, 1, 2)
+            W12_STEP(1, ah0, al0, bh1, bl1)
+            W12_STEP(2, ah1, al1, bh1, bl1)
             if (2 * kk + 3 < nq) W12_BLOAD(bh1, bl1, 2 * kk + 3)
-            __syncthreads();
+            W12_TS(0) __syncthreads(); W12_TS(1)
         }
+#undef W12_ALOAD
+#undef W12_STEP
 #undef W12_BLOAD
-#undef W12_MFMA
         // ---- epilogue, consumer part: bias + ReLU, 32 rows at a time through the chunk ----
         float bias_[TN];
 #pragma unroll
@@ -2132,6 +2157,7 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
         }
         __syncthreads();
     }
+#undef W12_TS
 }
 
 template <int XPMAX>
@@ -2142,14 +2168,43 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     if (!attr_set_dev[dev_ & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         attr_set_dev[dev_ & 63] = true;
     }
     const long long tiles = (M + 95) / 96;
-    hipLaunchKernelGGL((sep_w12_kernel<XPMAX>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
+    const char* tr = getenv("BD_WS_TRACE");
+    if (tr && tr[0] == '3') {
+        static unsigned* dbg = nullptr;
+        static int shots = 0;
+        if (!dbg) {
+            (void)hipMalloc(&dbg, 512);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        }
+        (void)hipMemsetAsync(dbg, 0, 512, stream);
+        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
+                           static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
+                           L.cin, L.h_out, L.w_out, dbg);
+        (void)hipStreamSynchronize(stream);
+        unsigned h[128];
+        (void)hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
+        if (++shots == 8)
+            for (int role = 0; role < 2; ++role) {
+                fprintf(stderr, "[trace] 12-wave kernel %s: work / wait cycles per barrier:", role ? "producer" : "consumer");
+                for (int i = 0; i < 20; ++i) {
+                    const unsigned arr = h[(role * 32 + i) * 2], lv = h[(role * 32 + i) * 2 + 1];
+                    const unsigned prev = i ? h[(role * 32 + i - 1) * 2 + 1] : arr;
+                    if (!arr && !lv) break;
+                    fprintf(stderr, " %u/%u", arr - prev, lv - arr);
+                }
+                fprintf(stderr, "\n");
+            }
+        return;
+    }
+    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
                        static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
-                       L.cin, L.h_out, L.w_out);
+                       L.cin, L.h_out, L.w_out, nullptr);
 }
 
 // --------------------------------------------------------------------------- fused stem
