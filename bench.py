@@ -81,12 +81,14 @@ def slot_plan(launches, pool_fused=True):
                 if launches[dw_slot] == 0 and layer >= 5 and (pw_slot - 2) in plan:
                     nm, fam, nb, fl = plan[pw_slot - 2]
                     # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own
-                    plan[pw_slot - 2] = (nm + f"+dw{layer}", fam, nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
+                    # (epilogue fusion exists only in the 8-wave kernel)
+                    plan[pw_slot - 2] = (nm + f"+dw{layer}", "sep_ws_kernel", nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
             elif layer == 2:      # fused stem: log-mel patch in, layer-2 output out
                 plan[pw_slot] = ("stem(1-2)", "stem_kernel", 96 * 64 * 4 + ho * wo * cout * 4,
                                  conv1[1] + dw[1] + pw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
-                fam = "sep_ws_kernel"     # every fused stride-1 layer runs the wave-specialised kernel by default
+                # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
+                fam = "sep_w12_kernel" if (pool_fused and c == 512 and cout == 512) else "sep_ws_kernel"
                 if layer == 14 and pool_fused:    # the average pool rides in the epilogue: [1024] out per window
                     plan[pw_slot] = ("sep14+pool", fam, (h * w * c + cout) * 4, dw[1] + pw[1] + ho * wo * cout)
                 else:
@@ -315,7 +317,7 @@ def main() -> None:
                 f["flops"] += fl * WINDOWS_PER_BATCH * args.steps
                 f["slots"].append(nm)
             total_ms = float(ms.sum())
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_s1_kernel", "sep_ws_kernel", "stem_kernel", "stem3_kernel")
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_s1_kernel", "sep_ws_kernel", "sep_w12_kernel", "stem_kernel", "stem3_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
             sec = d["ms"] * 1e-3
