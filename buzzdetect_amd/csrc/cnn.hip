@@ -2906,7 +2906,8 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0)
         variant = persistent_pays(((M + 95) / 96) * (L.cout / 256)) ? 11 : 9;
     // 512 -> 512 channels: the 12-wave kernel computes the depthwise once per row tile instead of once per 256 columns
-    if (variant == 9 && L.cout == 512 && L.cin <= 512 && P <= 96 && !getenv("BD_NO_W12")) variant = 12;
+    static const bool no_w12 = getenv("BD_NO_W12") != nullptr;    // developer switch for A/B timing
+    if (variant == 9 && L.cout == 512 && L.cin <= 512 && P <= 96 && !no_w12) variant = 12;
     if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;   // layer 4
     if (variant >= 3 && L.cin >= 128 && ws_shape) {                // wave-specialised kernels (BM = 96)
         if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
