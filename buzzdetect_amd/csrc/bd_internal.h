@@ -8,7 +8,7 @@
 
 namespace bd {
 
-constexpr int kMelMaxLen = 20;   // longest run of non-zero bins a mel band may have (kept in registers; YAMNet: 17)
+constexpr int kMelMaxLen = 18;   // longest run of non-zero bins a mel band may have (kept in registers; YAMNet: 17)
 
 // Constant tables of the front end, built on the host at bd_create (engine.hip) and kept in
 // device memory; every workgroup stages them into LDS once.

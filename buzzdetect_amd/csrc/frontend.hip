@@ -12,6 +12,8 @@
 //
 // Algorithmic HBM traffic: 640 B read (160 new samples) + 256 B written per frame.
 #include "bd_internal.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace bd {
 
@@ -21,7 +23,8 @@ constexpr int kWaves = 4;
 constexpr int kFramesPerWave = 4;
 constexpr int kGroupFrames = kWaves * kFramesPerWave;                         // 16 frames per pass
 constexpr int kGroupSamples = (kGroupFrames - 1) * BD_STFT_HOP + BD_STFT_WINDOW;  // 2800
-constexpr int kMelTaps = 20;   // mel weights a lane keeps in registers (longest band of the YAMNet filterbank: 17)
+constexpr int kMelTaps = kMelMaxLen;   // mel weights a lane keeps in registers (bd_create refuses longer bands; YAMNet: 17)
+static_assert(kMelTaps % 6 == 0, "the mel loop runs in batches of six");
 
 // Each wavefront works on its own z / mag tile, and LDS executes one wave's DS instructions in order,
 // so passes of a frame only need their LDS traffic drained and the compiler kept from reordering
@@ -55,7 +58,8 @@ __device__ __forceinline__ void dft4(float2& u0, float2& u1, float2& u2, float2&
 
 __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm, long long n_valid,
                                                      long long n_frames, float* __restrict__ out,
-                                                     const FeTables* __restrict__ tab) {
+                                                     const FeTables* __restrict__ tab, unsigned* __restrict__ dbg) {
+#define FE_TS(I) if (dbg && blockIdx.x == 3 && threadIdx.x == 0 && group == blockIdx.x && fi == 1) dbg[I] = (unsigned)__builtin_readcyclecounter();
     __shared__ __attribute__((aligned(16))) float s_pcm[kGroupSamples];
     __shared__ __attribute__((aligned(16))) float2 s_z[kWaves][256];
     __shared__ __attribute__((aligned(16))) float s_mag[kWaves][BD_SPECTRUM_BINS + 7];
@@ -90,16 +94,12 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
     const int zi_w1 = zsw(4 * lane);                                 // ^ r
     const int zi_w4 = zsw(((lane & ~3) << 2) + (lane & 3));          // ^ 4 r
     const int zi_w16 = zsw(((lane & ~15) << 2) + (lane & 15));       // ^ 16 r ^ (r >= 2 ? 31 : 0)
-    int zi_mir[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) zi_mir[r] = zsw((256 - (lane + 64 * r)) & 255);
 #define BD_ZLIN(R) ((zi_lin ^ zsw_mask(0, (R) & 1, (R) >> 1)) + 64 * (R))
     const int band_start = tab->band_start[lane];
     const int band_len = tab->band_len[lane];
     float bw[kMelTaps];                   // the band's mel weights (zero past band_len)
 #pragma unroll
     for (int j = 0; j < kMelTaps; ++j) bw[j] = j < band_len ? tab->band_w[j][lane] : 0.0f;
-    const int max_len = tab->max_len;     // <= kMelTaps, checked by the launcher
 
     float2* z = s_z[wave];
     float* mag = s_mag[wave];
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
             const long long frame = group * kGroupFrames + fl;
             const float* x = s_pcm + fl * BD_STFT_HOP;
 
+            FE_TS(0)
             // ---- pass 1 (p = 1): windowed samples straight from the PCM tile, no twiddles ----
             float2 u[4];
 #pragma unroll
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
             for (int r = 0; r < 4; ++r) z[zi_w1 ^ r] = u[r];
             wave_lds_sync();
 
+            FE_TS(1)
             // ---- passes 2..4 (p = 4, 16, 64) ----
             {
                 int pi = 0;
@@ -157,12 +159,13 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
                 }
             }
 
+            FE_TS(2)
             // ---- split the packed transform into the real spectrum, take magnitudes ----
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = lane + 64 * r;
                 const float2 zk = z[BD_ZLIN(r)];
-                const float2 zm = z[zi_mir[r]];
+                const float2 zm = z[zsw((256 - (lane + 64 * r)) & 255)];
                 const float ex = 0.5f * (zk.x + zm.x);
                 const float ey = 0.5f * (zk.y - zm.y);
                 const float ox = 0.5f * (zk.y + zm.y);    // O = -i/2 * (Zk - conj(Zm))
@@ -170,25 +173,36 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
                 const float2 t = tws[r];
                 const float xr = ex + (t.x * ox - t.y * oy);
                 const float xi = ey + (t.x * oy + t.y * ox);
-                mag[k] = sqrtf(xr * xr + xi * xi);
+                // v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf: its scale / class-test / select fix-ups were
+                // ~56 of a frame's ~245 vector instructions, and |X| only feeds log(mel + 0.001)
+                mag[k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
             }
             if (lane == 0) mag[256] = fabsf(z[0].x - z[0].y);
             wave_lds_sync();
 
+            FE_TS(3)
             // ---- banded mel reduction + log ----
+            // All kMelTaps reads are in bounds (band_start + 17 <= 257 + 6 of zero padding) and the weight is zero past
+            // band_len, where fmaf(m, 0, acc) returns acc exactly (m finite, acc >= +0): so no guards - twenty
+            // independent LDS reads in flight, then twenty FMAs.  With a uniform and a per-lane branch around every tap
+            // the compiler serialised read -> wait -> fma twenty times (1640 of a frame's 4570 cycles).
             float acc = 0.0f;
 #pragma unroll
-            for (int j = 0; j < kMelTaps; ++j) {
-                if (j < max_len) {
-                    const float m = mag[band_start + j];     // finite (padding is zero); weight is zero past band_len
-                    if (j < band_len) acc = fmaf(m, bw[j], acc);
-                }
+            for (int j0 = 0; j0 < kMelTaps; j0 += 6) {        // three batches of six: the register budget is 128
+                float mv[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) mv[j] = mag[band_start + j0 + j];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc = fmaf(mv[j], bw[j0 + j], acc);
             }
+            FE_TS(4)
             if (frame < n_frames) out[frame * BD_MEL_BANDS + lane] = logf(acc + 0.001f);
             wave_lds_sync();   // mag / z reads of this frame retire before the next frame overwrites them
+            FE_TS(5)
         }
     }
 #undef BD_ZLIN
+#undef FE_TS
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -419,8 +433,19 @@ void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* l
                            (long long)n_frames, logmel, tables);
         return;
     }
+    static unsigned* dbg = nullptr;           // developer aid: BD_FE_TRACE=1 prints a per-frame phase trace
+    static int shots = 0;
+    if (!dbg && getenv("BD_FE_TRACE")) (void)hipMalloc(&dbg, 64);
     hipLaunchKernelGGL(logmel_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
-                       (long long)n_frames, logmel, tables);
+                       (long long)n_frames, logmel, tables, dbg);
+    if (dbg) {
+        (void)hipStreamSynchronize(stream);
+        unsigned h[8];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        if (++shots == 4)
+            fprintf(stderr, "[trace] front end, one frame of one wave (4 waves/SIMD), cycles: pass 1 %u | passes 2-4 %u | split + magnitude %u | mel %u | log + store %u | total %u\n",
+                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[5] - h[0]);
+    }
 }
 
 void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
