@@ -234,7 +234,7 @@ int build_tables(const float* mel, bd::FeTables* t) {
         }
         const int len = last - first + 1;
         if (len > bd::kMelMaxLen)
-            return fail(BD_EWEIGHTS, "mel band spans more than 20 spectrum bins; not the 64-band YAMNet filterbank?");
+            return fail(BD_EWEIGHTS, "mel band spans more than 18 spectrum bins; not the 64-band YAMNet filterbank?");
         t->band_start[m] = first;
         t->band_len[m] = len;
         if (len > max_len) max_len = len;
