@@ -1879,8 +1879,9 @@ static int device_cus() {
 // run, bench.py and the reference's analyzers_gpu) 1.25 M vs 1.27 M - a persistent workgroup holds 136 KB of LDS
 // per CU for the whole launch, so the other stream's workgroups cannot slip into the gaps, which are exactly what
 // it removes on its own.  So: off unless asked for (BD_PERSISTENT=1, or explicit kernel variant 11).
-static bool persistent_pays(long long tiles) {
-    static const bool on = getenv("BD_PERSISTENT") != nullptr;
+static bool persistent_pays(long long tiles, bool pointwise_only = false) {
+    static const char* mode = getenv("BD_PERSISTENT");          // "1": everywhere, "pw": pointwise-only launches
+    const bool on = mode && (mode[0] == '1' || (pointwise_only && mode[0] == 'p'));
     return on && tiles > device_cus();
 }
 
@@ -2853,7 +2854,7 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
     if (rows <= 0 || rows >= (1LL << 31) || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0) return false;
     // (96 x 128 tiles with two workgroups per CU measured the same: 33.1 vs 32.6 us on layer 7)
-    const bool persistent = L.pw_variant16 == 11 || (L.pw_variant16 == 0 && persistent_pays(((rows + 95) / 96) * (L.cout / 256)));
+    const bool persistent = L.pw_variant16 == 11 || (L.pw_variant16 == 0 && persistent_pays(((rows + 95) / 96) * (L.cout / 256), true));
     if (persistent) launch_sep_wsp<256, 96, 96, 1>(in, L, out, rows, stream);
     else launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
     return true;
