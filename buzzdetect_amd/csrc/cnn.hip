@@ -1210,19 +1210,25 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             BL[j][s] = *reinterpret_cast<const f16x8*>(wpl[j] + (KOFF) * 32 + 512 * s);                   \
         }                                                                                                 \
     }
+        // one sub-stage = 2 TM steps (k16 step s x row tile i) of 3 TN MFMAs; the A fragments of step n+1 are requested
+        // before the MFMAs of step n are issued (reading all TM pairs of a k16 step and then waiting exposed two
+        // LDS latencies per stage)
+#define BD_W_AFRAG(AH, AL, BUF, N)                                                                        \
+    {                                                                                                     \
+        const int off = (BUF) * A_BYTES + swz64(((N) % TM) * 32 + frow, 2 * ((N) / TM) + fh);             \
+        AH = *reinterpret_cast<const f16x8*>(Ah + off);                                                   \
+        AL = *reinterpret_cast<const f16x8*>(Al + off);                                                   \
+    }
 #define BD_W_MFMA(BUF, BH, BL)                                                                            \
     {                                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
-            f16x8 ah[TM], al[TM];                                                                         \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
-                const int off = (BUF) * A_BYTES + swz64(i * 32 + frow, 2 * s + fh);                       \
-                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
-                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
-            }                                                                                             \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], BH[j][s], acc[i][j], 0, 0, 0);  \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BL[j][s], acc[i][j], 0, 0, 0);  \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BH[j][s], acc[i][j], 0, 0, 0);  \
+        f16x8 ahx[2], alx[2];                                                                             \
+        BD_W_AFRAG(ahx[0], alx[0], BUF, 0)                                                                \
+        _Pragma("unroll") for (int n = 0; n < 2 * TM; ++n) {                                              \
+            if (n + 1 < 2 * TM) BD_W_AFRAG(ahx[(n + 1) & 1], alx[(n + 1) & 1], BUF, n + 1)                \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
+                acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alx[n & 1], BH[j][n / TM], acc[n % TM][j], 0, 0, 0); \
+                acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahx[n & 1], BL[j][n / TM], acc[n % TM][j], 0, 0, 0); \
+                acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahx[n & 1], BH[j][n / TM], acc[n % TM][j], 0, 0, 0); \
             }                                                                                             \
         }                                                                                                 \
     }
@@ -1246,6 +1252,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
         if constexpr (KS == 1) BD_SYNC()
         BD_W_MFMA((t + 1) & (2 * KS - 1), b1h, b1l)
         BD_SYNC()
+#undef BD_W_AFRAG
 #undef BD_W_LOAD
 #undef BD_W_MFMA
     } else {
