@@ -1,16 +1,20 @@
 // YAMNet (MobileNetV1) body on gfx950: embedders/yamnet/yamnet.py:36-106 with the BatchNorms
 // (yamnet.py:26-33, scale=False, eps=1e-4) folded into the convolution weights at load time.
 // All activations are NHWC float32, exactly the reference's layout.
-//
-//   conv1_kernel      Conv2D 3x3 s2 SAME 1->32 + bias + ReLU, reading log-mel patches in place
-//                     (window w = frames [w*step, w*step+96) of the [T,64] spectrogram: the
-//                     tf.signal.frame / Reshape of features.py:72-76, yamnet.py:98-100 is index math)
-//   depthwise_kernel  DepthwiseConv2D 3x3 s1|s2 SAME + bias + ReLU
-//   pointwise_kernel  Conv2D 1x1 + bias + ReLU as C[M,N] = A[M,K] * Wt[N,K]^T on the f32 matrix
-//                     cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate)
-//   pool_head_kernel  GlobalAveragePooling2D over 3x2 + Dense(1024 -> n_classes)
-//
 // TF "SAME" for an even extent with stride 2 pads 0 before / 1 after; stride 1 pads 1 / 1.
+//
+// Default path (14 launches per pass):
+//   stem3_kernel<true>   layers 1-3: conv 3x3 s2 -> dw 3x3 -> pw 32->64 -> dw 3x3 s2 -> pw 64->128, one kernel
+//   sep_ws_kernel        fused depthwise + pointwise of a stride-1 layer, wave-specialised (4 producer + 4 MFMA
+//                        waves, slab ring by LDS-DMA, split-f16 MFMA); with PWO the plain 1x1 convolution of the
+//                        stride-2 layers; NDW = 1 / 3: next layer's stride-2 depthwise in the epilogue (3: layer 4,
+//                        overlapping band tiles); NDW = 2: global average pool in the epilogue (layer 14)
+//   sep_w12_kernel       the same for the 512 -> 512 layers 8-11 with 8 MFMA waves (depthwise once per row tile)
+//   pool_head_kernel<1>  Dense(1024 -> n_classes) on the pooled embeddings
+// Reference / selectable kernels (one per op; the fused ones are tested bit for bit against them):
+//   conv1_kernel, depthwise_kernel, pointwise_f16x3_kernel (split-f16), pointwise_kernel (exact-f32 MFMA),
+//   stem_kernel, stem3_kernel<false>, sep_s1_kernel (4-wave fusion), sep_wsp_kernel (persistent), pool_head_kernel<6>
+// Workgroup -> tile mapping is XCD-aware (tile_of); developer traces are behind BD_WS_TRACE / BD_STEM_TRACE.
 #include "bd_internal.h"
 
 namespace bd {
