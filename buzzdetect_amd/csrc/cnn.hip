@@ -2611,9 +2611,11 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                 const int off = swz64(rt * 32 + frow, 2 * s2 + fh);
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(s_ah + off);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(s_al + off);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wbh[s2], acc2[i], 0, 0, 0);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbl[s2], acc2[i], 0, 0, 0);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wbh[s2], acc2[i], 0, 0, 0);
+                // operands swapped: the accumulators hold the TRANSPOSED tile (lane = position, four consecutive
+                // channels per register quad), so phase E writes 16 bytes at a time; same products, same k order
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], al, acc2[i], 0, 0, 0);
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbl[s2], ah, acc2[i], 0, 0, 0);
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], ah, acc2[i], 0, 0, 0);
             }
         }
     }
@@ -2622,17 +2624,25 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
 
     // ---- E: bias + ReLU -> P; layer-2 rows past row 47 are the depthwise's zero padding ----
     {
-        const int n = wc * 32 + frow;
-        const float b = pw_b[n];
+        // transposed accumulators: lane -> position rt * 32 + frow; registers 4 g .. 4 g + 3 -> channels
+        // wc * 32 + 8 g + 4 fh + (0..3)
+        v4f b4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const v4f*>(pw_b + wc * 32 + 8 * g + 4 * fh);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int rt = wr + 2 * i;
             if (rt < R2) {
                 const bool live = r0 + rt < 48;
+                float* prow = P + (rt * 32 + frow) * PW + wc * 32 + 4 * fh;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = rt * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
-                    P[m * PW + n] = live ? fmaxf(acc2[i][r] + b, 0.0f) : 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    v4f v;
+                    v.x = live ? fmaxf(acc2[i][4 * g + 0] + b4[g].x, 0.0f) : 0.0f;
+                    v.y = live ? fmaxf(acc2[i][4 * g + 1] + b4[g].y, 0.0f) : 0.0f;
+                    v.z = live ? fmaxf(acc2[i][4 * g + 2] + b4[g].z, 0.0f) : 0.0f;
+                    v.w = live ? fmaxf(acc2[i][4 * g + 3] + b4[g].w, 0.0f) : 0.0f;
+                    *reinterpret_cast<v4f*>(prow + 8 * g) = v;
                 }
             }
         }
