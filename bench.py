@@ -3,34 +3,35 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the whole hot path (PCM -> log-mel -> YAMNet -> dense head) over one batch
-of synthetic 16 kHz mono audio already resident in HBM: BASELINE config 2's batch of 1024 windows
-(983.04 s = 15 728 640 samples, yamnet_k2 embedder at hop 1.0, model_general_v3 head).  With N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank runs its own batch per step — the
-round-robin file sharding of config 4 — and the per-window logits are gathered to rank 0 over RCCL
-inside the timed region.  Rank 0 prints ONE JSON line.
+A *step* is one pass of the whole hot path (PCM -> log-mel -> YAMNet -> dense head) over ONE synthetic 1 h
+16 kHz mono recording already resident in HBM, fed exactly as BASELINE config 2 / SURVEY 8d say: batches of
+1024 windows (983.04 s = 15 728 640 samples), i.e. 1024 + 1024 + 1024 + 678 = 3750 windows per step,
+yamnet_k2 embedder at hop 1.0 + model_general_v3 head.  K steps = K recordings in total, whatever N is
+(strong scaling, config 4's shape): recording i goes to rank i mod N; what is left when K is not a multiple
+of N is dealt batch by batch; every round of N recordings ends in ONE RCCL gather of the [3750, 13] logit
+blocks to rank 0, with sizes known on the host (no count exchange, no host synchronisation inside the timed
+region).  `python bench.py --gpus N` starts its own N child ranks (torch.distributed.run) when it is not
+already running under one.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-
-from buzzdetect_amd import sharding  # noqa: E402
-from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step  # noqa: E402
 
 SAMPLE_RATE = 16000
 WINDOWS_PER_BATCH = 1024
 HOP_PROP = 1.0
 FRAMELENGTH_S = 0.96
+FILE_SECONDS = 3600
+FILE_SAMPLES = FILE_SECONDS * SAMPLE_RATE                # 57 600 000
 
 # SURVEY §8d / DESIGN.md: algorithmic work per window at hop 1.0
 POINTWISE_FLOP_PER_WINDOW = 132_120_576          # 2 * 66 060 288 MAC in the thirteen 1x1 convolutions
@@ -39,6 +40,7 @@ FRONTEND_BYTES_PER_WINDOW = 61_440 + 24_576      # f32 PCM in + f32 log-mel out
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_SPLIT_F16_TFLOPS = 2500.0 / 3.0             # dense f16 MFMA peak / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 # per-window HBM bytes each depthwise / conv1 launch must move (read input + write output, f32 NHWC)
 _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1, 512), (1, 512),
@@ -105,8 +107,37 @@ def log(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def synthetic_batch(device, n_samples: int, seed: int) -> torch.Tensor:
+# --------------------------------------------------------------------------------------------------- launch
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` from a plain shell: start N fresh child ranks BEFORE this process touches a
+    GPU (nothing here initialises HIP), let rank 0's JSON line through on stdout, hand back the exit code."""
+    import torch
+    rehearsal = os.environ.get("BD_BENCH_REHEARSAL") == "1"
+    visible = torch.cuda.device_count()          # does not initialise the device on this stack
+    if visible < n and not rehearsal:
+        log(f"--gpus {n} but only {visible} GPU(s) visible (BD_BENCH_REHEARSAL=1 shares GPU 0 over gloo: control flow only)")
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# --------------------------------------------------------------------------------------------------- workload
+def synthetic_audio(device, n_samples: int, seed: int):
     """0.1*N(0,1) noise + 0.3*sin(2*pi*220 t) bursts of 0.5 s every 5 s, clipped to [-1,1)."""
+    import numpy as np
+    import torch
     gen = torch.Generator(device=device).manual_seed(seed)
     x = 0.1 * torch.randn(n_samples, generator=gen, device=device, dtype=torch.float32)
     t = torch.arange(n_samples, device=device, dtype=torch.float32) / SAMPLE_RATE
@@ -115,9 +146,21 @@ def synthetic_batch(device, n_samples: int, seed: int) -> torch.Tensor:
     return x.clamp_(-1.0, 1.0 - 2.0 ** -23)
 
 
-def cpu_baseline(engine: HipEngine, hop: int, step: int, windows: int):
+def file_batches(hop: int):
+    """(first sample, samples, windows) of one recording's batches: chunk edges on multiples of 1024 hops."""
+    out, at = [], 0
+    while at < FILE_SAMPLES:
+        n = min(WINDOWS_PER_BATCH * hop, FILE_SAMPLES - at)
+        out.append((at, n))
+        at += n
+    return out
+
+
+def cpu_baseline(engine, hop: int, step: int, windows: int):
     """The oracle timed on this box's host cores (checker + reported baseline, never the product).
     The sample is cut into the workload's own 1024-window chunks on both sides."""
+    import numpy as np
+    import torch
     from buzzdetect_amd import weights as W
     from oracle import yamnet_oracle as O
     from oracle.torch_baseline import TorchYamnet, usable_cores
@@ -132,13 +175,13 @@ def cpu_baseline(engine: HipEngine, hop: int, step: int, windows: int):
     model.predict(waves[0][: hop * 64], hop, step)                      # warm-up
     passes = []
     cpu_logits = None
-    for rep in range(3):
+    for rep in range(5):
         t0 = time.perf_counter()
         outs = [model.predict(w, hop, step) for w in waves]
         passes.append(time.perf_counter() - t0)
         cpu_logits = outs
         log(f"cpu_baseline: pass {rep}: {chunks * WINDOWS_PER_BATCH / passes[-1]:.1f} windows/s")
-    med = sorted(passes)[1]
+    med = sorted(passes)[2]
     n_win = sum(o.shape[0] for o in cpu_logits)
     gpu_logits = [engine.predict(w, FRAMELENGTH_S * HOP_PROP).numpy() for w in waves]
     d32 = max(float(np.abs(g - c).max()) for g, c in zip(gpu_logits, cpu_logits))
@@ -158,25 +201,107 @@ def cpu_baseline(engine: HipEngine, hop: int, step: int, windows: int):
         "value": round(n_win / med, 2), "unit": "windows/s", "cores": threads, "kind": "port",
         "implementation": "CPU restatement (torch-CPU fp32), not TensorFlow",
         "sample": f"{chunks} chunks x {WINDOWS_PER_BATCH} windows ({n_win * 0.96:.0f} s of audio), "
-                  f"1 warm-up + median of 3 passes",
+                  f"1 warm-up + median of 5 passes",
         "seconds_per_pass": round(med, 3), "cpu_model": cpu_model,
         "max_abs_dlogit_gpu_vs_cpu_f32": d32,
         "max_abs_dlogit_gpu_vs_cpu_f64_first8": float(np.abs(gpu_logits[0][:8] - ref64).max()),
     }
 
 
-def main() -> None:
+# --------------------------------------------------------------------------------------------------- extra legs
+def h2d_leg(engine, streams, device, hop: int, framehop_s: float, batches: int, s16: bool):
+    """Config-2 batches that start on the HOST: pinned buffers -> async copy on a copy stream -> (s16: device-side
+    conversion, bd_resample_s16 at 16 kHz -> 16 kHz) -> predict.  Copies are inside the timed region."""
+    import torch
+    n = WINDOWS_PER_BATCH * hop
+    dt = torch.int16 if s16 else torch.float32
+    host = []
+    for i in range(2):
+        x = synthetic_audio(device, n, 777 + i)
+        if s16:
+            x = (x * 32768.0).round().clamp_(-32768, 32767).to(torch.int16)
+        host.append(x.cpu().pin_memory())
+    copy_stream = torch.cuda.Stream(device)
+    ring = [torch.empty(n, dtype=dt, device=device) for _ in range(3)]
+    copied = [torch.cuda.Event() for _ in ring]
+    consumed = [None] * len(ring)
+
+    def run(count):
+        for i in range(count):
+            slot = i % len(ring)
+            with torch.cuda.stream(copy_stream):
+                if consumed[slot] is not None:
+                    copy_stream.wait_event(consumed[slot])
+                ring[slot].copy_(host[i % 2], non_blocking=True)
+                copied[slot].record(copy_stream)
+            s = streams[i % len(streams)]
+            with torch.cuda.stream(s):
+                s.wait_event(copied[slot])
+                pcm = engine[i % len(engine)].resample(ring[slot], SAMPLE_RATE, SAMPLE_RATE) if s16 else ring[slot]
+                engine[i % len(engine)].predict(pcm, framehop_s)
+                ev = torch.cuda.Event()
+                ev.record(s)
+                consumed[slot] = ev
+
+    run(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(batches)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    rate = batches * WINDOWS_PER_BATCH / sec
+    return round(rate, 1), round(batches * n * (2 if s16 else 4) / sec / 1e9, 2)
+
+
+def analyze_leg(device_index: int, hours: int, chunklength: float, framehop_prop: float, engine=None):
+    """analyze() file -> CSV over one generated 16-bit mono WAV of `hours` h on tmpfs; audio-seconds per second
+    (the reference's own rate definition, src/inference/worker.py:54-62, over the whole run)."""
+    import shutil
+    import tempfile
+    import wave
+    import numpy as np
+    import torch
+    from buzzdetect_amd.analyze import analyze
+    root = tempfile.mkdtemp(prefix="bd_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        audio, out = os.path.join(root, "audio"), os.path.join(root, "out")
+        os.makedirs(audio)
+        hour = synthetic_audio(torch.device("cuda", device_index), FILE_SAMPLES, 4242)
+        block = (hour * 32768.0).round().clamp_(-32768, 32767).to(torch.int16).cpu().numpy().astype("<i2").tobytes()
+        with wave.open(os.path.join(audio, f"synthetic_{hours}h.wav"), "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(SAMPLE_RATE)
+            for _ in range(hours):
+                w.writeframes(block)
+        del block, hour
+        t0 = time.perf_counter()
+        rep = analyze("model_general_v3", classes_out="all", framehop_prop=framehop_prop, chunklength=chunklength,
+                      dir_audio=audio, dir_out=out, embeddername="yamnet_k2", engine=engine, rank=0, world_size=1)
+        sec = time.perf_counter() - t0
+        assert rep.files_done == 1, rep
+        return {"audio_s_per_s": round(rep.audio_seconds / sec, 1), "windows_per_s": round(rep.windows / sec, 1),
+                "seconds": round(sec, 3), "windows": rep.windows, "chunks": rep.chunks,
+                "pcm_GBps_s16": round(rep.audio_seconds * SAMPLE_RATE * 2 / sec / 1e9, 3)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+# --------------------------------------------------------------------------------------------------- main
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--cpu-windows", type=int, default=4096,
-                    help="size of the bounded CPU-baseline sample (about 10-20 s of CPU work over 4 passes)")
+                    help="size of the bounded CPU-baseline sample (about 15-25 s of CPU work over 6 passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the host-resident (H2D-inclusive), analyze() and arithmetic-mode legs")
     ap.add_argument("--per-slot", action="store_true", help="print per-kernel times to stderr")
     ap.add_argument("--streams", type=int, default=2,
-                    help="analyzer streams per GPU: steps are dealt round-robin to this many engines, each on "
+                    help="analyzer streams per GPU: batches are dealt round-robin to this many engines, each on "
                          "its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253)")
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable-layer kernel variant (tuning)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
@@ -184,20 +309,30 @@ def main() -> None:
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
+
+    import numpy as np
+    import torch
+    from buzzdetect_amd import sharding
+    from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        return 2
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X; there is no CPU path for the product")
+        log("bench.py needs an MI355X; there is no CPU path for the product")
+        return 2
     # BD_BENCH_REHEARSAL=1: every rank uses GPU 0 and the collectives run over gloo on host copies - only to
     # exercise the multi-rank control flow on a one-GPU box; never a measurement.
     rehearsal = os.environ.get("BD_BENCH_REHEARSAL") == "1"
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
@@ -208,6 +343,7 @@ def main() -> None:
     engines = [HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=dev_index)
                for _ in range(max(1, args.streams))]
     streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in engines[1:]]
+    comm_stream = torch.cuda.Stream(device)
     engine = engines[0]
     for e in engines:
         if args.group_windows:
@@ -221,43 +357,70 @@ def main() -> None:
             e.set_frontend_variant(args.frontend_variant)
     framehop_s = FRAMELENGTH_S * HOP_PROP
     hop, step = hop_samples(framehop_s), patch_step(framehop_s)
-    n_samples = hop * WINDOWS_PER_BATCH                      # 15 728 640
-    assert engine.num_windows(n_samples, hop, step) == WINDOWS_PER_BATCH
+    batches = file_batches(hop)
+    batch_windows = [engine.num_windows(n, hop, step) for _, n in batches]
+    windows_per_file = sum(batch_windows)
+    assert batch_windows == [1024, 1024, 1024, 678] and windows_per_file == 3750, batch_windows
+    n_classes = engine.n_classes
 
-    # a few distinct batches so that a step never re-reads the PCM it has just processed
-    batches = [synthetic_batch(device, n_samples, 1234 + rank * 16 + i) for i in range(4)]
+    # a few distinct recordings so that a step never re-reads the PCM it has just processed
+    files = [synthetic_audio(device, FILE_SAMPLES, 1234 + i) for i in range(3)]
     torch.cuda.synchronize()
 
-    def one_step(i: int):
-        j = i % len(engines)
-        with torch.cuda.stream(streams[j]):
-            res = engines[j].predict(batches[i % len(batches)], framehop_s)
-        gathered = None
-        if world > 1:             # one communicator: collectives are issued in step order on stream 0
-            streams[0].wait_stream(streams[j])
-            with torch.cuda.stream(streams[0]):
-                gathered = sharding.gather_rows(res.tensor.cpu() if rehearsal else res.tensor, dst=0)
-                res.tensor.record_stream(streams[0])
-        return res, gathered
+    RING = 4
+    blocks = {}            # rows -> ring of [rows, C] round buffers (+ gather targets on rank 0)
+
+    def buffers(rows: int):
+        if rows not in blocks:
+            local = [torch.zeros((rows, n_classes), dtype=torch.float32, device=device) for _ in range(RING)]
+            gath = None
+            if world > 1 and rank == 0:
+                gath = [torch.empty((world, rows, n_classes), dtype=torch.float32,
+                                    device="cpu" if rehearsal else device) for _ in range(RING)]
+            blocks[rows] = (local, gath, [None] * RING)
+        return blocks[rows]
+
+    issued = [0]
+
+    def run_files(n_files: int, use_streams: bool = True):
+        """n_files recordings through this rank's share of the rounds (see the module docstring)."""
+        for rnd in sharding.plan_rounds(n_files, batch_windows, world):
+            local, gath, reusable = buffers(rnd.rows)
+            slot = issued[0] % RING
+            issued[0] += 1
+            mine = rnd.units[rank]
+            used = set()
+            for u, at in zip(mine, sharding.unit_offsets(mine)):
+                j = (u.batch % len(engines)) if use_streams else 0
+                s = streams[j]
+                if j not in used and reusable[slot] is not None:
+                    s.wait_event(reusable[slot])           # the gather that last read this block is done
+                used.add(j)
+                first, n = batches[u.batch]
+                with torch.cuda.stream(s):
+                    engines[j].predict(files[u.file % len(files)][first:first + n], framehop_s,
+                                       out=local[slot][at:at + u.windows])
+            if world > 1:         # ONE gather per round, after both analyzer streams, off their critical path
+                for j in used:
+                    comm_stream.wait_stream(streams[j])
+                with torch.cuda.stream(comm_stream):
+                    if rehearsal:
+                        sharding.gather_round(local[slot].cpu(), rnd.rows, dst=0, out=gath[slot] if gath else None)
+                    else:
+                        sharding.gather_round(local[slot], rnd.rows, dst=0, out=gath[slot] if gath else None)
+                    ev = torch.cuda.Event()
+                    ev.record(comm_stream)
+                    reusable[slot] = ev
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if rank == 0:
-        log(f"warm-up {args.warmup} steps, then {args.steps} timed steps on {world} GPU(s)")
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
-    def timed_region(steps: int, single_stream: bool = False) -> float:
+    def timed_region(steps: int, use_streams: bool = True) -> float:
         fence()
         t0 = time.perf_counter()
-        for i in range(steps):
-            if single_stream:     # per-kernel event timing needs the kernels of one stream back to back
-                engine.predict(batches[i % len(batches)], framehop_s)
-            else:
-                one_step(i)
+        run_files(steps, use_streams)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -266,65 +429,88 @@ def main() -> None:
             dt = float(tmax.item())
         return dt
 
-    # region 1: the number reported as `value` — nothing but the hot path on the stream
-    engine.profile_enable(False)
+    if rank == 0:
+        log(f"warm-up {args.warmup} steps, then {args.steps} timed steps (1 h recordings) over {world} GPU(s)")
+    run_files(max(args.warmup, 0))
+    fence()
+
+    # region 1: the number reported as `value` — nothing but the hot path (and, for N > 1, the gathers)
+    for e in engines:
+        e.profile_enable(False)
     elapsed = timed_region(args.steps)
-    # region 2: the same K steps again with every kernel bracketed by HIP events on its own stream
-    # (costs a few % of wall time, which is why it is not the region `value` comes from)
+    total_windows = windows_per_file * args.steps
+    value = total_windows / elapsed
+    if rank == 0:
+        log(f"{value:.0f} windows/s ({1e3 * elapsed / args.steps:.3f} ms/step of {windows_per_file} windows)")
+
+    # region 2 (rank 0's own share, one stream): the same batches with every kernel bracketed by HIP events on
+    # its stream (costs a few % of wall time, which is why `value` does not come from this region)
     events_on = not args.no_kernel_events
     ms = launches = None
     elapsed_events = None
+    ev_steps = max(1, min(args.steps, 10))
     if events_on:
         engine.profile_read()                                # drop anything recorded so far
         engine.profile_enable(True)
-        elapsed_events = timed_region(args.steps, single_stream=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(ev_steps):
+            for first, n in batches:
+                engine.predict(files[i % len(files)][first:first + n], framehop_s)
+        torch.cuda.synchronize()
+        elapsed_events = time.perf_counter() - t0
         engine.profile_enable(False)
         ms, launches = engine.profile_read()
 
-    total_windows = WINDOWS_PER_BATCH * args.steps * world
-    value = total_windows / elapsed
-    if rank == 0:
-        log(f"{value:.0f} windows/s ({1e3 * elapsed / args.steps:.3f} ms/step)")
-
+    rc = 0
     if rank == 0:
         out = {
             "metric": "yamnet_windows_per_s", "value": round(value, 1), "unit": "windows/s",
             "audio_seconds_per_s": round(value * framehop_s, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
-            "config": {"workload": "config 2: 16 kHz mono, batches of 1024 windows (983.04 s), yamnet_k2 hop 1.0 "
-                                   "+ model_general_v3 head; embedder weights seeded synthetic in the reference "
-                                   "layout, head weights real",
-                       "windows_per_step_per_gpu": WINDOWS_PER_BATCH, "samples_per_step_per_gpu": n_samples,
-                       "hop_samples": hop, "patch_step": step, "analyzer_streams": len(engines), "sharding": "round-robin batches per rank, "
-                       "RCCL gather of [W,13] logits to rank 0 each step" if world > 1 else "single GPU",
-                       "timing": "value from K clean steps; per-kernel HIP-event times from a second identical K-step region"},
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "f32 in / f32 accumulate; 1x1-conv products as split-f16 MFMA (hi+lo halves, 3 MFMAs, 22-bit "
+                          "operands) - max|dlogit| vs the f64 oracle equals the exact-f32-MFMA mode's (value_mode0_f32)",
+            "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
+            "config": {"workload": "config 2: one synthetic 1 h 16 kHz mono recording per step, fed as batches of 1024 "
+                                   "windows (1024+1024+1024+678 = 3750 windows, 983.04 s chunks), embedder yamnet_k2 "
+                                   "(mel Const of embedders/yamnet_k2) hop 1.0 + model_general_v3 head; embedder weights "
+                                   "seeded synthetic in the reference layout, head weights real",
+                       "windows_per_step": windows_per_file, "samples_per_step": FILE_SAMPLES,
+                       "batch_windows": batch_windows, "hop_samples": hop, "patch_step": step,
+                       "analyzer_streams": len(engines),
+                       "sharding": (f"config 4 shape: {args.steps} recordings in total, recording i -> rank i mod {world}, "
+                                    f"remainder dealt per batch; one RCCL gather of the [rows,13] logit blocks to rank 0 "
+                                    f"per round of {world} recordings, sizes known on the host") if world > 1 else "single GPU",
+                       "timing": "value from K clean steps; per-kernel HIP-event times from a second region "
+                                 f"({ev_steps} steps, one stream)"},
         }
         if events_on and launches.sum() > 0 and args.per_slot:
             for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches, pool_fused=args.sep_variant is None).items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
-                log(f"slot {slot:2d} {nm:10s} {fam:24s} {us:8.1f} us  {nb * WINDOWS_PER_BATCH / us / 1e6:6.2f} TB/s  "
-                    f"{fl * WINDOWS_PER_BATCH / us / 1e6:7.1f} TFLOP/s")
+                wl = windows_per_file * ev_steps / max(int(launches[slot]), 1)     # windows per launch on average
+                log(f"slot {slot:2d} {nm:10s} {fam:24s} {us:8.1f} us  {nb * wl / us / 1e6:6.2f} TB/s  "
+                    f"{fl * wl / us / 1e6:7.1f} TFLOP/s   (avg {wl:.0f} windows/launch)")
         if events_on and launches.sum() > 0:
-            out["ms_per_step_with_kernel_events"] = round(1e3 * elapsed_events / args.steps, 4)
+            out["ms_per_step_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
             fams = {}
             for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant is None).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                 f["ms"] += ms[slot]
                 f["launches"] += int(launches[slot])
-                f["bytes"] += nb * WINDOWS_PER_BATCH * args.steps
-                f["flops"] += fl * WINDOWS_PER_BATCH * args.steps
+                f["bytes"] += nb * windows_per_file * ev_steps
+                f["flops"] += fl * windows_per_file * ev_steps
                 f["slots"].append(nm)
             total_ms = float(ms.sum())
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_s1_kernel", "sep_ws_kernel", "sep_w12_kernel", "stem_kernel", "stem3_kernel")
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "stem3_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
             sec = d["ms"] * 1e-3
             if dom in mfma_fams:
                 achieved = d["flops"] / sec / 1e12
                 out["roofline"] = {
-                    "kernel": f"{dom} ({', '.join(d['slots'])}: {d['launches'] // args.steps} launches per step)",
+                    "kernel": f"{dom} ({', '.join(d['slots'])}: {d['launches'] // (ev_steps * len(batches))} launches per batch)",
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": round(PEAK_SPLIT_F16_TFLOPS, 1),
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_SPLIT_F16_TFLOPS, 4), "traffic": None,
                     "peak_note": "achieved = algorithmic f32-equivalent FLOP/s (1x1 conv + depthwise of the layers this "
@@ -338,11 +524,11 @@ def main() -> None:
                                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}
             try:      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
-                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_1p3M.json")) as f:
+                with open(os.path.join(REPO, PMC_TRAFFIC_FILE)) as f:
                     pmc = json.load(f)["per_kernel_family"].get(dom)
                 if pmc:
                     out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic_1p3M.json ((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch)"
+                    out["roofline"]["traffic_source"] = PMC_TRAFFIC_FILE + " ((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch)"
             except (OSError, ValueError, KeyError):
                 pass
             out["roofline"].update({"avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
@@ -353,12 +539,19 @@ def main() -> None:
             stages = {}
             for fam, k in sorted(fams.items(), key=lambda kv: -kv[1]["ms"]):
                 sec = k["ms"] * 1e-3
-                stages[fam] = {"slots": k["slots"], "ms_per_step": round(k["ms"] / args.steps, 4),
+                stages[fam] = {"slots": k["slots"], "ms_per_step": round(k["ms"] / ev_steps, 4),
                                "share": round(k["ms"] / total_ms, 4),
                                "GBps_algorithmic": round(k["bytes"] / sec / 1e9, 1),
                                "frac_hbm_peak": round(k["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4),
                                "TFLOPs_algorithmic": round(k["flops"] / sec / 1e12, 2)}
             out["stages"] = stages
+
+        if world == 1 and not args.no_extras:
+            try:
+                extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s)
+            except Exception as exc:                     # an extra leg must never take the headline line down
+                log(f"extras failed: {type(exc).__name__}: {exc}")
+                out["extras_error"] = f"{type(exc).__name__}: {exc}"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(engine, hop, step, args.cpu_windows)
         print(json.dumps(out), flush=True)
@@ -366,7 +559,63 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s):
+    """Numbers reported BESIDE `value` (never as it): host-resident input, file -> CSV, other arithmetic modes."""
+    import numpy as np
+    import torch
+    k = max(8, min(40, args.steps))
+    v, gbs = h2d_leg(engines, streams, device, hop, framehop_s, k, s16=True)
+    out["value_h2d_s16"] = {"value": v, "unit": "windows/s", "pcie_GBps": gbs,
+                            "what": "config-2 batches starting in pinned HOST memory as 16-bit PCM: async H2D on a copy "
+                                    "stream (3-deep device ring) + device-side s16->f32 + predict, copies inside the timed region"}
+    log(f"host-resident s16 batches: {v:.0f} windows/s ({gbs} GB/s over PCIe)")
+    v, gbs = h2d_leg(engines, streams, device, hop, framehop_s, k, s16=False)
+    out["value_h2d_f32"] = {"value": v, "unit": "windows/s", "pcie_GBps": gbs,
+                            "what": "the same with float32 PCM on the host (the reference's dtype_in)"}
+    log(f"host-resident f32 batches: {v:.0f} windows/s ({gbs} GB/s over PCIe)")
+
+    legs = {}
+    for name, hours, chunk, hp in (("config2_1h_hop1.0", 1, WINDOWS_PER_BATCH * FRAMELENGTH_S, 1.0),
+                                   ("config3_24h_600s_hop1.0", 24, 600.0, 1.0),
+                                   ("config3_24h_600s_hop0.5", 24, 600.0, 0.5)):
+        legs[name] = analyze_leg(dev_index, hours, chunk, hp)
+        log(f"analyze() {name}: {legs[name]['audio_s_per_s']:.0f} audio-s/s, {legs[name]['windows_per_s']:.0f} windows/s")
+    out["analyze_audio_s_per_s"] = {"what": "analyze(): 16-bit WAV on tmpfs -> reference-format CSV, wall clock of the whole "
+                                            "call (file read, H2D, device conversion, hot path, D2H, CSV)", **legs}
+
+    # the other arithmetic modes of the 1x1 convolutions, same K batches of 1024 windows, reported beside `value`
+    x = synthetic_audio(device, WINDOWS_PER_BATCH * hop, 99)
+    ref = engines[0].predict(x, framehop_s).numpy().copy()
+    modes = {}
+    for mode in getattr(engines[0], "POINTWISE_MODES", ("f32",)):
+        if mode == "f16x3":
+            continue
+        for e in engines:
+            e.set_pointwise_mode(mode)
+        got = engines[0].predict(x, framehop_s).numpy()
+        for i in range(4):
+            engines[i % len(engines)].predict(x, framehop_s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                engines[i % len(engines)].predict(x, framehop_s)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t0
+        modes[mode] = {"value": round(k * WINDOWS_PER_BATCH / sec, 1), "unit": "windows/s",
+                       "max_abs_dlogit_vs_default_mode": float(np.abs(got - ref).max())}
+        log(f"pointwise mode {mode}: {modes[mode]['value']:.0f} windows/s, max|dlogit| vs default {modes[mode]['max_abs_dlogit_vs_default_mode']:.2e}")
+    for e in engines:
+        e.set_pointwise_mode("f16x3")
+    if "f32" in modes:
+        out["value_mode0_f32"] = {**modes["f32"], "what": "1x1 convolutions on v_mfma_f32_32x32x2_f32 (exact f32 products)"}
+    if "f16" in modes:
+        out["value_mode2_f16"] = {**modes["f16"], "what": "config 5 arithmetic: plain f16 operands, one MFMA per product, f32 "
+                                                          "accumulate; outside the 1e-4 gate by design, never `value`"}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

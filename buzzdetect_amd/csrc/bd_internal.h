@@ -8,16 +8,36 @@
 
 namespace bd {
 
-constexpr int kMelMaxLen = 18;   // longest run of non-zero bins a mel band may have (kept in registers; YAMNet: 17)
+constexpr int kMelMaxLen = 18;   // longest run of non-zero bins a mel band may have (YAMNet: 17)
+constexpr int kMelNonZero = 461; // non-zero entries of the [257,64] YAMNet mel matrix (both graph variants)
+
+// Sparsity pattern of tf.signal.linear_to_mel_weight_matrix(64, 257, 16000, 125, 7500) as baked into the
+// reference's graphs (features.py:50-55): band m is non-zero on bins
+// [kMelStart[m], kMelStart[m] + kMelLen[m]).  Bins 0-4 and 240-256 feed no band.  bd_create checks the
+// matrix it is given against this pattern; the front-end kernel is unrolled over it.
+constexpr int kMelStart[BD_MEL_BANDS] = {
+    5, 5, 6, 7, 9, 10, 11, 12, 13, 14, 16, 17, 18, 20, 21, 23, 25, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 47, 49, 52, 54, 57,
+    60, 63, 66, 69, 72, 76, 79, 83, 87, 90, 95, 99, 103, 108, 112, 117, 122, 127, 133, 138, 144, 150, 156, 162, 169, 176, 183,
+    190, 198, 206, 214, 223};
+constexpr int kMelLen[BD_MEL_BANDS] = {
+    1, 2, 3, 3, 2, 2, 2, 2, 3, 3, 2, 3, 3, 3, 4, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 6, 6,
+    6, 6, 6, 7, 7, 7, 8, 7, 8, 9, 8, 9, 9, 9, 10, 10, 11, 11, 11, 12, 12, 12, 13, 14, 14, 14, 15, 16, 16, 17, 17, 17};
+constexpr int mel_offset(int band) {          // index of band's first weight in FeTables::melw
+    int o = 0;
+    for (int m = 0; m < band; ++m) o += kMelLen[m];
+    return o;
+}
+static_assert(mel_offset(BD_MEL_BANDS) == kMelNonZero, "mel pattern tables disagree");
 
 // Constant tables of the front end, built on the host at bd_create (engine.hip) and kept in
-// device memory; every workgroup stages them into LDS once.
+// device memory.
 struct FeTables {
-    float  hann[BD_STFT_WINDOW];          // periodic Hann, evaluated in float32 like tf.signal.hann_window
+    float  hann[BD_STFT_WINDOW + 16];     // periodic Hann, evaluated in float32 like tf.signal.hann_window; zero past 400
     float2 tw256[256];                    // exp(-2*pi*i*k/256)
     float2 tw512[BD_SPECTRUM_BINS + 1];   // exp(-2*pi*i*k/512), k = 0..256 (+1 pad)
-    int    band_start[BD_MEL_BANDS];      // first non-zero bin of each mel band
-    int    band_len[BD_MEL_BANDS];        // number of consecutive non-zero bins
+    float  melw[kMelNonZero + 3];         // band-major non-zeros: melw[mel_offset(m) + j] = mel[kMelStart[m] + j][m]
+    int    band_start[BD_MEL_BANDS];      // = kMelStart / kMelLen (kept for the radix-4 reference kernel)
+    int    band_len[BD_MEL_BANDS];
     int    max_len;
     int    pad_[3];
     float  band_w[kMelMaxLen][BD_MEL_BANDS];  // band_w[j][m] = mel[band_start[m] + j][m]

@@ -218,27 +218,21 @@ int build_tables(const float* mel, bd::FeTables* t) {
     }
     int max_len = 1;
     for (int m = 0; m < BD_MEL_BANDS; ++m) {
-        int first = -1, last = -1;
+        const int first = bd::kMelStart[m], len = bd::kMelLen[m];
         for (int k = 0; k < BD_SPECTRUM_BINS; ++k) {
             const float w = mel[k * BD_MEL_BANDS + m];
             if (!std::isfinite(w)) return fail(BD_EWEIGHTS, "mel matrix has a non-finite entry");
-            if (w != 0.0f) {
-                if (first < 0) first = k;
-                last = k;
-            }
+            if (w != 0.0f && (k < first || k >= first + len))
+                return fail(BD_EWEIGHTS, "mel matrix has a non-zero outside the 64-band YAMNet filterbank pattern "
+                                         "(linear_to_mel_weight_matrix(64, 257, 16000, 125, 7500)); not a YAMNet front end");
         }
-        if (first < 0) {
-            t->band_start[m] = 0;
-            t->band_len[m] = 0;
-            continue;
-        }
-        const int len = last - first + 1;
-        if (len > bd::kMelMaxLen)
-            return fail(BD_EWEIGHTS, "mel band spans more than 18 spectrum bins; not the 64-band YAMNet filterbank?");
         t->band_start[m] = first;
         t->band_len[m] = len;
         if (len > max_len) max_len = len;
-        for (int j = 0; j < len; ++j) t->band_w[j][m] = mel[(first + j) * BD_MEL_BANDS + m];
+        for (int j = 0; j < len; ++j) {
+            t->band_w[j][m] = mel[(first + j) * BD_MEL_BANDS + m];
+            t->melw[bd::mel_offset(m) + j] = mel[(first + j) * BD_MEL_BANDS + m];
+        }
     }
     t->max_len = max_len;
     return BD_OK;

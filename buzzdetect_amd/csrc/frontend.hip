@@ -3,17 +3,28 @@
 // Restates embedders/yamnet/features.py:22-58 (tf.signal.stft 400/160/512 -> tf.abs ->
 // matmul with the [257,64] mel matrix -> log(x + 0.001)) with pad_waveform (features.py:82-108)
 // folded in as "samples past n_valid read as zero".  Nothing of [T,400] / [T,257] is ever
-// written to HBM: a workgroup stages a run of PCM into LDS, each 64-lane wavefront owns one
-// STFT frame at a time and carries it through
-//   Hann window -> 256-point complex FFT of the even/odd-packed frame (radix-4 Stockham,
-//   4 passes through the wave's own LDS tile) -> real-FFT split -> |X[k]| -> banded mel
-//   reduction (lane m owns band m; every band is a short run of bins) -> logf
-// and writes one coalesced 256-byte row of the [T,64] output.
+// written to HBM.
+//
+// logmel_kernel: one 512-thread workgroup per CU walks groups of 64 STFT frames.
+//   FFT phase   sixteen lanes own a frame (four frames per wavefront, two rounds per group): the frame is
+//               read straight from global memory as 200 packed complex points z[n] = x[2n] + i x[2n+1]
+//               (+56 zeros), Hann-windowed, and transformed as 256 = 16 x 16: DFT-16 over n1 in
+//               registers, twiddle, ONE transpose through the wave's own LDS tile, DFT-16 over n2 in
+//               registers.  The packed spectrum goes through the same tile once more in natural order
+//               so that every lane can pick up the mirrored bins Z[256 - k] of half of its own bins and
+//               split BOTH X[k] and X[256 - k] out of one (Z[k], Z[256 - k]) pair.  |X| lands in a
+//               [64 frames][244] f32 tile.  Wave-level ordering only, no workgroup barrier.
+//   mel phase   lane = frame: each of the eight waves owns a run of mel bands (balanced by non-zeros);
+//               a band is a short run of bins, so its weights are wave-uniform and come in through
+//               scalar loads - 461 v_fmac per 64 frames instead of 18 per frame and lane, and every LDS
+//               read is a conflict-free 16-byte row read.  log() and a [64][64] staging tile follow.
+//   output      coalesced 256-byte rows of the [T,64] log-mel buffer.
 //
 // Algorithmic HBM traffic: 640 B read (160 new samples) + 256 B written per frame.
 #include "bd_internal.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace bd {
 
@@ -56,7 +67,7 @@ __device__ __forceinline__ void dft4(float2& u0, float2& u1, float2& u2, float2&
     u3 = make_float2(b.x - d.x, b.y - d.y);
 }
 
-__global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm, long long n_valid,
+__global__ __launch_bounds__(256, 4) void logmel_r4_kernel(const float* __restrict__ pcm, long long n_valid,
                                                      long long n_frames, float* __restrict__ out,
                                                      const FeTables* __restrict__ tab, unsigned* __restrict__ dbg) {
 #define FE_TS(I) if (dbg && blockIdx.x == 3 && threadIdx.x == 0 && group == blockIdx.x && fi == 1) dbg[I] = (unsigned)__builtin_readcyclecounter();
@@ -206,13 +217,32 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Second formulation of the same transform: 256 = 16 x 16.  Sixteen lanes own one frame (four frames per
-// wavefront), lane n2 holds the 16 packed points z[16 n1 + n2] in registers:
-//   DFT-16 over n1 in registers -> twiddle W256^(n2 k1) -> ONE transpose through LDS -> DFT-16 over n2 in
-//   registers -> Z[k1 + 16 k2] -> natural order in LDS -> real split against Z[256 - k] -> |X| -> LDS ->
-//   banded mel with lane = band (as above), one frame after the other -> logf.
-// Three wave-level sync points per four frames instead of six per frame; same arithmetic definition
-// (results differ from logmel_kernel only by float summation order).
+// The default front end (see the header comment): 16 lanes per frame, 256 = 16 x 16, lane = frame mel.
+namespace fe {
+
+constexpr int kThreads = 512;
+constexpr int kWavesG = 8;
+constexpr int kGroup = 64;             // frames per workgroup pass
+constexpr int kXRow = 36;              // transpose tile: row (fq, k1) = 16 float2 + 16 B of bank padding, in dwords
+constexpr int kXFrame = 16 * kXRow;    // 576
+constexpr int kXWave = 4 * kXFrame;    // 2304 dwords = 9216 B per wave
+constexpr int kZFrame = 2 * 256 + 32;  // natural-order tile: 256 float2 + 128 B so that two frames fill all 64 banks
+constexpr int kMagRow = 244;           // |X| tile row: bins 0..243 (5..239 are used); 244 = 52 mod 64 -> 16-byte row reads of
+                                       // sixteen consecutive lanes cover all 64 banks
+constexpr int kOutRow = 65;
+static_assert(4 * kZFrame <= kXWave, "the natural-order tile reuses the transpose tile");
+
+// mel bands of wave w in the mel phase: [kCut[w], kCut[w + 1]); balanced on (non-zeros + log) per band
+constexpr int kCut[kWavesG + 1] = {0, 13, 24, 33, 42, 49, 55, 60, 64};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 c_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
@@ -245,119 +275,170 @@ __device__ __forceinline__ void dft16(float2 (&x)[16]) {
     for (int r = 0; r < 4; ++r) radix4(a[0][r], a[1][r], a[2][r], a[3][r], x[r], x[r + 4], x[r + 8], x[r + 12]);
 }
 
-__global__ __launch_bounds__(256) void logmel16_kernel(const float* __restrict__ pcm, long long n_valid,
-                                                       long long n_frames, float* __restrict__ out,
-                                                       const FeTables* __restrict__ tab) {
-    constexpr int TZ = 17 * 16;                            // transposed tile: rows of 17 (bank padding)
-    __shared__ __attribute__((aligned(16))) float s_pcm[kGroupSamples];
-    __shared__ __attribute__((aligned(16))) float2 s_t[kWaves][4][TZ];      // transpose, then Z, then |X|
-    __shared__ __attribute__((aligned(16))) float2 s_tw512[256];
+// mel phase of wave W: lane = frame; bands [kCut[W], kCut[W + 1]) over that frame's |X| row
+template <int W>
+__device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, float* __restrict__ out_row,
+                                         const float* __restrict__ melw) {
+    constexpr int b0 = kCut[W], b1 = kCut[W + 1];
+    constexpr int klo = kMelStart[b0] & ~3;
+    constexpr int khi = (kMelStart[b1 - 1] + kMelLen[b1 - 1] + 3) & ~3;
+    float m[khi - klo];
+#pragma unroll
+    for (int q = 0; q < (khi - klo) / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(mag_row + klo + 4 * q);
+        m[4 * q] = v.x;
+        m[4 * q + 1] = v.y;
+        m[4 * q + 2] = v.z;
+        m[4 * q + 3] = v.w;
+    }
+    static_for<b0, b1>([&](auto bi) {
+        constexpr int b = decltype(bi)::value;
+        constexpr int off = mel_offset(b), st = kMelStart[b] - klo;
+        float acc = 0.0f;
+        static_for<0, kMelLen[b]>([&](auto ji) {
+            constexpr int j = decltype(ji)::value;
+            acc = fmaf(m[st + j], melw[off + j], acc);
+        });
+        // acc + 0.001 is in [1e-3, ~1e3]: v_log_f32 (1 ulp, no denormal range) * ln 2
+        out_row[b] = __builtin_amdgcn_logf(acc + 0.001f) * 0.69314718055994531f;
+    });
+}
+
+__global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __restrict__ pcm, int n_valid, int n_frames,
+                                                             float* __restrict__ out,
+                                                             const FeTables* __restrict__ tab) {
+    __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        // 62 464 B
+    __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kXWave];          // 73 728 B
+    __shared__ __attribute__((aligned(16))) float s_out[kGroup * kOutRow];        // 16 640 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int fq = lane >> 4;                              // frame within the wave
-    const int n2 = lane & 15;                              // also k1 after the transpose
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fq = lane >> 4;              // frame of the round
+    const int j16 = lane & 15;             // n2 before the transpose, k1 after it
 
-    s_tw512[tid] = tab->tw512[tid];
-    float2 hann2[13];                                      // Hann taps of z[16 n1 + n2], n1 = 0..12
+    // per-lane constants of the whole kernel
+    float2 hann2[13];                      // Hann taps of z[16 n1 + n2], n1 = 0..12 (zero past sample 400)
 #pragma unroll
     for (int n1 = 0; n1 < 13; ++n1) {
-        const int e = 2 * (16 * n1 + n2);
-        hann2[n1] = e < BD_STFT_WINDOW ? make_float2(tab->hann[e], tab->hann[e + 1]) : make_float2(0.f, 0.f);
+        const int e = 2 * (16 * n1 + j16);
+        hann2[n1] = make_float2(tab->hann[e], tab->hann[e + 1]);
     }
-    float2 tw[15];                                         // W256^(n2 k1), k1 = 1..15
+    float2 tw[15];                         // W256^(n2 k1), k1 = 1..15
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tab->tw256[(n2 * k1) & 255];
-    const int band_start = tab->band_start[lane];
-    const int band_len = tab->band_len[lane];
-    float bw[kMelTaps];
+    for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tab->tw256[(j16 * k1) & 255];
+    float2 tws[8];                         // 0.5 * exp(-2 pi i k / 512), k = k1 + 16 k2, k2 = 0..7 (the 1/2 of the split)
 #pragma unroll
-    for (int j = 0; j < kMelTaps; ++j) bw[j] = j < band_len ? tab->band_w[j][lane] : 0.0f;
-    const int max_len = tab->max_len;
+    for (int k2 = 0; k2 < 8; ++k2) {
+        const float2 t = tab->tw512[j16 + 16 * k2];
+        tws[k2] = make_float2(0.5f * t.x, 0.5f * t.y);
+    }
+    const float* melw = tab->melw;
 
-    float2* const t_mine = s_t[wave][fq];
-    float* const mag_wave = reinterpret_cast<float*>(s_t[wave]);            // [4][2 * TZ] floats, |X| at [f][k]
+    float* const xw = s_x + wave * kXWave;
+    float2* const x_wr = reinterpret_cast<float2*>(xw + fq * kXFrame) + j16;                 // + k1 * (kXRow / 2)
+    const float4* const x_rd = reinterpret_cast<const float4*>(xw + fq * kXFrame + j16 * kXRow);
+    float2* const z_wr = reinterpret_cast<float2*>(xw + fq * kZFrame) + j16;                 // + 16 k2
+    const float2* const z_base = reinterpret_cast<const float2*>(xw + fq * kZFrame);
 
-    const long long n_groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
-    for (long long group = blockIdx.x; group < n_groups; group += gridDim.x) {
-        __syncthreads();
-        const long long base = group * (long long)(kGroupFrames * BD_STFT_HOP);
-        for (int i = tid; i < kGroupSamples; i += 256) {
-            const long long idx = base + i;
-            s_pcm[i] = idx < n_valid ? pcm[idx] : 0.0f;
-        }
-        __syncthreads();
-
-        const int fl = wave * 4 + fq;                                       // frame of this 16-lane group
-        const float* x = s_pcm + fl * BD_STFT_HOP;
-        float2 u[16];
+    const int n_groups = (n_frames + kGroup - 1) / kGroup;
+    for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        // ---------------- FFT phase: this wave's eight frames in two rounds of four ----------------
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            const int fl = wave * 8 + round * 4 + fq;          // frame within the group
+            const int frame = group * kGroup + fl;
+            const int s0 = frame * BD_STFT_HOP + 2 * j16;      // first sample this lane reads
+            float2 u[16];
+            // all of the wave's samples in range (the usual case) -> unguarded 8-byte loads
+            const int last = (group * kGroup + wave * 8 + round * 4 + 3) * BD_STFT_HOP + BD_STFT_WINDOW;
+            if (last <= n_valid) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            if (n1 < 13) {
-                const int e = 2 * (16 * n1 + n2);
-                float2 xv = make_float2(0.f, 0.f);
-                if (e < BD_STFT_WINDOW) xv = *reinterpret_cast<const float2*>(x + e);
-                u[n1] = make_float2(xv.x * hann2[n1].x, xv.y * hann2[n1].y);
+                for (int n1 = 0; n1 < 13; ++n1) {
+                    float2 xv = make_float2(0.f, 0.f);
+                    if (n1 < 12 || j16 < 8) xv = *reinterpret_cast<const float2*>(pcm + s0 + 32 * n1);
+                    u[n1] = make_float2(xv.x * hann2[n1].x, xv.y * hann2[n1].y);
+                }
             } else {
-                u[n1] = make_float2(0.f, 0.f);
-            }
-        }
-        dft16(u);                                                           // over n1 -> k1
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) u[k1] = cmul(u[k1], tw[k1 - 1]);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) t_mine[k1 * 17 + n2] = u[k1];
-        wave_lds_sync();
-#pragma unroll
-        for (int m2 = 0; m2 < 16; ++m2) u[m2] = t_mine[n2 * 17 + m2];       // lane k1 = n2 gathers over n2
-        wave_lds_sync();                                                    // tile is rewritten below
-        dft16(u);                                                           // over n2 -> k2: u[k2] = Z[k1 + 16 k2]
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) t_mine[n2 + 16 * k2] = u[k2];       // natural order
-        wave_lds_sync();
-        float mg[16];
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            const int k = n2 + 16 * k2;
-            const float2 zk = u[k2];
-            const float2 zm = t_mine[(256 - k) & 255];
-            const float ex = 0.5f * (zk.x + zm.x);
-            const float ey = 0.5f * (zk.y - zm.y);
-            const float ox = 0.5f * (zk.y + zm.y);
-            const float oy = -0.5f * (zk.x - zm.x);
-            const float2 t = s_tw512[k];
-            const float xr = ex + (t.x * ox - t.y * oy);
-            const float xi = ey + (t.x * oy + t.y * ox);
-            mg[k2] = sqrtf(xr * xr + xi * xi);
-        }
-        const float nyq = fabsf(u[0].x - u[0].y);                           // meaningful in lane k1 = 0 only
-        wave_lds_sync();                                                    // Z reads done: overwrite with |X|
-        float* mag = mag_wave + fq * (2 * TZ);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) mag[n2 + 16 * k2] = mg[k2];
-        if (n2 == 0) mag[256] = nyq;
-        if (n2 < 7) mag[257 + n2] = 0.0f;                                   // padding read by the fixed-length loop
-        wave_lds_sync();
-
-        // ---- banded mel + log: lane = band, the wave's four frames one after the other ----
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const float* mf = mag_wave + f * (2 * TZ);
-            float acc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kMelTaps; ++j) {
-                if (j < max_len) {
-                    const float m = mf[band_start + j];
-                    if (j < band_len) acc = fmaf(m, bw[j], acc);
+                for (int n1 = 0; n1 < 13; ++n1) {
+                    const int s = s0 + 32 * n1;
+                    const bool in_frame = n1 < 12 || j16 < 8;
+                    const float a = (in_frame && s < n_valid) ? pcm[s] : 0.0f;
+                    const float b = (in_frame && s + 1 < n_valid) ? pcm[s + 1] : 0.0f;
+                    u[n1] = make_float2(a * hann2[n1].x, b * hann2[n1].y);
                 }
             }
-            const long long frame = group * kGroupFrames + wave * 4 + f;
-            if (frame < n_frames) out[frame * BD_MEL_BANDS + lane] = logf(acc + 0.001f);
+            u[13] = u[14] = u[15] = make_float2(0.f, 0.f);
+            dft16(u);                                          // over n1 -> k1
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) u[k1] = cmul(u[k1], tw[k1 - 1]);
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) x_wr[k1 * (kXRow / 2)] = u[k1];
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                      // lane k1 gathers its row over n2
+                const float4 v = x_rd[q];
+                u[2 * q] = make_float2(v.x, v.y);
+                u[2 * q + 1] = make_float2(v.z, v.w);
+            }
+            wave_lds_sync();                                   // the tile is rewritten below
+            dft16(u);                                          // over n2 -> k2: u[k2] = Z[k1 + 16 k2]
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) z_wr[16 * k2] = u[k2];
+            wave_lds_sync();
+            // ---- real-FFT split: the pair (Z[k], Z[256 - k]) gives X[k] and X[256 - k]; this lane takes its bins
+            //      k = k1 + 16 k2 with k2 < 8, the lane holding 16 - k1 takes the other half of the pairs ----
+            float* const mrow = s_mag + fl * kMagRow;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const float2 zk = u[k2];
+                const float2 zm = z_base[(256 - j16 - 16 * k2) & 255];
+                const float ex = zk.x + zm.x, ey = zk.y - zm.y;            // 2 E[k]
+                const float ox = zk.y + zm.y, oy = zm.x - zk.x;            // 2 O[k]
+                const float2 t = tws[k2];
+                const float a = t.x * ox - t.y * oy, b = t.x * oy + t.y * ox;     // W^k O[k]
+                const float pr = 0.5f * ex + a, pi = 0.5f * ey + b;        // X[k]
+                const float qr = 0.5f * ex - a, qi = 0.5f * ey - b;        // conj(X[256 - k])
+                // v_sqrt_f32 (1 ulp): |X| only feeds log(mel + 0.001)
+                mrow[j16 + 16 * k2] = __builtin_amdgcn_sqrtf(pr * pr + pi * pi);
+                if (k2 > 0) mrow[256 - j16 - 16 * k2] = __builtin_amdgcn_sqrtf(qr * qr + qi * qi);   // <= 240: inside the row
+            }
+            // bin 128 is its own mirror: X[128] = conj(Z[128])
+            if (j16 == 0) mrow[128] = __builtin_amdgcn_sqrtf(u[8].x * u[8].x + u[8].y * u[8].y);
+            wave_lds_sync();                                   // mirror reads retire before the next round's transpose
         }
-        wave_lds_sync();
+        __syncthreads();
+
+        // ---------------- mel phase: lane = frame, wave = run of bands ----------------
+        {
+            const float* mag_row = s_mag + lane * kMagRow;
+            float* out_row = s_out + lane * kOutRow;
+            switch (wave) {
+                case 0: mel_wave<0>(mag_row, out_row, melw); break;
+                case 1: mel_wave<1>(mag_row, out_row, melw); break;
+                case 2: mel_wave<2>(mag_row, out_row, melw); break;
+                case 3: mel_wave<3>(mag_row, out_row, melw); break;
+                case 4: mel_wave<4>(mag_row, out_row, melw); break;
+                case 5: mel_wave<5>(mag_row, out_row, melw); break;
+                case 6: mel_wave<6>(mag_row, out_row, melw); break;
+                default: mel_wave<7>(mag_row, out_row, melw); break;
+            }
+        }
+        __syncthreads();
+
+        // ---------------- output: 64 rows of 256 bytes ----------------
+#pragma unroll
+        for (int q = 0; q < kGroup * BD_MEL_BANDS / kThreads; ++q) {
+            const int i = tid + kThreads * q;
+            const int fl = i >> 6, band = i & 63;
+            const int frame = group * kGroup + fl;
+            if (frame < n_frames) out[(long long)frame * BD_MEL_BANDS + band] = s_out[fl * kOutRow + band];
+        }
     }
 }
+
+}  // namespace fe
 
 __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ logmel, long long n_windows,
                                                       int patch_step, float* __restrict__ patches) {
@@ -426,26 +507,17 @@ void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
                    const FeTables* tables, hipStream_t stream, int variant) {
     if (n_frames <= 0) return;
-    const int64_t groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
-    const int grid = (int)(groups < 4096 ? groups : 4096);
-    if (variant == 1) {
-        hipLaunchKernelGGL(logmel16_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
-                           (long long)n_frames, logmel, tables);
+    if (variant == 1) {          // radix-4 x 4 passes, one wave per frame (reference formulation)
+        const int64_t groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
+        const int grid = (int)(groups < 4096 ? groups : 4096);
+        hipLaunchKernelGGL(logmel_r4_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
+                           (long long)n_frames, logmel, tables, (unsigned*)nullptr);
         return;
     }
-    static unsigned* dbg = nullptr;           // developer aid: BD_FE_TRACE=1 prints a per-frame phase trace
-    static int shots = 0;
-    if (!dbg && getenv("BD_FE_TRACE")) (void)hipMalloc(&dbg, 64);
-    hipLaunchKernelGGL(logmel_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
-                       (long long)n_frames, logmel, tables, dbg);
-    if (dbg) {
-        (void)hipStreamSynchronize(stream);
-        unsigned h[8];
-        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-        if (++shots == 4)
-            fprintf(stderr, "[trace] front end, one frame of one wave (4 waves/SIMD), cycles: pass 1 %u | passes 2-4 %u | split + magnitude %u | mel %u | log + store %u | total %u\n",
-                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[5] - h[0]);
-    }
+    const int64_t groups = (n_frames + fe::kGroup - 1) / fe::kGroup;
+    const int grid = (int)(groups < 256 ? groups : 256);      // one 152 KB workgroup per CU
+    hipLaunchKernelGGL(fe::logmel_kernel, dim3(grid), dim3(fe::kThreads), 0, stream, pcm, (int)n_valid, (int)n_frames,
+                       logmel, tables);
 }
 
 void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,

@@ -21,8 +21,9 @@ STFT_HOP = 160
 
 
 def hop_samples(framehop_s: float) -> int:
-    """``tf.cast(patch_hop_seconds * sample_rate, tf.int32)`` (features.py:99): truncation."""
-    return int(framehop_s * 16000.0)
+    """``tf.cast(patch_hop_seconds * sample_rate, tf.int32)`` (features.py:99): the Python-float product becomes
+    a float32 tensor first, then truncates (0.96 * 0.35 * 16000 = 5375.999... -> 5376.0f -> 5376, not 5375)."""
+    return int(np.float32(framehop_s * 16000.0))
 
 
 def patch_step(framehop_s: float) -> int:
@@ -230,7 +231,8 @@ class HipEngine:
                                             self._stream().cuda_stream))
         return out
 
-    def run(self, samples, hop: int, step: int, want_embeddings: bool, want_logits: bool):
+    def run(self, samples, hop: int, step: int, want_embeddings: bool, want_logits: bool,
+            out: Optional[torch.Tensor] = None):
         x = self.to_device(samples)
         n = x.numel()
         w = self.num_windows(n, hop, step)
@@ -243,7 +245,14 @@ class HipEngine:
             if want_logits:
                 if self.n_classes == 0:
                     raise RuntimeError("engine was created without a classifier head")
-                logits = torch.empty((w, self.n_classes), dtype=torch.float32, device=self.device)
+                if out is None:
+                    logits = torch.empty((w, self.n_classes), dtype=torch.float32, device=self.device)
+                else:       # caller-owned rows (e.g. a slice of a per-recording buffer that is gathered later)
+                    if (tuple(out.shape) != (w, self.n_classes) or out.dtype != torch.float32 or
+                            out.device != self.device or not out.is_contiguous() or out.data_ptr() % 16):
+                        raise ValueError(f"out must be a contiguous, 16-byte aligned float32 [{w}, {self.n_classes}] "
+                                         f"tensor on {self.device}")
+                    logits = out
                 _lib.check(self._lib.bd_predict(self._handle, x.data_ptr(), n, hop, step, ws.data_ptr(), ws.numel(),
                                                 emb.data_ptr() if emb is not None else None, logits.data_ptr(),
                                                 stream.cuda_stream))
@@ -289,8 +298,9 @@ class HipEngine:
         emb, _ = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), True, False)
         return DeviceResult(emb, self._stream())
 
-    def predict(self, samples, framehop_s: float) -> DeviceResult:
-        _, logits = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), False, True)
+    def predict(self, samples, framehop_s: float, out: Optional[torch.Tensor] = None) -> DeviceResult:
+        """``out``: optional caller-owned ``[W, n_classes]`` device rows to write the logits into."""
+        _, logits = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), False, True, out=out)
         return DeviceResult(logits, self._stream())
 
     def stage_tap(self, samples, hop: int, step: int, stage: int, windows: int) -> torch.Tensor:

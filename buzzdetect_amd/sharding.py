@@ -9,7 +9,8 @@ crosses ranks; weights are replicated.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -62,3 +63,84 @@ def interleave_round_robin(per_rank: Sequence[Sequence[torch.Tensor]]) -> List[t
     for i in range(total):
         out.append(per_rank[i % world][i // world])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Strong scaling over a fixed set of recordings (config 4): recordings go to ranks round-robin, one
+# recording per rank per ROUND; what is left when the count is not a multiple of the world size is dealt
+# at chunk (batch) level so that no rank idles through a whole recording.  Every round ends in ONE
+# gather of equal-sized row blocks whose size is known on the host: no count exchange, no host sync.
+
+@dataclass(frozen=True)
+class Unit:
+    """One launch set: batch ``batch`` (``windows`` rows) of recording ``file``."""
+    file: int
+    batch: int
+    windows: int
+
+
+@dataclass(frozen=True)
+class Round:
+    units: Tuple[Tuple[Unit, ...], ...]     # units[rank] = what that rank runs this round, in order
+    rows: int                               # rows every rank contributes to the gather (padded)
+
+
+ROW_ALIGN = 4      # a unit's rows start on a multiple of 4 rows: 4 x 13 f32 = 208 B keeps every block 16-byte aligned
+
+
+def unit_offsets(units: Sequence[Unit]) -> List[int]:
+    """Row offset of each unit inside its rank's block of a round (+ the block's used length as last item)."""
+    at, out = 0, []
+    for u in units:
+        out.append(at)
+        at += (u.windows + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+    return out + [at]
+
+
+def plan_rounds(n_files: int, batch_windows: Sequence[int], world_size: int) -> List[Round]:
+    """``batch_windows`` = window counts of one recording's batches (config 2: 1024, 1024, 1024, 678)."""
+    if world_size < 1 or n_files < 0 or not batch_windows:
+        raise ValueError("plan_rounds: bad argument")
+    per_file = tuple(int(w) for w in batch_windows)
+    rounds: List[Round] = []
+    full = n_files // world_size
+    for g in range(full):
+        units = tuple(tuple(Unit(g * world_size + r, b, w) for b, w in enumerate(per_file))
+                      for r in range(world_size))
+        rounds.append(Round(units, unit_offsets(units[0])[-1]))
+    left = [Unit(f, b, w) for f in range(full * world_size, n_files) for b, w in enumerate(per_file)]
+    if left:
+        units = tuple(tuple(left[r::world_size]) for r in range(world_size))
+        rounds.append(Round(units, max(unit_offsets(us)[-1] for us in units)))
+    return rounds
+
+
+def gather_round(local: torch.Tensor, rows: int, dst: int = 0, out: Optional[torch.Tensor] = None, group=None,
+                 async_op: bool = False):
+    """Gather every rank's ``[rows, C]`` block (``local`` may hold fewer rows: the rest of the block is
+    whatever ``local``'s buffer holds — callers hand in a ``rows``-sized buffer) to ``dst``.
+    Returns ``(out [world, rows, C] on dst / None elsewhere, work handle or None)``."""
+    if local.shape[0] != rows:
+        raise ValueError(f"gather_round: block has {local.shape[0]} rows, the round was planned with {rows}")
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local.unsqueeze(0), None
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if dist.get_rank(group) == dst:
+        if out is None:
+            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        work = dist.gather(local, [out[r] for r in range(world)], dst=dst, group=group, async_op=async_op)
+        return out, work
+    work = dist.gather(local, None, dst=dst, group=group, async_op=async_op)
+    return None, work
+
+
+def assemble_files(rounds: Sequence[Round], gathered: Sequence[torch.Tensor], n_files: int) -> List[torch.Tensor]:
+    """On the destination rank: per-recording ``[W, C]`` rows in recording order from the per-round
+    ``[world, rows, C]`` gathers."""
+    parts: List[List[Tuple[int, torch.Tensor]]] = [[] for _ in range(n_files)]
+    for rnd, g in zip(rounds, gathered):
+        for r, units in enumerate(rnd.units):
+            for u, at in zip(units, unit_offsets(units)):
+                parts[u.file].append((u.batch, g[r, at:at + u.windows]))
+    return [torch.cat([t for _, t in sorted(p, key=lambda bt: bt[0])]) if p else torch.empty(0) for p in parts]

@@ -43,6 +43,12 @@ def test_hop_derivation():
     assert O.patch_step(1.0) == 96 and O.patch_step(0.5) == 48
     # free hop (Keras-3 yamnet): pad hop and patch step need not agree
     assert O.hop_samples(0.3) == 4608 and O.patch_step(0.3) == 29
+    # the product is rounded to float32 before the truncating cast (tf.cast of a Python float):
+    # 0.96 * p * 16000 = 5375.999..., 10751.999..., 14591.999... in float64
+    assert [O.hop_samples(p) for p in (0.35, 0.7, 0.95)] == [5376, 10752, 14592]
+    from buzzdetect_amd import engine as E
+    for p in (1.0, 0.5, 0.3, 0.35, 0.7, 0.95, 0.1, 0.25, 0.9):
+        assert E.hop_samples(0.96 * p) == O.hop_samples(p) and E.patch_step(0.96 * p) == O.patch_step(p)
 
 
 def test_mel_constant_is_the_graph_constant():

@@ -73,3 +73,96 @@ def test_gather_rows_world_size_2_gloo(tmp_path):
 def test_gather_rows_single_process_is_identity():
     t = torch.arange(26.0).reshape(2, 13)
     assert sharding.gather_rows(t)[0] is t
+
+
+# ---------------------------------------------------------------------------------------------------
+# strong scaling over a fixed set of recordings: round plan + one fixed-size gather per round
+def test_plan_rounds_covers_every_batch_once():
+    per_file = [1024, 1024, 1024, 678]
+    for n_files, world in ((20, 8), (20, 3), (8, 8), (3, 8), (1, 2), (0, 4), (1000, 8)):
+        rounds = sharding.plan_rounds(n_files, per_file, world)
+        seen = sorted((u.file, u.batch) for rnd in rounds for us in rnd.units for u in us)
+        assert seen == [(f, b) for f in range(n_files) for b in range(4)]
+        for rnd in rounds:
+            assert len(rnd.units) == world
+            for us in rnd.units:
+                offs = sharding.unit_offsets(us)
+                assert all(o % sharding.ROW_ALIGN == 0 for o in offs) and offs[-1] <= rnd.rows
+        full = n_files // world
+        for g in range(full):                       # whole recordings: recording g*world + r on rank r
+            for r in range(world):
+                assert [(u.file, u.batch) for u in rounds[g].units[r]] == [(g * world + r, b) for b in range(4)]
+            assert rounds[g].rows == 3752           # 3750 rows, blocks padded to 4-row boundaries
+    assert len(sharding.plan_rounds(1000, per_file, 8)) == 125          # config 4: 125 rounds, no remainder
+    # the remainder is dealt batch by batch, so no rank idles through a whole recording
+    last = sharding.plan_rounds(20, per_file, 8)[-1]
+    assert [len(us) for us in last.units] == [2] * 8
+
+
+def _worker_rounds(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        per_file, n_files = [5, 5, 3], 5                    # 2 full rounds + a remainder dealt per batch
+        rounds = sharding.plan_rounds(n_files, per_file, world)
+        gathered = []
+        for rnd in rounds:
+            block = torch.full((rnd.rows, 13), -1.0)
+            mine = rnd.units[rank]
+            for u, at in zip(mine, sharding.unit_offsets(mine)):    # "predict": row value = file*100 + batch*10 + row
+                block[at:at + u.windows] = (u.file * 100 + u.batch * 10 + torch.arange(u.windows, dtype=torch.float32))[:, None]
+            g, work = sharding.gather_round(block, rnd.rows, dst=0)
+            assert work is None
+            if rank == 0:
+                assert g.shape == (world, rnd.rows, 13)
+                gathered.append(g)
+            else:
+                assert g is None
+        if rank == 0:
+            files = sharding.assemble_files(rounds, gathered, n_files)
+            for f, t in enumerate(files):
+                want = torch.cat([f * 100 + b * 10 + torch.arange(w, dtype=torch.float32) for b, w in enumerate(per_file)])
+                assert t.shape == (13, 13) and torch.equal(t[:, 0], want) and torch.equal(t[:, 12], want)
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+        with pytest.raises(ValueError):
+            sharding.gather_round(torch.zeros(3, 13), 4)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_once_per_round_world_size_2_gloo(tmp_path):
+    mp.spawn(_worker_rounds, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell must start N child ranks itself (and never exec)."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls["cmd"], calls["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("BD_BENCH_REHEARSAL", "1")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    assert bench.main() == 7                               # the children's exit code is handed back
+    cmd = calls["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # without the rehearsal switch a box with fewer GPUs than ranks is refused before anything is started
+    monkeypatch.delenv("BD_BENCH_REHEARSAL")
+    calls.clear()
+    assert bench.main() == 2 and not calls
