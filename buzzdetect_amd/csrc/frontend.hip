@@ -243,189 +243,353 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 c_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+// Complex arithmetic on packed f32 pairs (re, im) = one 64-bit register pair.  + - * on v2f compile to v_pk_add /
+// v_pk_mul; the forms that swap or negate a half use the VOP3P op_sel / neg modifiers, which the compiler does not
+// derive from scalar code (it answered the float2 version of this kernel with ~130 v_mov per four frames).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void radix4(float2 u0, float2 u1, float2 u2, float2 u3, float2& y0, float2& y1,
-                                       float2& y2, float2& y3) {
-    const float2 s0 = c_add(u0, u2), s1 = c_sub(u0, u2), s2 = c_add(u1, u3), s3 = c_mi(c_sub(u1, u3));
-    y0 = c_add(s0, s2);
-    y1 = c_add(s1, s3);
-    y2 = c_sub(s0, s2);
-    y3 = c_sub(s1, s3);
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b) {      // a + (-i) b = (a.x + b.y, a.y - b.x)
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f sub_mi(v2f a, v2f b) {      // a - (-i) b = (a.x - b.y, a.y + b.x)
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a * b as two instructions: cmul1 = (-a.y b.y, a.y b.x), cmul2 = (a.x b.x, a.x b.y) + that.  Callers issue the first
+// halves of several independent products before the second halves (the second waits on the first otherwise, and the
+// compiler pads a dependent pair of asm statements with s_nop).  _v: b in vector registers, _s: b wave-uniform.
+__device__ __forceinline__ v2f cmul1_v(v2f a, v2f b) {
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ v2f cmul2_v(v2f a, v2f b, v2f t) {
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f cmul1_s(v2f a, v2f b) {
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "s"(b));
+    return t;
+}
+__device__ __forceinline__ v2f cmul2_s(v2f a, v2f b, v2f t) {
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "s"(b), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {    // a + conj(b) = (a.x + b.x, a.y - b.y)
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f odd_part(v2f a, v2f b) {    // -i (a - conj(b)) = (a.y + b.y, b.x - a.x)
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f fma_s(v2f a, v2f s, v2f c) {        // a * s + c, s wave-uniform
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(s), "v"(c));
+    return d;
+}
+__device__ __forceinline__ v2f fms_s(v2f a, v2f s, v2f c) {        // a * s - c
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "s"(s), "v"(c));
+    return d;
+}
+
+// forward DFT-4; with U2MI the third input is given as w where u2 = -i w (a folded W16^4 twiddle)
+template <bool U2MI = false>
+__device__ __forceinline__ void radix4(v2f u0, v2f u1, v2f u2, v2f u3, v2f& y0, v2f& y1, v2f& y2, v2f& y3) {
+    const v2f s0 = U2MI ? add_mi(u0, u2) : u0 + u2;
+    const v2f s1 = U2MI ? sub_mi(u0, u2) : u0 - u2;
+    const v2f s2 = u1 + u3, d3 = u1 - u3;
+    y0 = s0 + s2;
+    y2 = s0 - s2;
+    y1 = add_mi(s1, d3);
+    y3 = sub_mi(s1, d3);
 }
 
 // in-place forward DFT of 16 points, natural order in and out (two radix-4 stages in registers)
-__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+__device__ __forceinline__ void dft16(v2f (&x)[16]) {
     constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f, H = 0.70710678118654752f;
-    float2 a[4][4];
+    const v2f W1 = {C, -S}, W2 = {H, -H}, W3 = {S, -C}, W6 = {-H, -H}, W9 = {-C, S};
+    v2f a[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) radix4(x[q], x[4 + q], x[8 + q], x[12 + q], a[q][0], a[q][1], a[q][2], a[q][3]);
-    a[1][1] = cmul(a[1][1], make_float2(C, -S));     // W16^1
-    a[1][2] = cmul(a[1][2], make_float2(H, -H));     // W16^2
-    a[1][3] = cmul(a[1][3], make_float2(S, -C));     // W16^3
-    a[2][1] = cmul(a[2][1], make_float2(H, -H));     // W16^2
-    a[2][2] = c_mi(a[2][2]);                         // W16^4 = -i
-    a[2][3] = cmul(a[2][3], make_float2(-H, -H));    // W16^6
-    a[3][1] = cmul(a[3][1], make_float2(S, -C));     // W16^3
-    a[3][2] = cmul(a[3][2], make_float2(-H, -H));    // W16^6
-    a[3][3] = cmul(a[3][3], make_float2(-C, S));     // W16^9
-#pragma unroll
-    for (int r = 0; r < 4; ++r) radix4(a[0][r], a[1][r], a[2][r], a[3][r], x[r], x[r + 4], x[r + 8], x[r + 12]);
+    //  a[2][2] * W16^4 = -i a[2][2]: folded into the second stage (U2MI)
+    const v2f t11 = cmul1_s(a[1][1], W1), t12 = cmul1_s(a[1][2], W2), t13 = cmul1_s(a[1][3], W3), t21 = cmul1_s(a[2][1], W2);
+    const v2f t23 = cmul1_s(a[2][3], W6), t31 = cmul1_s(a[3][1], W3), t32 = cmul1_s(a[3][2], W6), t33 = cmul1_s(a[3][3], W9);
+    a[1][1] = cmul2_s(a[1][1], W1, t11);
+    a[1][2] = cmul2_s(a[1][2], W2, t12);
+    a[1][3] = cmul2_s(a[1][3], W3, t13);
+    a[2][1] = cmul2_s(a[2][1], W2, t21);
+    a[2][3] = cmul2_s(a[2][3], W6, t23);
+    a[3][1] = cmul2_s(a[3][1], W3, t31);
+    a[3][2] = cmul2_s(a[3][2], W6, t32);
+    a[3][3] = cmul2_s(a[3][3], W9, t33);
+    radix4(a[0][0], a[1][0], a[2][0], a[3][0], x[0], x[4], x[8], x[12]);
+    radix4(a[0][1], a[1][1], a[2][1], a[3][1], x[1], x[5], x[9], x[13]);
+    radix4<true>(a[0][2], a[1][2], a[2][2], a[3][2], x[2], x[6], x[10], x[14]);
+    radix4(a[0][3], a[1][3], a[2][3], a[3][3], x[3], x[7], x[11], x[15]);
 }
 
-// mel phase of wave W: lane = frame; bands [kCut[W], kCut[W + 1]) over that frame's |X| row
-template <int W>
-__device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, float* __restrict__ out_row,
-                                         const float* __restrict__ melw) {
-    constexpr int b0 = kCut[W], b1 = kCut[W + 1];
-    constexpr int klo = kMelStart[b0] & ~3;
-    constexpr int khi = (kMelStart[b1 - 1] + kMelLen[b1 - 1] + 3) & ~3;
-    float m[khi - klo];
-#pragma unroll
-    for (int q = 0; q < (khi - klo) / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(mag_row + klo + 4 * q);
-        m[4 * q] = v.x;
-        m[4 * q + 1] = v.y;
-        m[4 * q + 2] = v.z;
-        m[4 * q + 3] = v.w;
-    }
-    static_for<b0, b1>([&](auto bi) {
+__device__ __forceinline__ unsigned lds_addr(const void* p) {      // byte address inside the workgroup's LDS
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int OFFSET>       // the caller waits (s_waitcnt lgkmcnt) before using the value: the compiler does not track it
+__device__ __forceinline__ v4f lds_read128(unsigned addr) {
+    v4f v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
+    return v;
+}
+
+// after the s_waitcnt that covers an lds_read128: makes every later use of the value depend on a statement the compiler
+// keeps behind that wait (it may otherwise move plain arithmetic on the register above the wait)
+__device__ __forceinline__ v4f lds_landed(v4f v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }   // a wave's DS operations execute in order
+
+// mel phase of wave W: lane = frame; bands [kCut[W], kCut[W + 1]) over that frame's |X| row.  The weights are the same
+// for every lane: they sit in LDS (s_melw, band-major) and arrive as broadcast 16-byte reads in the same queue
+// as the |X| row, one wait for all of them (scalar loads would each need their own lgkmcnt(0) drain).
+template <int B0, int B1, int KLO>       // bands [B0, B1) from the |X| registers m[] (m[0] = bin KLO)
+__device__ __forceinline__ void mel_bands(const float* __restrict__ m, float* __restrict__ out_row, unsigned melw_addr) {
+    constexpr int wlo = mel_offset(B0) & ~3, whi = (mel_offset(B1) + 3) & ~3;
+    v4f w4[(whi - wlo) / 4];
+    static_for<0, (whi - wlo) / 4>([&](auto qi) { w4[decltype(qi)::value] = lds_read128<16 * decltype(qi)::value>(melw_addr + 4 * wlo); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<0, (whi - wlo) / 4>([&](auto qi) { w4[decltype(qi)::value] = lds_landed(w4[decltype(qi)::value]); });
+    const float* w = reinterpret_cast<const float*>(w4);
+    static_for<B0, B1>([&](auto bi) {
         constexpr int b = decltype(bi)::value;
-        constexpr int off = mel_offset(b), st = kMelStart[b] - klo;
+        constexpr int off = mel_offset(b) - wlo, st = kMelStart[b] - KLO;
         float acc = 0.0f;
         static_for<0, kMelLen[b]>([&](auto ji) {
             constexpr int j = decltype(ji)::value;
-            acc = fmaf(m[st + j], melw[off + j], acc);
+            acc = fmaf(m[st + j], w[off + j], acc);
         });
         // acc + 0.001 is in [1e-3, ~1e3]: v_log_f32 (1 ulp, no denormal range) * ln 2
         out_row[b] = __builtin_amdgcn_logf(acc + 0.001f) * 0.69314718055994531f;
     });
 }
 
+template <int W>
+__device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, float* __restrict__ out_row,
+                                         const float* __restrict__ s_melw) {
+    constexpr int b0 = kCut[W], b1 = kCut[W + 1], bm = (b0 + b1 + 1) / 2;
+    constexpr int klo = kMelStart[b0] & ~3;
+    constexpr int khi = (kMelStart[b1 - 1] + kMelLen[b1 - 1] + 3) & ~3;
+    v4f m4[(khi - klo) / 4];
+    // ds_read_b128 by hand: the compiler narrows float4 loads to the components that are used and then only
+    // knows 8-byte alignment (ds_read2_b64: twice the LDS cycles and bank conflicts on the row stride)
+    const unsigned m_addr = lds_addr(mag_row + klo), w_addr = lds_addr(s_melw);
+    static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_read128<16 * decltype(qi)::value>(m_addr); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_landed(m4[decltype(qi)::value]); });
+    const float* m = reinterpret_cast<const float*>(m4);
+    // the weights in two halves: all of them at once would not fit the register file beside the FFT phase's constants
+    mel_bands<b0, bm, klo>(m, out_row, w_addr);
+    mel_bands<bm, b1, klo>(m, out_row, w_addr);
+}
+
+// BD_FE_TRACE (tools/fe_trace.hip only): s_memtime stamps of two waves of one workgroup, second group it handles
+#ifdef BD_FE_TRACE
+#define FE_TRACE_ARG , unsigned long long* __restrict__ stamps
+#define FE_STAMP(I)                                                                                        \
+    if (stamps && blockIdx.x == 5 && group == (int)(blockIdx.x + gridDim.x) && lane == 0 && (wave == 0 || wave == 7)) \
+        stamps[(wave ? 32 : 0) + (I)] = __builtin_amdgcn_s_memtime();
+#else
+#define FE_TRACE_ARG
+#define FE_STAMP(I)
+#endif
+
 __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __restrict__ pcm, int n_valid, int n_frames,
                                                              float* __restrict__ out,
-                                                             const FeTables* __restrict__ tab) {
+                                                             const FeTables* __restrict__ tab FE_TRACE_ARG) {
     __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        // 62 464 B
     __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kXWave];          // 73 728 B
     __shared__ __attribute__((aligned(16))) float s_out[kGroup * kOutRow];        // 16 640 B
+    __shared__ __attribute__((aligned(16))) float s_melw[kMelNonZero + 3];        //  1 856 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < kMelNonZero + 3) s_melw[tid] = tab->melw[tid];      // visible to all after the first barrier
     const int fq = lane >> 4;              // frame of the round
     const int j16 = lane & 15;             // n2 before the transpose, k1 after it
 
     // per-lane constants of the whole kernel
-    float2 hann2[13];                      // Hann taps of z[16 n1 + n2], n1 = 0..12 (zero past sample 400)
+    v2f hann2[13];                         // Hann taps of z[16 n1 + n2], n1 = 0..12 (zero past sample 400)
 #pragma unroll
     for (int n1 = 0; n1 < 13; ++n1) {
         const int e = 2 * (16 * n1 + j16);
-        hann2[n1] = make_float2(tab->hann[e], tab->hann[e + 1]);
+        hann2[n1] = v2f{tab->hann[e], tab->hann[e + 1]};
     }
-    float2 tw[15];                         // W256^(n2 k1), k1 = 1..15
+    v2f tw[15];                            // W256^(n2 k1), k1 = 1..15
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) tw[k1 - 1] = tab->tw256[(j16 * k1) & 255];
-    float2 tws[8];                         // 0.5 * exp(-2 pi i k / 512), k = k1 + 16 k2, k2 = 0..7 (the 1/2 of the split)
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const float2 t = tab->tw256[(j16 * k1) & 255];
+        tw[k1 - 1] = v2f{t.x, t.y};
+    }
+    v2f tws[8];                            // 0.5 * exp(-2 pi i k / 512), k = k1 + 16 k2, k2 = 0..7 (the 1/2 of the split)
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
         const float2 t = tab->tw512[j16 + 16 * k2];
-        tws[k2] = make_float2(0.5f * t.x, 0.5f * t.y);
+        tws[k2] = v2f{0.5f * t.x, 0.5f * t.y};
     }
-    const float* melw = tab->melw;
+    const v2f kHalf = {0.5f, 0.5f};
 
     float* const xw = s_x + wave * kXWave;
-    float2* const x_wr = reinterpret_cast<float2*>(xw + fq * kXFrame) + j16;                 // + k1 * (kXRow / 2)
+    v2f* const x_wr = reinterpret_cast<v2f*>(xw + fq * kXFrame) + j16;                       // + k1 * (kXRow / 2)
     const float4* const x_rd = reinterpret_cast<const float4*>(xw + fq * kXFrame + j16 * kXRow);
-    float2* const z_wr = reinterpret_cast<float2*>(xw + fq * kZFrame) + j16;                 // + 16 k2
-    const float2* const z_base = reinterpret_cast<const float2*>(xw + fq * kZFrame);
+    v2f* const z_wr = reinterpret_cast<v2f*>(xw + fq * kZFrame) + j16;                       // + 16 k2
+    const v2f* const z_base = reinterpret_cast<const v2f*>(xw + fq * kZFrame);
+    // mirrored bin of (k1, k2): (256 - k1 - 16 k2) & 255 = zm0 - 16 k2 for k2 >= 1; for k2 = 0 it is 256 - k1 (k1 = 0: bin 0)
+    const int zm0 = j16 ? 256 - j16 : 128;     // (k1 = 0: the pair of bin 0 feeds no mel band; read something finite)
+    const int zm1 = 240 - j16;
 
     const int n_groups = (n_frames + kGroup - 1) / kGroup;
+
+    // PCM goes through a buffer resource whose size is n_valid samples: a dword past the end reads as zero, which
+    // IS pad_waveform's zero padding, with no bounds code and no second code path.  Lanes whose thirteenth point
+    // lies past sample 400 of the frame (n2 >= 8) read from an offset beyond any buffer instead: zero as well.
+    const __amdgpu_buffer_rsrc_t pcm_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm), 0, n_valid * 4, 0x00020000);
+    const int off12 = j16 < 8 ? 12 * 128 : 0x7f000000;        // byte offset of the n1 = 12 point relative to the lane's first
+    // the 13 packed points of this lane for round `round` of group `g`
+    auto load_round = [&](v2f (&raw)[13], int g, int round) {
+        const int frame = g * kGroup + wave * 8 + round * 4 + fq;
+        const int byte0 = (frame * BD_STFT_HOP + 2 * j16) * 4;
+#pragma unroll
+        for (int n1 = 0; n1 < 12; ++n1)
+            raw[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(pcm_rsrc, byte0 + 128 * n1, 0, 0));
+        raw[12] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(pcm_rsrc, byte0 + off12, 0, 0));
+    };
+    v2f raw[13];
+    if ((int)blockIdx.x < n_groups) load_round(raw, blockIdx.x, 0);
     for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
         // ---------------- FFT phase: this wave's eight frames in two rounds of four ----------------
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
             const int fl = wave * 8 + round * 4 + fq;          // frame within the group
-            const int frame = group * kGroup + fl;
-            const int s0 = frame * BD_STFT_HOP + 2 * j16;      // first sample this lane reads
-            float2 u[16];
-            // all of the wave's samples in range (the usual case) -> unguarded 8-byte loads
-            const int last = (group * kGroup + wave * 8 + round * 4 + 3) * BD_STFT_HOP + BD_STFT_WINDOW;
-            if (last <= n_valid) {
+            v2f u[16];
+            FE_STAMP(round * 8 + 0)
 #pragma unroll
-                for (int n1 = 0; n1 < 13; ++n1) {
-                    float2 xv = make_float2(0.f, 0.f);
-                    if (n1 < 12 || j16 < 8) xv = *reinterpret_cast<const float2*>(pcm + s0 + 32 * n1);
-                    u[n1] = make_float2(xv.x * hann2[n1].x, xv.y * hann2[n1].y);
-                }
-            } else {
-#pragma unroll
-                for (int n1 = 0; n1 < 13; ++n1) {
-                    const int s = s0 + 32 * n1;
-                    const bool in_frame = n1 < 12 || j16 < 8;
-                    const float a = (in_frame && s < n_valid) ? pcm[s] : 0.0f;
-                    const float b = (in_frame && s + 1 < n_valid) ? pcm[s + 1] : 0.0f;
-                    u[n1] = make_float2(a * hann2[n1].x, b * hann2[n1].y);
-                }
+            for (int n1 = 0; n1 < 13; ++n1) u[n1] = raw[n1] * hann2[n1];
+            u[13] = u[14] = u[15] = v2f{0.f, 0.f};
+            {   // request the next round's samples now: they arrive under this round's arithmetic
+                const int ng = round == 0 ? group : group + (int)gridDim.x;
+                if (ng < n_groups) load_round(raw, ng, round ^ 1);
             }
-            u[13] = u[14] = u[15] = make_float2(0.f, 0.f);
+            FE_STAMP(round * 8 + 1)
             dft16(u);                                          // over n1 -> k1
 #pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) u[k1] = cmul(u[k1], tw[k1 - 1]);
+            for (int kb = 1; kb < 16; kb += 5) {               // five independent products at a time
+                v2f t[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) t[i] = cmul1_v(u[kb + i], tw[kb + i - 1]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) u[kb + i] = cmul2_v(u[kb + i], tw[kb + i - 1], t[i]);
+            }
+            FE_STAMP(round * 8 + 2)
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) x_wr[k1 * (kXRow / 2)] = u[k1];
-            wave_lds_sync();
+            lds_order();
 #pragma unroll
             for (int q = 0; q < 8; ++q) {                      // lane k1 gathers its row over n2
                 const float4 v = x_rd[q];
-                u[2 * q] = make_float2(v.x, v.y);
-                u[2 * q + 1] = make_float2(v.z, v.w);
+                u[2 * q] = v2f{v.x, v.y};
+                u[2 * q + 1] = v2f{v.z, v.w};
             }
-            wave_lds_sync();                                   // the tile is rewritten below
+            lds_order();                                       // the tile is rewritten below
+            FE_STAMP(round * 8 + 3)
             dft16(u);                                          // over n2 -> k2: u[k2] = Z[k1 + 16 k2]
+            FE_STAMP(round * 8 + 4)
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) z_wr[16 * k2] = u[k2];
-            wave_lds_sync();
+            for (int k2 = 8; k2 < 16; ++k2) z_wr[16 * k2] = u[k2];   // only bins >= 128 are ever read back as mirrors
+            lds_order();
             // ---- real-FFT split: the pair (Z[k], Z[256 - k]) gives X[k] and X[256 - k]; this lane takes its bins
             //      k = k1 + 16 k2 with k2 < 8, the lane holding 16 - k1 takes the other half of the pairs ----
             float* const mrow = s_mag + fl * kMagRow;
+            v2f zm[8];
+            zm[0] = z_base[zm0];
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) {
-                const float2 zk = u[k2];
-                const float2 zm = z_base[(256 - j16 - 16 * k2) & 255];
-                const float ex = zk.x + zm.x, ey = zk.y - zm.y;            // 2 E[k]
-                const float ox = zk.y + zm.y, oy = zm.x - zk.x;            // 2 O[k]
-                const float2 t = tws[k2];
-                const float a = t.x * ox - t.y * oy, b = t.x * oy + t.y * ox;     // W^k O[k]
-                const float pr = 0.5f * ex + a, pi = 0.5f * ey + b;        // X[k]
-                const float qr = 0.5f * ex - a, qi = 0.5f * ey - b;        // conj(X[256 - k])
+            for (int k2 = 1; k2 < 8; ++k2) zm[k2] = z_base[zm1 - 16 * (k2 - 1)];
+            FE_STAMP(round * 8 + 5)
+#pragma unroll
+            for (int kb = 0; kb < 8; kb += 4) {                // four pairs at a time
+                v2f e2[4], o2[4], t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e2[i] = add_conj(u[kb + i], zm[kb + i]);   // 2 E[k]
+                    o2[i] = odd_part(u[kb + i], zm[kb + i]);   // 2 O[k]
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = cmul1_v(o2[i], tws[kb + i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o2[i] = cmul2_v(o2[i], tws[kb + i], t[i]);       // W^k O[k]
+                float mp[4], mq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v2f p = fma_s(e2[i], kHalf, o2[i]);  // X[k]
+                    const v2f q = fms_s(e2[i], kHalf, o2[i]);  // conj(X[256 - k])
+                    const v2f pp = p * p, qq = q * q;
+                    mp[i] = pp.x + pp.y;
+                    mq[i] = qq.x + qq.y;
+                }
                 // v_sqrt_f32 (1 ulp): |X| only feeds log(mel + 0.001)
-                mrow[j16 + 16 * k2] = __builtin_amdgcn_sqrtf(pr * pr + pi * pi);
-                if (k2 > 0) mrow[256 - j16 - 16 * k2] = __builtin_amdgcn_sqrtf(qr * qr + qi * qi);   // <= 240: inside the row
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mp[i] = __builtin_amdgcn_sqrtf(mp[i]);
+                    mq[i] = __builtin_amdgcn_sqrtf(mq[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k2 = kb + i;
+                    mrow[j16 + 16 * k2] = mp[i];
+                    if (k2 > 0) mrow[zm1 - 16 * (k2 - 1)] = mq[i];     // bins 129..240
+                }
             }
             // bin 128 is its own mirror: X[128] = conj(Z[128])
-            if (j16 == 0) mrow[128] = __builtin_amdgcn_sqrtf(u[8].x * u[8].x + u[8].y * u[8].y);
-            wave_lds_sync();                                   // mirror reads retire before the next round's transpose
+            if (j16 == 0) {
+                const v2f zz = u[8] * u[8];
+                mrow[128] = __builtin_amdgcn_sqrtf(zz.x + zz.y);
+            }
+            lds_order();                                       // mirror reads stay ahead of the next round's transpose
+            FE_STAMP(round * 8 + 6)
         }
+        FE_STAMP(16)
         __syncthreads();
+        FE_STAMP(17)
 
         // ---------------- mel phase: lane = frame, wave = run of bands ----------------
         {
             const float* mag_row = s_mag + lane * kMagRow;
             float* out_row = s_out + lane * kOutRow;
             switch (wave) {
-                case 0: mel_wave<0>(mag_row, out_row, melw); break;
-                case 1: mel_wave<1>(mag_row, out_row, melw); break;
-                case 2: mel_wave<2>(mag_row, out_row, melw); break;
-                case 3: mel_wave<3>(mag_row, out_row, melw); break;
-                case 4: mel_wave<4>(mag_row, out_row, melw); break;
-                case 5: mel_wave<5>(mag_row, out_row, melw); break;
-                case 6: mel_wave<6>(mag_row, out_row, melw); break;
-                default: mel_wave<7>(mag_row, out_row, melw); break;
+                case 0: mel_wave<0>(mag_row, out_row, s_melw); break;
+                case 1: mel_wave<1>(mag_row, out_row, s_melw); break;
+                case 2: mel_wave<2>(mag_row, out_row, s_melw); break;
+                case 3: mel_wave<3>(mag_row, out_row, s_melw); break;
+                case 4: mel_wave<4>(mag_row, out_row, s_melw); break;
+                case 5: mel_wave<5>(mag_row, out_row, s_melw); break;
+                case 6: mel_wave<6>(mag_row, out_row, s_melw); break;
+                default: mel_wave<7>(mag_row, out_row, s_melw); break;
             }
         }
+        FE_STAMP(18)
         __syncthreads();
+        FE_STAMP(19)
 
         // ---------------- output: 64 rows of 256 bytes ----------------
 #pragma unroll
@@ -435,6 +599,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             const int frame = group * kGroup + fl;
             if (frame < n_frames) out[(long long)frame * BD_MEL_BANDS + band] = s_out[fl * kOutRow + band];
         }
+        FE_STAMP(20)
     }
 }
 
@@ -516,8 +681,13 @@ void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* l
     }
     const int64_t groups = (n_frames + fe::kGroup - 1) / fe::kGroup;
     const int grid = (int)(groups < 256 ? groups : 256);      // one 152 KB workgroup per CU
+#ifdef BD_FE_TRACE
+    hipLaunchKernelGGL(fe::logmel_kernel, dim3(grid), dim3(fe::kThreads), 0, stream, pcm, (int)n_valid, (int)n_frames,
+                       logmel, tables, (unsigned long long*)nullptr);
+#else
     hipLaunchKernelGGL(fe::logmel_kernel, dim3(grid), dim3(fe::kThreads), 0, stream, pcm, (int)n_valid, (int)n_frames,
                        logmel, tables);
+#endif
 }
 
 void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
