@@ -220,9 +220,10 @@ __global__ __launch_bounds__(256, 4) void logmel_r4_kernel(const float* __restri
 // The default front end (see the header comment): 16 lanes per frame, 256 = 16 x 16, lane = frame mel.
 namespace fe {
 
-constexpr int kThreads = 512;
-constexpr int kWavesG = 8;
-constexpr int kGroup = 64;             // frames per workgroup pass
+constexpr int kThreads = 256;
+constexpr int kWavesG = 4;
+constexpr int kGroup = 32;             // frames per workgroup pass (two workgroups per CU: one's barriers and mel phase
+                                       // run under the other's FFT phase)
 constexpr int kXRow = 36;              // transpose tile: row (fq, k1) = 16 float2 + 16 B of bank padding, in dwords
 constexpr int kXFrame = 16 * kXRow;    // 576
 constexpr int kXWave = 4 * kXFrame;    // 2304 dwords = 9216 B per wave
@@ -233,7 +234,13 @@ constexpr int kOutRow = 65;
 static_assert(4 * kZFrame <= kXWave, "the natural-order tile reuses the transpose tile");
 
 // mel bands of wave w in the mel phase: [kCut[w], kCut[w + 1]); balanced on (non-zeros + log) per band
-constexpr int kCut[kWavesG + 1] = {0, 13, 24, 33, 42, 49, 55, 60, 64};
+constexpr int kCut[kWavesG + 1] = {0, 24, 42, 55, 64};
+// a run of bands is worked off in pieces of at most 48 weights (three s_load_dwordx16): first band of the piece after b0
+constexpr int mel_piece_end(int b0, int b1) {
+    int b = b0 + 1;
+    while (b < b1 && mel_offset(b + 1) - (mel_offset(b0) & ~3) <= 48) ++b;
+    return b;
+}
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -359,47 +366,70 @@ __device__ __forceinline__ v4f lds_landed(v4f v) {
 
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }   // a wave's DS operations execute in order
 
-// mel phase of wave W: lane = frame; bands [kCut[W], kCut[W + 1]) over that frame's |X| row.  The weights are the same
-// for every lane: they sit in LDS (s_melw, band-major) and arrive as broadcast 16-byte reads in the same queue
-// as the |X| row, one wait for all of them (scalar loads would each need their own lgkmcnt(0) drain).
-template <int B0, int B1, int KLO>       // bands [B0, B1) from the |X| registers m[] (m[0] = bin KLO)
-__device__ __forceinline__ void mel_bands(const float* __restrict__ m, float* __restrict__ out_row, unsigned melw_addr) {
-    constexpr int wlo = mel_offset(B0) & ~3, whi = (mel_offset(B1) + 3) & ~3;
-    v4f w4[(whi - wlo) / 4];
-    static_for<0, (whi - wlo) / 4>([&](auto qi) { w4[decltype(qi)::value] = lds_read128<16 * decltype(qi)::value>(melw_addr + 4 * wlo); });
+// mel phase of wave W: lane = frame; bands [kCut[W], kCut[W + 1]) over that frame's |X| row.
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <int BYTE_OFFSET>      // 16 wave-uniform floats into scalar registers; the caller waits (lgkmcnt) before use
+__device__ __forceinline__ v16f scalar_load16(const float* p) {
+    v16f v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "n"(BYTE_OFFSET) : "memory");
+    return v;
+}
+__device__ __forceinline__ v16f scalar_landed(v16f v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// bands [B0, B1) from the |X| registers m[] (m[0] = bin KLO).  The weights are the same for every lane: they come in
+// as scalar loads (the scalar cache holds the 1.8 KB table after the first group), all requested before the one wait
+// that also covers the |X| row reads, and are used as the scalar operand of v_fmac.
+template <int B0, int B1, int KLO>
+__device__ __forceinline__ void mel_bands(const float* __restrict__ m, float* __restrict__ out_row,
+                                          const float* __restrict__ melw) {
+    constexpr int wlo = mel_offset(B0) & ~3, n16 = (mel_offset(B1) - wlo + 15) / 16;
+    static_assert(n16 <= 3, "a half-run of bands holds at most 48 weights");
+    v16f w16[n16];
+    static_for<0, n16>([&](auto qi) { w16[decltype(qi)::value] = scalar_load16<4 * wlo + 64 * decltype(qi)::value>(melw); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    static_for<0, (whi - wlo) / 4>([&](auto qi) { w4[decltype(qi)::value] = lds_landed(w4[decltype(qi)::value]); });
-    const float* w = reinterpret_cast<const float*>(w4);
+    static_for<0, n16>([&](auto qi) { w16[decltype(qi)::value] = scalar_landed(w16[decltype(qi)::value]); });
     static_for<B0, B1>([&](auto bi) {
         constexpr int b = decltype(bi)::value;
         constexpr int off = mel_offset(b) - wlo, st = kMelStart[b] - KLO;
         float acc = 0.0f;
         static_for<0, kMelLen[b]>([&](auto ji) {
             constexpr int j = decltype(ji)::value;
-            acc = fmaf(m[st + j], w[off + j], acc);
+            acc = fmaf(m[st + j], w16[(off + j) / 16][(off + j) % 16], acc);
         });
         // acc + 0.001 is in [1e-3, ~1e3]: v_log_f32 (1 ulp, no denormal range) * ln 2
         out_row[b] = __builtin_amdgcn_logf(acc + 0.001f) * 0.69314718055994531f;
     });
 }
 
+template <int B0, int B1, int KLO>
+__device__ __forceinline__ void mel_run(const float* __restrict__ m, float* __restrict__ out_row,
+                                        const float* __restrict__ melw) {
+    if constexpr (B0 < B1) {
+        constexpr int bn = mel_piece_end(B0, B1);
+        mel_bands<B0, bn, KLO>(m, out_row, melw);
+        mel_run<bn, B1, KLO>(m, out_row, melw);
+    }
+}
+
 template <int W>
 __device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, float* __restrict__ out_row,
-                                         const float* __restrict__ s_melw) {
-    constexpr int b0 = kCut[W], b1 = kCut[W + 1], bm = (b0 + b1 + 1) / 2;
+                                         const float* __restrict__ melw) {
+    constexpr int b0 = kCut[W], b1 = kCut[W + 1];
     constexpr int klo = kMelStart[b0] & ~3;
     constexpr int khi = (kMelStart[b1 - 1] + kMelLen[b1 - 1] + 3) & ~3;
     v4f m4[(khi - klo) / 4];
     // ds_read_b128 by hand: the compiler narrows float4 loads to the components that are used and then only
     // knows 8-byte alignment (ds_read2_b64: twice the LDS cycles and bank conflicts on the row stride)
-    const unsigned m_addr = lds_addr(mag_row + klo), w_addr = lds_addr(s_melw);
+    const unsigned m_addr = lds_addr(mag_row + klo);
     static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_read128<16 * decltype(qi)::value>(m_addr); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_landed(m4[decltype(qi)::value]); });
     const float* m = reinterpret_cast<const float*>(m4);
-    // the weights in two halves: all of them at once would not fit the register file beside the FFT phase's constants
-    mel_bands<b0, bm, klo>(m, out_row, w_addr);
-    mel_bands<bm, b1, klo>(m, out_row, w_addr);
+    mel_run<b0, b1, klo>(m, out_row, melw);
 }
 
 // BD_FE_TRACE (tools/fe_trace.hip only): s_memtime stamps of two waves of one workgroup, second group it handles
@@ -416,15 +446,14 @@ __device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, floa
 __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __restrict__ pcm, int n_valid, int n_frames,
                                                              float* __restrict__ out,
                                                              const FeTables* __restrict__ tab FE_TRACE_ARG) {
-    __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        // 62 464 B
-    __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kXWave];          // 73 728 B
-    __shared__ __attribute__((aligned(16))) float s_out[kGroup * kOutRow];        // 16 640 B
-    __shared__ __attribute__((aligned(16))) float s_melw[kMelNonZero + 3];        //  1 856 B
+    __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        // 31 232 B
+    __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kXWave];          // 36 864 B
+    __shared__ __attribute__((aligned(16))) float s_out[kGroup * kOutRow];        //  8 320 B  (76 416 B: two workgroups per CU)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < kMelNonZero + 3) s_melw[tid] = tab->melw[tid];      // visible to all after the first barrier
+    const float* const melw = tab->melw;
     const int fq = lane >> 4;              // frame of the round
     const int j16 = lane & 15;             // n2 before the transpose, k1 after it
 
@@ -465,6 +494,8 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     // lies past sample 400 of the frame (n2 >= 8) read from an offset beyond any buffer instead: zero as well.
     const __amdgpu_buffer_rsrc_t pcm_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm), 0, n_valid * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out, 0, n_frames * (BD_MEL_BANDS * 4), 0x00020000);
     const int off12 = j16 < 8 ? 12 * 128 : 0x7f000000;        // byte offset of the n1 = 12 point relative to the lane's first
     // the 13 packed points of this lane for round `round` of group `g`
     auto load_round = [&](v2f (&raw)[13], int g, int round) {
@@ -475,8 +506,15 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             raw[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(pcm_rsrc, byte0 + 128 * n1, 0, 0));
         raw[12] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(pcm_rsrc, byte0 + off12, 0, 0));
     };
-    v2f raw[13];
-    if ((int)blockIdx.x < n_groups) load_round(raw, blockIdx.x, 0);
+    // raw[]: samples in flight for the round after the current one; win[]: the windowed points of the round about to run.
+    // A round's samples are requested one round ahead and turned into win[] at a point where nothing younger than them
+    // is outstanding (before the output stores of a group: s_waitcnt vmcnt counts loads and stores in order).
+    v2f raw[13], win[13];
+    if ((int)blockIdx.x < n_groups) {
+        load_round(raw, blockIdx.x, 0);
+#pragma unroll
+        for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * hann2[n1];
+    }
     for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
         // ---------------- FFT phase: this wave's eight frames in two rounds of four ----------------
 #pragma unroll 1
@@ -485,7 +523,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             v2f u[16];
             FE_STAMP(round * 8 + 0)
 #pragma unroll
-            for (int n1 = 0; n1 < 13; ++n1) u[n1] = raw[n1] * hann2[n1];
+            for (int n1 = 0; n1 < 13; ++n1) u[n1] = win[n1];
             u[13] = u[14] = u[15] = v2f{0.f, 0.f};
             {   // request the next round's samples now: they arrive under this round's arithmetic
                 const int ng = round == 0 ? group : group + (int)gridDim.x;
@@ -543,9 +581,8 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 for (int i = 0; i < 4; ++i) {
                     const v2f p = fma_s(e2[i], kHalf, o2[i]);  // X[k]
                     const v2f q = fms_s(e2[i], kHalf, o2[i]);  // conj(X[256 - k])
-                    const v2f pp = p * p, qq = q * q;
-                    mp[i] = pp.x + pp.y;
-                    mq[i] = qq.x + qq.y;
+                    mp[i] = fmaf(p.y, p.y, p.x * p.x);
+                    mq[i] = fmaf(q.y, q.y, q.x * q.x);
                 }
                 // v_sqrt_f32 (1 ulp): |X| only feeds log(mel + 0.001)
 #pragma unroll
@@ -566,38 +603,50 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 mrow[128] = __builtin_amdgcn_sqrtf(zz.x + zz.y);
             }
             lds_order();                                       // mirror reads stay ahead of the next round's transpose
+            if (round == 0) {                                  // round 1's samples were requested a round ago
+#pragma unroll
+                for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * hann2[n1];
+            }
             FE_STAMP(round * 8 + 6)
         }
         FE_STAMP(16)
         __syncthreads();
         FE_STAMP(17)
 
-        // ---------------- mel phase: lane = frame, wave = run of bands ----------------
-        {
+        // ---------------- mel phase: lane = frame (lanes 32..63 idle), wave = run of bands ----------------
+        if (lane < kGroup) {
             const float* mag_row = s_mag + lane * kMagRow;
             float* out_row = s_out + lane * kOutRow;
             switch (wave) {
-                case 0: mel_wave<0>(mag_row, out_row, s_melw); break;
-                case 1: mel_wave<1>(mag_row, out_row, s_melw); break;
-                case 2: mel_wave<2>(mag_row, out_row, s_melw); break;
-                case 3: mel_wave<3>(mag_row, out_row, s_melw); break;
-                case 4: mel_wave<4>(mag_row, out_row, s_melw); break;
-                case 5: mel_wave<5>(mag_row, out_row, s_melw); break;
-                case 6: mel_wave<6>(mag_row, out_row, s_melw); break;
-                default: mel_wave<7>(mag_row, out_row, s_melw); break;
+                case 0: mel_wave<0>(mag_row, out_row, melw); break;
+                case 1: mel_wave<1>(mag_row, out_row, melw); break;
+                case 2: mel_wave<2>(mag_row, out_row, melw); break;
+                default: mel_wave<3>(mag_row, out_row, melw); break;
             }
         }
         FE_STAMP(18)
         __syncthreads();
         FE_STAMP(19)
 
-        // ---------------- output: 64 rows of 256 bytes ----------------
+        // the next group's first round: its samples were requested at the start of round 1; consume them BEFORE the stores
+        if (group + (int)gridDim.x < n_groups) {
 #pragma unroll
-        for (int q = 0; q < kGroup * BD_MEL_BANDS / kThreads; ++q) {
-            const int i = tid + kThreads * q;
-            const int fl = i >> 6, band = i & 63;
-            const int frame = group * kGroup + fl;
-            if (frame < n_frames) out[(long long)frame * BD_MEL_BANDS + band] = s_out[fl * kOutRow + band];
+            for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * hann2[n1];
+        }
+
+        // ---------------- output: 32 rows of 256 bytes ----------------
+        // all eight LDS reads first, then eight stores through a buffer resource sized n_frames rows: rows of a last,
+        // partial group fall outside it and are dropped by the bounds check (no per-row branch)
+        {
+            float v[kGroup * BD_MEL_BANDS / kThreads];
+#pragma unroll
+            for (int q = 0; q < kGroup * BD_MEL_BANDS / kThreads; ++q)
+                v[q] = s_out[(kWavesG * q + (tid >> 6)) * kOutRow + lane];
+            const int byte0 = (group * kGroup + (tid >> 6)) * (BD_MEL_BANDS * 4) + lane * 4;
+#pragma unroll
+            for (int q = 0; q < kGroup * BD_MEL_BANDS / kThreads; ++q)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), out_rsrc,
+                                                      byte0 + q * (kWavesG * BD_MEL_BANDS * 4), 0, 0);
         }
         FE_STAMP(20)
     }
@@ -680,7 +729,7 @@ void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* l
         return;
     }
     const int64_t groups = (n_frames + fe::kGroup - 1) / fe::kGroup;
-    const int grid = (int)(groups < 256 ? groups : 256);      // one 152 KB workgroup per CU
+    const int grid = (int)(groups < 512 ? groups : 512);      // two 76 KB workgroups per CU
 #ifdef BD_FE_TRACE
     hipLaunchKernelGGL(fe::logmel_kernel, dim3(grid), dim3(fe::kThreads), 0, stream, pcm, (int)n_valid, (int)n_frames,
                        logmel, tables, (unsigned long long*)nullptr);

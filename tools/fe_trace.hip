@@ -23,7 +23,7 @@ int main() {
     for (int it = 0; it < 5; ++it) {
         (void)hipEventRecord(e0);
         for (int r = 0; r < 20; ++r)
-            hipLaunchKernelGGL(bd::fe::logmel_kernel, dim3(256), dim3(512), 0, 0, d_pcm, n, frames, d_out, d_t, d_s);
+            hipLaunchKernelGGL(bd::fe::logmel_kernel, dim3(512), dim3(bd::fe::kThreads), 0, 0, d_pcm, n, frames, d_out, d_t, d_s);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         printf("%.1f us per launch (with stamps)\n", ms * 1000 / 20);
@@ -31,7 +31,7 @@ int main() {
     unsigned long long st[64]; (void)hipMemcpy(st, d_s, sizeof(st), hipMemcpyDeviceToHost);
     const char* names[21] = {"r0 start", "r0 windowed+prefetch issued", "r0 dft1+tw", "r0 exchange", "r0 dft2", "r0 mirror", "r0 mags", "", "r1 start", "r1 windowed", "r1 dft1+tw", "r1 exchange", "r1 dft2", "r1 mirror", "r1 mags", "", "fft done", "barrier A", "mel done", "barrier B", "output done"};
     for (int w = 0; w < 2; ++w) {
-        printf("wave %d:\n", w ? 7 : 0);
+        printf("wave %d:\n", w ? bd::fe::kWavesG - 1 : 0);
         unsigned long long prev = st[w * 32];
         for (int i = 0; i < 21; ++i) {
             if (!names[i][0]) continue;
