@@ -35,7 +35,8 @@ struct FeTables {
     float  hann[BD_STFT_WINDOW + 16];     // periodic Hann, evaluated in float32 like tf.signal.hann_window; zero past 400
     float2 tw256[256];                    // exp(-2*pi*i*k/256)
     float2 tw512[BD_SPECTRUM_BINS + 1];   // exp(-2*pi*i*k/512), k = 0..256 (+1 pad)
-    float  melw[kMelNonZero + 3];         // band-major non-zeros: melw[mel_offset(m) + j] = mel[kMelStart[m] + j][m]
+    float  melw[kMelNonZero + 19];        // band-major non-zeros: melw[mel_offset(m) + j] = mel[kMelStart[m] + j][m]; zero
+                                          // padding so that every wave may load 48 from its 16-byte boundary
     int    band_start[BD_MEL_BANDS];      // = kMelStart / kMelLen (kept for the radix-4 reference kernel)
     int    band_len[BD_MEL_BANDS];
     int    max_len;

@@ -220,27 +220,23 @@ __global__ __launch_bounds__(256, 4) void logmel_r4_kernel(const float* __restri
 // The default front end (see the header comment): 16 lanes per frame, 256 = 16 x 16, lane = frame mel.
 namespace fe {
 
-constexpr int kThreads = 256;
-constexpr int kWavesG = 4;
-constexpr int kGroup = 32;             // frames per workgroup pass (two workgroups per CU: one's barriers and mel phase
-                                       // run under the other's FFT phase)
-constexpr int kXRow = 36;              // transpose tile: row (fq, k1) = 16 float2 + 16 B of bank padding, in dwords
-constexpr int kXFrame = 16 * kXRow;    // 576
-constexpr int kXWave = 4 * kXFrame;    // 2304 dwords = 9216 B per wave
-constexpr int kZFrame = 2 * 256 + 32;  // natural-order tile: 256 float2 + 128 B so that two frames fill all 64 banks
+constexpr int kThreads = 1024;         // one workgroup per CU, four waves per SIMD (128 VGPRs): a wave issues one vector
+constexpr int kWavesG = 16;            // instruction per ~5 cycles, so the packed-f32 pipe only fills with several waves
+constexpr int kGroup = 64;             // frames per workgroup pass: every wave transforms four of them
+constexpr int kXRow = 36;              // transpose tile: row (frame, k1) = 16 float2 + 16 B of bank padding, in dwords
+constexpr int kXFrame = 8 * kXRow;     // 288 dwords; the transpose runs eight of the sixteen rows at a time: 4 frames = 4608 B
+constexpr int kZFrame = 2 * 128 + 32;  // natural-order tile of the upper half spectrum: 128 float2 + 128 B bank shift
+constexpr int kTile = 1284;            // a wave's LDS region in dwords (5136 B); 1284 = 4 mod 32 spreads the staged
+                                       // output rows of the sixteen regions over the banks
 constexpr int kMagRow = 244;           // |X| tile row: bins 0..243 (5..239 are used); 244 = 52 mod 64 -> 16-byte row reads of
                                        // sixteen consecutive lanes cover all 64 banks
 constexpr int kOutRow = 65;
-static_assert(4 * kZFrame <= kXWave, "the natural-order tile reuses the transpose tile");
+constexpr int kTabRows = 13 + 15 + 8;  // per-lane constants in LDS: Hann pairs, W256^(n2 k1), split twiddles; [row][16] float2
+static_assert(4 * kXFrame <= kTile && 4 * kZFrame <= kTile && 4 * kOutRow <= kTile, "a wave's region holds each of its tiles");
 
-// mel bands of wave w in the mel phase: [kCut[w], kCut[w + 1]); balanced on (non-zeros + log) per band
-constexpr int kCut[kWavesG + 1] = {0, 24, 42, 55, 64};
-// a run of bands is worked off in pieces of at most 48 weights (three s_load_dwordx16): first band of the piece after b0
-constexpr int mel_piece_end(int b0, int b1) {
-    int b = b0 + 1;
-    while (b < b1 && mel_offset(b + 1) - (mel_offset(b0) & ~3) <= 48) ++b;
-    return b;
-}
+// mel bands of wave w in the mel phase: [kCut[w], kCut[w + 1]); balanced on (non-zeros + log) per band; each run holds at
+// most 48 weights counted from a 16-byte boundary (three s_load_dwordx16)
+constexpr int kCut[kWavesG + 1] = {0, 7, 13, 19, 24, 29, 33, 38, 42, 45, 49, 52, 55, 57, 60, 62, 64};
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -366,7 +362,6 @@ __device__ __forceinline__ v4f lds_landed(v4f v) {
 
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }   // a wave's DS operations execute in order
 
-// mel phase of wave W: lane = frame; bands [kCut[W], kCut[W + 1]) over that frame's |X| row.
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 template <int BYTE_OFFSET>      // 16 wave-uniform floats into scalar registers; the caller waits (lgkmcnt) before use
@@ -380,21 +375,33 @@ __device__ __forceinline__ v16f scalar_landed(v16f v) {
     return v;
 }
 
-// bands [B0, B1) from the |X| registers m[] (m[0] = bin KLO).  The weights are the same for every lane: they come in
-// as scalar loads (the scalar cache holds the 1.8 KB table after the first group), all requested before the one wait
-// that also covers the |X| row reads, and are used as the scalar operand of v_fmac.
-template <int B0, int B1, int KLO>
-__device__ __forceinline__ void mel_bands(const float* __restrict__ m, float* __restrict__ out_row,
-                                          const float* __restrict__ melw) {
-    constexpr int wlo = mel_offset(B0) & ~3, n16 = (mel_offset(B1) - wlo + 15) / 16;
-    static_assert(n16 <= 3, "a half-run of bands holds at most 48 weights");
+// mel phase of wave W: lane = frame; bands [kCut[W], kCut[W + 1]) over that frame's |X| row.  The weights are the same for
+// every lane: they come in as scalar loads (the scalar cache holds the 1.8 KB table after the first group), requested
+// before the one wait that also covers the |X| row reads, and are used as the scalar operand of v_fmac.  (Requesting them
+// ahead of the barrier that ends the FFT phase made the compiler spill the still-empty scalar registers: no gain.)
+template <int W>
+__device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, float* __restrict__ out_row,
+                                         const float* __restrict__ melw) {
+    constexpr int b0 = kCut[W], b1 = kCut[W + 1];
+    constexpr int klo = kMelStart[b0] & ~3;
+    constexpr int khi = (kMelStart[b1 - 1] + kMelLen[b1 - 1] + 3) & ~3;
+    constexpr int wlo = mel_offset(b0) & ~3, n16 = (mel_offset(b1) - wlo + 15) / 16;
+    static_assert(n16 <= 3, "a wave's run of bands holds at most 48 weights");
+    // the weights first (scalar loads, longest latency), then the |X| row, one wait for both
     v16f w16[n16];
     static_for<0, n16>([&](auto qi) { w16[decltype(qi)::value] = scalar_load16<4 * wlo + 64 * decltype(qi)::value>(melw); });
+    v4f m4[(khi - klo) / 4];
+    // ds_read_b128 by hand: the compiler narrows float4 loads to the components that are used and then only
+    // knows 8-byte alignment (ds_read2_b64: twice the LDS cycles and bank conflicts on the row stride)
+    const unsigned m_addr = lds_addr(mag_row + klo);
+    static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_read128<16 * decltype(qi)::value>(m_addr); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     static_for<0, n16>([&](auto qi) { w16[decltype(qi)::value] = scalar_landed(w16[decltype(qi)::value]); });
-    static_for<B0, B1>([&](auto bi) {
+    static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_landed(m4[decltype(qi)::value]); });
+    const float* m = reinterpret_cast<const float*>(m4);
+    static_for<b0, b1>([&](auto bi) {
         constexpr int b = decltype(bi)::value;
-        constexpr int off = mel_offset(b) - wlo, st = kMelStart[b] - KLO;
+        constexpr int off = mel_offset(b) - wlo, st = kMelStart[b] - klo;
         float acc = 0.0f;
         static_for<0, kMelLen[b]>([&](auto ji) {
             constexpr int j = decltype(ji)::value;
@@ -405,90 +412,64 @@ __device__ __forceinline__ void mel_bands(const float* __restrict__ m, float* __
     });
 }
 
-template <int B0, int B1, int KLO>
-__device__ __forceinline__ void mel_run(const float* __restrict__ m, float* __restrict__ out_row,
-                                        const float* __restrict__ melw) {
-    if constexpr (B0 < B1) {
-        constexpr int bn = mel_piece_end(B0, B1);
-        mel_bands<B0, bn, KLO>(m, out_row, melw);
-        mel_run<bn, B1, KLO>(m, out_row, melw);
-    }
-}
-
-template <int W>
-__device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, float* __restrict__ out_row,
-                                         const float* __restrict__ melw) {
-    constexpr int b0 = kCut[W], b1 = kCut[W + 1];
-    constexpr int klo = kMelStart[b0] & ~3;
-    constexpr int khi = (kMelStart[b1 - 1] + kMelLen[b1 - 1] + 3) & ~3;
-    v4f m4[(khi - klo) / 4];
-    // ds_read_b128 by hand: the compiler narrows float4 loads to the components that are used and then only
-    // knows 8-byte alignment (ds_read2_b64: twice the LDS cycles and bank conflicts on the row stride)
-    const unsigned m_addr = lds_addr(mag_row + klo);
-    static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_read128<16 * decltype(qi)::value>(m_addr); });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    static_for<0, (khi - klo) / 4>([&](auto qi) { m4[decltype(qi)::value] = lds_landed(m4[decltype(qi)::value]); });
-    const float* m = reinterpret_cast<const float*>(m4);
-    mel_run<b0, b1, klo>(m, out_row, melw);
-}
-
 // BD_FE_TRACE (tools/fe_trace.hip only): s_memtime stamps of two waves of one workgroup, second group it handles
 #ifdef BD_FE_TRACE
 #define FE_TRACE_ARG , unsigned long long* __restrict__ stamps
 #define FE_STAMP(I)                                                                                        \
-    if (stamps && blockIdx.x == 5 && group == (int)(blockIdx.x + gridDim.x) && lane == 0 && (wave == 0 || wave == 7)) \
+    if (stamps && blockIdx.x == 5 && group == (int)(blockIdx.x + gridDim.x) && lane == 0 && (wave == 0 || wave == kWavesG - 1)) \
         stamps[(wave ? 32 : 0) + (I)] = __builtin_amdgcn_s_memtime();
 #else
 #define FE_TRACE_ARG
 #define FE_STAMP(I)
 #endif
 
-__global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __restrict__ pcm, int n_valid, int n_frames,
-                                                             float* __restrict__ out,
-                                                             const FeTables* __restrict__ tab FE_TRACE_ARG) {
-    __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        // 31 232 B
-    __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kXWave];          // 36 864 B
-    __shared__ __attribute__((aligned(16))) float s_out[kGroup * kOutRow];        //  8 320 B  (76 416 B: two workgroups per CU)
+__global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restrict__ pcm, int n_valid, int n_frames,
+                                                          float* __restrict__ out,
+                                                          const FeTables* __restrict__ tab FE_TRACE_ARG) {
+    __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        // 62 464 B
+    __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kTile];           // 82 176 B
+    __shared__ __attribute__((aligned(16))) v2f s_tab[kTabRows * 16];             //  4 608 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* const melw = tab->melw;
-    const int fq = lane >> 4;              // frame of the round
+    const int fq = lane >> 4;              // frame of the wave's four
     const int j16 = lane & 15;             // n2 before the transpose, k1 after it
 
-    // per-lane constants of the whole kernel
-    v2f hann2[13];                         // Hann taps of z[16 n1 + n2], n1 = 0..12 (zero past sample 400)
-#pragma unroll
-    for (int n1 = 0; n1 < 13; ++n1) {
-        const int e = 2 * (16 * n1 + j16);
-        hann2[n1] = v2f{tab->hann[e], tab->hann[e + 1]};
+    // Per-lane constants (a lane's n2 / k1 never changes) live in LDS, [row][16]: the register file has to hold four
+    // waves per SIMD.  rows 0..12: Hann taps of z[16 n1 + n2] (zero past sample 400); 13..27: W256^(n2 k1), k1 = 1..15;
+    // 28..35: 0.5 exp(-2 pi i k / 512), k = k1 + 16 k2, k2 = 0..7 (the 1/2 of the real-FFT split).
+    if (tid < kTabRows * 16) {
+        const int r = tid >> 4, c = tid & 15;
+        v2f v;
+        if (r < 13) {
+            v = v2f{tab->hann[2 * (16 * r + c)], tab->hann[2 * (16 * r + c) + 1]};
+        } else if (r < 28) {
+            const float2 t = tab->tw256[(c * (r - 12)) & 255];
+            v = v2f{t.x, t.y};
+        } else {
+            const float2 t = tab->tw512[c + 16 * (r - 28)];
+            v = v2f{0.5f * t.x, 0.5f * t.y};
+        }
+        s_tab[tid] = v;
     }
-    v2f tw[15];                            // W256^(n2 k1), k1 = 1..15
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) {
-        const float2 t = tab->tw256[(j16 * k1) & 255];
-        tw[k1 - 1] = v2f{t.x, t.y};
-    }
-    v2f tws[8];                            // 0.5 * exp(-2 pi i k / 512), k = k1 + 16 k2, k2 = 0..7 (the 1/2 of the split)
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-        const float2 t = tab->tw512[j16 + 16 * k2];
-        tws[k2] = v2f{0.5f * t.x, 0.5f * t.y};
-    }
+    const v2f* const t_hann = s_tab + j16;
+    const v2f* const t_tw = s_tab + 13 * 16 + j16;
+    const v2f* const t_tws = s_tab + 28 * 16 + j16;
+    const float* const melw = tab->melw;
     const v2f kHalf = {0.5f, 0.5f};
 
-    float* const xw = s_x + wave * kXWave;
-    v2f* const x_wr = reinterpret_cast<v2f*>(xw + fq * kXFrame) + j16;                       // + k1 * (kXRow / 2)
-    const float4* const x_rd = reinterpret_cast<const float4*>(xw + fq * kXFrame + j16 * kXRow);
-    v2f* const z_wr = reinterpret_cast<v2f*>(xw + fq * kZFrame) + j16;                       // + 16 k2
+    float* const xw = s_x + wave * kTile;                       // this wave's region
+    v2f* const x_wr = reinterpret_cast<v2f*>(xw + fq * kXFrame) + j16;                        // + (k1 & 7) * (kXRow / 2)
+    const float4* const x_rd = reinterpret_cast<const float4*>(xw + fq * kXFrame + (j16 & 7) * kXRow);
+    v2f* const z_wr = reinterpret_cast<v2f*>(xw + fq * kZFrame) + j16;                       // + 16 (k2 - 8)
     const v2f* const z_base = reinterpret_cast<const v2f*>(xw + fq * kZFrame);
-    // mirrored bin of (k1, k2): (256 - k1 - 16 k2) & 255 = zm0 - 16 k2 for k2 >= 1; for k2 = 0 it is 256 - k1 (k1 = 0: bin 0)
-    const int zm0 = j16 ? 256 - j16 : 128;     // (k1 = 0: the pair of bin 0 feeds no mel band; read something finite)
-    const int zm1 = 240 - j16;
+    // mirrored bin of (k1, k2) minus 128: k2 = 0: 128 - k1 (k1 = 0: the pair of bin 0 feeds no mel band; read something
+    // finite); k2 >= 1: 112 - k1 - 16 (k2 - 1)
+    const int zm0 = j16 ? 128 - j16 : 0;
+    const int zm1 = 112 - j16;
 
     const int n_groups = (n_frames + kGroup - 1) / kGroup;
-
     // PCM goes through a buffer resource whose size is n_valid samples: a dword past the end reads as zero, which
     // IS pad_waveform's zero padding, with no bounds code and no second code path.  Lanes whose thirteenth point
     // lies past sample 400 of the frame (n2 >= 8) read from an offset beyond any buffer instead: zero as well.
@@ -497,64 +478,70 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     const __amdgpu_buffer_rsrc_t out_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(out, 0, n_frames * (BD_MEL_BANDS * 4), 0x00020000);
     const int off12 = j16 < 8 ? 12 * 128 : 0x7f000000;        // byte offset of the n1 = 12 point relative to the lane's first
-    // the 13 packed points of this lane for round `round` of group `g`
-    auto load_round = [&](v2f (&raw)[13], int g, int round) {
-        const int frame = g * kGroup + wave * 8 + round * 4 + fq;
+    // the 13 packed points of this lane's frame in group g
+    auto load_group = [&](v2f (&raw)[13], int g) {
+        const int frame = g * kGroup + wave * 4 + fq;
         const int byte0 = (frame * BD_STFT_HOP + 2 * j16) * 4;
 #pragma unroll
         for (int n1 = 0; n1 < 12; ++n1)
             raw[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(pcm_rsrc, byte0 + 128 * n1, 0, 0));
         raw[12] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(pcm_rsrc, byte0 + off12, 0, 0));
     };
-    // raw[]: samples in flight for the round after the current one; win[]: the windowed points of the round about to run.
-    // A round's samples are requested one round ahead and turned into win[] at a point where nothing younger than them
-    // is outstanding (before the output stores of a group: s_waitcnt vmcnt counts loads and stores in order).
+    // raw[]: samples in flight for the next group; win[]: the windowed points of the group about to run.  A group's
+    // samples are requested at the end of the previous group's transform and turned into win[] at a point where nothing
+    // younger than them is outstanding (before the output stores: s_waitcnt vmcnt counts loads and stores in order).
     v2f raw[13], win[13];
-    if ((int)blockIdx.x < n_groups) {
-        load_round(raw, blockIdx.x, 0);
+    __syncthreads();                                           // s_tab
+    load_group(raw, blockIdx.x);
 #pragma unroll
-        for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * hann2[n1];
-    }
+    for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * t_hann[16 * n1];
     for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
-        // ---------------- FFT phase: this wave's eight frames in two rounds of four ----------------
-#pragma unroll 1
-        for (int round = 0; round < 2; ++round) {
-            const int fl = wave * 8 + round * 4 + fq;          // frame within the group
+        // ---------------- FFT phase: this wave's four frames ----------------
+        {
+            constexpr int round = 0;
+            const int fl = wave * 4 + fq;                      // frame within the group
             v2f u[16];
             FE_STAMP(round * 8 + 0)
 #pragma unroll
             for (int n1 = 0; n1 < 13; ++n1) u[n1] = win[n1];
             u[13] = u[14] = u[15] = v2f{0.f, 0.f};
-            {   // request the next round's samples now: they arrive under this round's arithmetic
-                const int ng = round == 0 ? group : group + (int)gridDim.x;
-                if (ng < n_groups) load_round(raw, ng, round ^ 1);
-            }
             FE_STAMP(round * 8 + 1)
             dft16(u);                                          // over n1 -> k1
 #pragma unroll
             for (int kb = 1; kb < 16; kb += 5) {               // five independent products at a time
-                v2f t[5];
+                v2f t[5], w[5];
+                lds_order();                                   // keeps the table reads where they are (register budget)
 #pragma unroll
-                for (int i = 0; i < 5; ++i) t[i] = cmul1_v(u[kb + i], tw[kb + i - 1]);
+                for (int i = 0; i < 5; ++i) w[i] = t_tw[16 * (kb + i - 1)];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) u[kb + i] = cmul2_v(u[kb + i], tw[kb + i - 1], t[i]);
+                for (int i = 0; i < 5; ++i) t[i] = cmul1_v(u[kb + i], w[i]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) u[kb + i] = cmul2_v(u[kb + i], w[i], t[i]);
             }
             FE_STAMP(round * 8 + 2)
+            // transpose through the wave's tile, eight rows (k1) at a time: every lane writes its eight points of those
+            // rows (full-width stores), then the eight lanes of each frame that own one of the rows gather theirs
+            v2f v[16];
 #pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) x_wr[k1 * (kXRow / 2)] = u[k1];
-            lds_order();
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {                      // lane k1 gathers its row over n2
-                const float4 v = x_rd[q];
-                u[2 * q] = v2f{v.x, v.y};
-                u[2 * q + 1] = v2f{v.z, v.w};
+                for (int k1 = 0; k1 < 8; ++k1) x_wr[k1 * (kXRow / 2)] = u[8 * h + k1];
+                lds_order();
+                if ((j16 >> 3) == h) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {              // lane k1 gathers its row over n2
+                        const float4 f = x_rd[q];
+                        v[2 * q] = v2f{f.x, f.y};
+                        v[2 * q + 1] = v2f{f.z, f.w};
+                    }
+                }
+                lds_order();                                   // the tile is rewritten by the second half / below
             }
-            lds_order();                                       // the tile is rewritten below
             FE_STAMP(round * 8 + 3)
-            dft16(u);                                          // over n2 -> k2: u[k2] = Z[k1 + 16 k2]
+            dft16(v);                                          // over n2 -> k2: v[k2] = Z[k1 + 16 k2]
             FE_STAMP(round * 8 + 4)
 #pragma unroll
-            for (int k2 = 8; k2 < 16; ++k2) z_wr[16 * k2] = u[k2];   // only bins >= 128 are ever read back as mirrors
+            for (int k2 = 8; k2 < 16; ++k2) z_wr[16 * (k2 - 8)] = v[k2];   // only bins >= 128 are ever read back as mirrors
             lds_order();
             // ---- real-FFT split: the pair (Z[k], Z[256 - k]) gives X[k] and X[256 - k]; this lane takes its bins
             //      k = k1 + 16 k2 with k2 < 8, the lane holding 16 - k1 takes the other half of the pairs ----
@@ -566,16 +553,19 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             FE_STAMP(round * 8 + 5)
 #pragma unroll
             for (int kb = 0; kb < 8; kb += 4) {                // four pairs at a time
-                v2f e2[4], o2[4], t[4];
+                v2f e2[4], o2[4], t[4], w[4];
+                lds_order();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = t_tws[16 * (kb + i)];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    e2[i] = add_conj(u[kb + i], zm[kb + i]);   // 2 E[k]
-                    o2[i] = odd_part(u[kb + i], zm[kb + i]);   // 2 O[k]
+                    e2[i] = add_conj(v[kb + i], zm[kb + i]);   // 2 E[k]
+                    o2[i] = odd_part(v[kb + i], zm[kb + i]);   // 2 O[k]
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = cmul1_v(o2[i], tws[kb + i]);
+                for (int i = 0; i < 4; ++i) t[i] = cmul1_v(o2[i], w[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o2[i] = cmul2_v(o2[i], tws[kb + i], t[i]);       // W^k O[k]
+                for (int i = 0; i < 4; ++i) o2[i] = cmul2_v(o2[i], w[i], t[i]);              // W^k O[k]
                 float mp[4], mq[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -594,59 +584,68 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 for (int i = 0; i < 4; ++i) {
                     const int k2 = kb + i;
                     mrow[j16 + 16 * k2] = mp[i];
-                    if (k2 > 0) mrow[zm1 - 16 * (k2 - 1)] = mq[i];     // bins 129..240
+                    if (k2 > 0) mrow[240 - j16 - 16 * (k2 - 1)] = mq[i];     // bins 129..240
                 }
             }
             // bin 128 is its own mirror: X[128] = conj(Z[128])
-            if (j16 == 0) {
-                const v2f zz = u[8] * u[8];
-                mrow[128] = __builtin_amdgcn_sqrtf(zz.x + zz.y);
-            }
-            lds_order();                                       // mirror reads stay ahead of the next round's transpose
-            if (round == 0) {                                  // round 1's samples were requested a round ago
-#pragma unroll
-                for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * hann2[n1];
-            }
+            if (j16 == 0) mrow[128] = __builtin_amdgcn_sqrtf(fmaf(v[8].y, v[8].y, v[8].x * v[8].x));
+            lds_order();
+            // request the next group's samples: they arrive under the barriers, the mel phase and the output.  (Also
+            // behind the last group: the buffer resource answers zero, and an unconditional definition keeps raw[] and
+            // win[] from staying live around the whole loop.)
+            load_group(raw, group + (int)gridDim.x);
             FE_STAMP(round * 8 + 6)
         }
         FE_STAMP(16)
         __syncthreads();
         FE_STAMP(17)
 
-        // ---------------- mel phase: lane = frame (lanes 32..63 idle), wave = run of bands ----------------
-        if (lane < kGroup) {
+        // ---------------- mel phase: lane = frame, wave = run of bands ----------------
+        // The staged log-mel row of frame f lives in the region of the wave that transformed (and will store) it:
+        // that wave may then go on into its next transform, which rewrites only its own region, without a third barrier.
+        {
             const float* mag_row = s_mag + lane * kMagRow;
-            float* out_row = s_out + lane * kOutRow;
+            float* out_row = s_x + (lane >> 2) * kTile + (lane & 3) * kOutRow;
             switch (wave) {
                 case 0: mel_wave<0>(mag_row, out_row, melw); break;
                 case 1: mel_wave<1>(mag_row, out_row, melw); break;
                 case 2: mel_wave<2>(mag_row, out_row, melw); break;
-                default: mel_wave<3>(mag_row, out_row, melw); break;
+                case 3: mel_wave<3>(mag_row, out_row, melw); break;
+                case 4: mel_wave<4>(mag_row, out_row, melw); break;
+                case 5: mel_wave<5>(mag_row, out_row, melw); break;
+                case 6: mel_wave<6>(mag_row, out_row, melw); break;
+                case 7: mel_wave<7>(mag_row, out_row, melw); break;
+                case 8: mel_wave<8>(mag_row, out_row, melw); break;
+                case 9: mel_wave<9>(mag_row, out_row, melw); break;
+                case 10: mel_wave<10>(mag_row, out_row, melw); break;
+                case 11: mel_wave<11>(mag_row, out_row, melw); break;
+                case 12: mel_wave<12>(mag_row, out_row, melw); break;
+                case 13: mel_wave<13>(mag_row, out_row, melw); break;
+                case 14: mel_wave<14>(mag_row, out_row, melw); break;
+                default: mel_wave<15>(mag_row, out_row, melw); break;
             }
         }
         FE_STAMP(18)
         __syncthreads();
         FE_STAMP(19)
 
-        // the next group's first round: its samples were requested at the start of round 1; consume them BEFORE the stores
-        if (group + (int)gridDim.x < n_groups) {
+        // the next group: its samples were requested at the end of the transform; consume them BEFORE the stores
 #pragma unroll
-            for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * hann2[n1];
-        }
+        for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * t_hann[16 * n1];
 
-        // ---------------- output: 32 rows of 256 bytes ----------------
-        // all eight LDS reads first, then eight stores through a buffer resource sized n_frames rows: rows of a last,
-        // partial group fall outside it and are dropped by the bounds check (no per-row branch)
+        // ---------------- output: this wave's four rows of 256 bytes ----------------
+        // four LDS reads, then four stores through a buffer resource sized n_frames rows: rows of a last, partial group
+        // fall outside it and are dropped by the bounds check (no per-row branch)
         {
-            float v[kGroup * BD_MEL_BANDS / kThreads];
+            float o[4];
 #pragma unroll
-            for (int q = 0; q < kGroup * BD_MEL_BANDS / kThreads; ++q)
-                v[q] = s_out[(kWavesG * q + (tid >> 6)) * kOutRow + lane];
-            const int byte0 = (group * kGroup + (tid >> 6)) * (BD_MEL_BANDS * 4) + lane * 4;
+            for (int q = 0; q < 4; ++q) o[q] = xw[q * kOutRow + lane];
+            const int byte0 = ((group * kGroup + wave * 4) * BD_MEL_BANDS + lane) * 4;
 #pragma unroll
-            for (int q = 0; q < kGroup * BD_MEL_BANDS / kThreads; ++q)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), out_rsrc,
-                                                      byte0 + q * (kWavesG * BD_MEL_BANDS * 4), 0, 0);
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[q]), out_rsrc,
+                                                      byte0 + q * (BD_MEL_BANDS * 4), 0, 0);
+            lds_order();                                       // the row reads stay ahead of the next transform's tile writes
         }
         FE_STAMP(20)
     }
@@ -729,7 +728,7 @@ void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* l
         return;
     }
     const int64_t groups = (n_frames + fe::kGroup - 1) / fe::kGroup;
-    const int grid = (int)(groups < 512 ? groups : 512);      // two 76 KB workgroups per CU
+    const int grid = (int)(groups < 256 ? groups : 256);      // one 149 KB, 16-wave workgroup per CU
 #ifdef BD_FE_TRACE
     hipLaunchKernelGGL(fe::logmel_kernel, dim3(grid), dim3(fe::kThreads), 0, stream, pcm, (int)n_valid, (int)n_frames,
                        logmel, tables, (unsigned long long*)nullptr);

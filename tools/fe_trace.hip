@@ -23,7 +23,7 @@ int main() {
     for (int it = 0; it < 5; ++it) {
         (void)hipEventRecord(e0);
         for (int r = 0; r < 20; ++r)
-            hipLaunchKernelGGL(bd::fe::logmel_kernel, dim3(512), dim3(bd::fe::kThreads), 0, 0, d_pcm, n, frames, d_out, d_t, d_s);
+            hipLaunchKernelGGL(bd::fe::logmel_kernel, dim3(256), dim3(bd::fe::kThreads), 0, 0, d_pcm, n, frames, d_out, d_t, d_s);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         printf("%.1f us per launch (with stamps)\n", ms * 1000 / 20);
