@@ -85,9 +85,6 @@ def slot_plan(launches, pool_fused=True):
                     # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own
                     # (epilogue fusion exists only in the 8-wave kernel)
                     plan[pw_slot - 2] = (nm + f"+dw{layer}", "sep_ws_kernel", nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
-            elif layer == 2:      # fused stem: log-mel patch in, layer-2 output out
-                plan[pw_slot] = ("stem(1-2)", "stem_kernel", 96 * 64 * 4 + ho * wo * cout * 4,
-                                 conv1[1] + dw[1] + pw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
                 # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
                 fam = "sep_w12_kernel" if (pool_fused and c == 512 and cout == 512) else "sep_ws_kernel"
@@ -303,9 +300,8 @@ def main() -> int:
     ap.add_argument("--streams", type=int, default=2,
                     help="analyzer streams per GPU: batches are dealt round-robin to this many engines, each on "
                          "its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253)")
-    ap.add_argument("--sep-variant", type=int, default=None, help="fused separable-layer kernel variant (tuning)")
+    ap.add_argument("--sep-variant", type=int, default=None, help="fused separable layers: 9 = 8-wave kernel only, 12 = with the 12-wave kernel (no epilogue fusion; tuning)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
-    ap.add_argument("--frontend-variant", type=int, default=None, help="front-end FFT formulation (tuning)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     args = ap.parse_args()
 
@@ -353,8 +349,6 @@ def main() -> int:
         if args.pw_variant is not None:
             for layer in range(5, 15):
                 e.set_pointwise_variant(layer, args.pw_variant)
-        if args.frontend_variant is not None:
-            e.set_frontend_variant(args.frontend_variant)
     framehop_s = FRAMELENGTH_S * HOP_PROP
     hop, step = hop_samples(framehop_s), patch_step(framehop_s)
     batches = file_batches(hop)

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import subprocess
 from typing import Optional
 
 from . import build as _build
@@ -73,7 +74,6 @@ PROTOTYPES = {
     "bd_set_pointwise_variant": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "bd_set_pointwise_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "bd_set_fusion": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
-    "bd_set_frontend_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "bd_debug_pointwise_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "bd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -96,10 +96,20 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = library_path()
+    external = "BUZZDETECT_HIP_LIB" in os.environ
     if not os.path.exists(path):
-        if not build_if_missing or "BUZZDETECT_HIP_LIB" in os.environ:
+        if not build_if_missing or external:
             raise FileNotFoundError(f"{path} not found; run `python -m buzzdetect_amd.build`")
         _build.build()
+    elif not external and _build.needs_build():
+        # the in-tree library is older than its sources (it is git-ignored, so a checkout does not refresh it):
+        # rebuild where hipcc exists, refuse to run stale kernels where it does not
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is older than its sources; run `python -m buzzdetect_amd.build`")
+        try:
+            _build.build()
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:
+            raise RuntimeError(f"{path} is older than its sources and could not be rebuilt: {exc}") from exc
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export it

@@ -7,6 +7,7 @@ with the repository snapshot to the GPU box; it is git-ignored.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -27,12 +28,24 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
 
 
+STAMP_PATH = LIB_PATH + ".srchash"      # sha256 of the sources the library was built from (travels with it)
+
+
+def source_hash() -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """True when there is no library or it was built from other sources (content hash, not mtimes: a snapshot copied
+    to another machine keeps neither order nor times)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > built for d in deps)
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -43,8 +56,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
            "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[buzzdetect_amd.build]", " ".join(cmd), flush=True)
+    stamp = source_hash()
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(STAMP_PATH, "w") as f:
+        f.write(stamp + "\n")
     return LIB_PATH
 
 

@@ -8,7 +8,6 @@
 
 namespace bd {
 
-constexpr int kMelMaxLen = 18;   // longest run of non-zero bins a mel band may have (YAMNet: 17)
 constexpr int kMelNonZero = 461; // non-zero entries of the [257,64] YAMNet mel matrix (both graph variants)
 
 // Sparsity pattern of tf.signal.linear_to_mel_weight_matrix(64, 257, 16000, 125, 7500) as baked into the
@@ -37,11 +36,6 @@ struct FeTables {
     float2 tw512[BD_SPECTRUM_BINS + 1];   // exp(-2*pi*i*k/512), k = 0..256 (+1 pad)
     float  melw[kMelNonZero + 19];        // band-major non-zeros: melw[mel_offset(m) + j] = mel[kMelStart[m] + j][m]; zero
                                           // padding so that every wave may load 48 from its 16-byte boundary
-    int    band_start[BD_MEL_BANDS];      // = kMelStart / kMelLen (kept for the radix-4 reference kernel)
-    int    band_len[BD_MEL_BANDS];
-    int    max_len;
-    int    pad_[3];
-    float  band_w[kMelMaxLen][BD_MEL_BANDS];  // band_w[j][m] = mel[band_start[m] + j][m]
 };
 
 // Which log-mel frames a window reads when one launch covers several chunks: the chunks' log-mel rows are
@@ -79,7 +73,7 @@ struct SepLayer {
 
 // ---- launchers (each enqueues exactly one kernel on `stream`) ----
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
-                   const FeTables* tables, hipStream_t stream, int variant = 0);
+                   const FeTables* tables, hipStream_t stream);
 void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const float* taps, int half, int up,
                      int down, float* out, int64_t n_out, hipStream_t stream);
 void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
@@ -96,9 +90,6 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
                             hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     hipStream_t stream);
-void launch_stem(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                 const float* c1_b,
-                 const SepLayer& L2, float* out, hipStream_t stream);
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);

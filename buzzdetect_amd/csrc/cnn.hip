@@ -11,17 +11,32 @@
 //                        overlapping band tiles); NDW = 2: global average pool in the epilogue (layer 14)
 //   sep_w12_kernel       the same for the 512 -> 512 layers 8-11 with 8 MFMA waves (depthwise once per row tile)
 //   pool_head_kernel<1>  Dense(1024 -> n_classes) on the pooled embeddings
-// Reference / selectable kernels (one per op; the fused ones are tested bit for bit against them):
+// Reference kernels, one per op (the fused ones are tested bit for bit against them; they are also the exact-f32 mode):
 //   conv1_kernel, depthwise_kernel, pointwise_f16x3_kernel (split-f16), pointwise_kernel (exact-f32 MFMA),
-//   stem_kernel, stem3_kernel<false>, sep_s1_kernel (4-wave fusion), sep_wsp_kernel (persistent), pool_head_kernel<6>
-// Workgroup -> tile mapping is XCD-aware (tile_of); developer traces are behind BD_WS_TRACE / BD_STEM_TRACE.
+//   stem3_kernel<false> (layers 1-2 + depthwise 3, for the stage taps), pool_head_kernel<6>
+// Workgroup -> tile mapping is XCD-aware (tile_of).  Clock traces of single workgroups exist only in a developer build
+// (-DBD_KERNEL_TRACE, then selected by BD_WS_TRACE / BD_STEM_TRACE); the shipped launch path reads no environment and
+// keeps no mutable state besides the once-per-device dynamic-LDS attribute flags.
 #include "bd_internal.h"
+#include <mutex>
 
 namespace bd {
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// hipFuncSetAttribute(max dynamic LDS) once per kernel instantiation and device; safe when several analyzer threads
+// (one engine each, src/inference/worker.py:21) make their first launch at the same time.
+constexpr int kMaxDevices = 64;
+template <typename Kernel>
+void allow_dynamic_lds(Kernel kernel, int bytes, std::once_flag (&once)[kMaxDevices]) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & (kMaxDevices - 1)], [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    });
+}
 
 // --------------------------------------------------------------------------- conv1
 constexpr int kC1Rows = 4;   // output rows per workgroup
@@ -464,15 +479,8 @@ void launch_pw16(const float* A, const _Float16* Whi, const _Float16* Wlo, const
                  long long M, int N, int K, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = 2u * 2u * (BM + BN) * 64;
-    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_f16x3_kernel<BM, BN, WGM, WGN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&pointwise_f16x3_kernel<BM, BN, WGM, WGN>, (int)lds, lds_once);
     const int tiles_n = N / BN;
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
     hipLaunchKernelGGL((pointwise_f16x3_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A,
@@ -484,275 +492,12 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
                hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = 2u * (BM + BN) * kLds * sizeof(float);
-    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_kernel<BM, BN, WGM, WGN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&pointwise_kernel<BM, BN, WGM, WGN>, (int)lds, lds_once);
     const int tiles_n = N / BN;
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
     hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A, Wt,
                        bias, C, M, N, K, tiles_n);
-}
-
-// --------------------------------------------------------------------------- fused separable layer (stride 1)
-// depthwise 3x3 s1 + BN + ReLU  ->  pointwise 1x1 + BN + ReLU in one kernel (yamnet.py:52-74): the
-// depthwise output is produced 32 channels at a time straight into the split-f16 A tile of the GEMM
-// and never exists in HBM.  Per K stage a workgroup stages the input rows it needs (its BM output
-// positions plus one halo row above and below when the tile is a band of one window; whole windows
-// otherwise — either way ONE contiguous run of NHWC rows) as f32 into LDS, every thread computes
-// BM/32 depthwise outputs x 4 channels from it (9 ds_read_b128 each), splits them into hi/lo halves
-// and the MFMA phase proceeds exactly as in pointwise_f16x3_kernel.  Same arithmetic order as the
-// unfused kernels, so results are bit-identical to them.
-//
-// Requirements (checked by the launcher): stride 1, OH*OW % BM == 0 with BM % OW == 0 (band of rows)
-// or BM % (OH*OW) == 0 (whole windows); XPMAX >= rows staged.
-template <int BM, int BN, int WGM, int WGN, int XPMAX>
-__global__ __launch_bounds__(WGM* WGN * 64) void sep_s1_kernel(
-    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
-    float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n) {
-    constexpr int NT = WGM * WGN * 64;
-    static_assert(NT == 256, "thread mapping assumes 256 threads");
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int LA = BM / 32;             // depthwise outputs (float4 of channels) per thread per stage
-    constexpr int XL = (XPMAX + 31) / 32;   // float4 loads of the input tile per thread per stage
-    constexpr int BCH = BN * 4 / NT;
-    static_assert(BM % 32 == 0 && (BN * 4) % NT == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* const Xs = reinterpret_cast<float*>(smem_raw);            // [XPMAX + 1][32]; row XPMAX stays zero
-    float* const Ws = Xs + (XPMAX + 1) * 32;                          // [10][32]: 9 depthwise taps + bias of the stage
-    char* const Ah = smem_raw + (XPMAX + 1) * 128 + 10 * 128;         // [2][A_BYTES]
-    char* const Al = Ah + 2 * A_BYTES;
-    char* const Bh = Al + 2 * A_BYTES;                                // [2][B_BYTES]
-    char* const Bl = Bh + 2 * B_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave / WGN, wc = wave % WGN;
-    const long long tile_m = blockIdx.x / tiles_n;
-    const int tile_n = blockIdx.x % tiles_n;
-    const long long m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
-    const int P = H * W;
-
-    // ---- which input rows does this tile need?  [x_lo, x_lo + x_cnt) of the flattened [rows][K] input
-    long long x_lo;
-    int x_cnt;
-    if (P >= BM) {                                   // a band of BM / W output rows of one window
-        const long long n = m0 / P;
-        const int oh_a = (int)(m0 % P) / W;
-        const int oh_b = oh_a + BM / W;
-        const int r0 = oh_a > 0 ? oh_a - 1 : 0;
-        const int r1 = oh_b < H ? oh_b + 1 : H;
-        x_lo = (n * H + r0) * W;
-        x_cnt = (r1 - r0) * W;
-    } else {                                         // whole windows
-        x_lo = m0;
-        x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
-    }
-
-    const int lrow = tid >> 3;
-    const int lc4 = tid & 7;
-
-    // input-tile loads: row lrow + 32 j of the staged run (clamped; rows past x_cnt are never read back)
-    const float* xp[XL];
-#pragma unroll
-    for (int j = 0; j < XL; ++j) {
-        int r = lrow + 32 * j;
-        r = r < x_cnt ? r : x_cnt - 1;
-        xp[j] = X + (size_t)(x_lo + r) * K + lc4 * 4;
-    }
-    // depthwise outputs owned by this thread: tile rows lrow + 32 i.  The float offset into Xs of each of
-    // its 9 taps is fixed for the whole K loop; taps that fall outside the window point at the zero row.
-    int xtap[LA][9];
-    int a_st[LA];
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int ml = lrow + 32 * i;
-        long long m = m0 + ml;
-        m = m < M ? m : M - 1;
-        const int q = (int)(m % P);
-        const int oh = q / W, ow = q % W;
-        const int xc = (int)(m - x_lo);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = oh + kh - 1, iw = ow + kw - 1;
-                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
-                xtap[i][kh * 3 + kw] = (ok ? xc + (kh - 1) * W + (kw - 1) : XPMAX) * 32 + lc4 * 4;
-            }
-        a_st[i] = swz64(ml, lc4 >> 1) + (lc4 & 1) * 8;
-    }
-    if (tid < 8) *reinterpret_cast<float4*>(Xs + XPMAX * 32 + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    // stage weights of the depthwise: thread t < 80 carries tap (t >> 3) (9 = bias) for channels 4 (t & 7)
-    const float* wsrc = tid < 72 ? dw_w + (size_t)(tid >> 3) * K + lc4 * 4 : dw_b + lc4 * 4;
-    const _Float16* bph[BCH];
-    const _Float16* bpl[BCH];
-    int b_st[BCH];
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-        const int id = tid + NT * i;
-        const int row = id >> 2, slot = id & 3;
-        bph[i] = Whi + (size_t)(n0 + row) * K + slot * 8;
-        bpl[i] = Wlo + (size_t)(n0 + row) * K + slot * 8;
-        b_st[i] = swz64(row, slot);
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // native vector types: HIP's float4/uint4 structs end up as stack objects when carried around the loop
-    v4f rx[XL];
-    v4f rw = {0.f, 0.f, 0.f, 0.f};
-    v4u rbh[BCH], rbl[BCH];
-
-#define BD_SEP_LOAD(KOFF)                                                                                 \
-    {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < XL; ++j) rx[j] = *reinterpret_cast<const v4f*>(xp[j] + (KOFF)); \
-        if (tid < 80) rw = *reinterpret_cast<const v4f*>(wsrc + (KOFF));                               \
-        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
-            rbh[i] = *reinterpret_cast<const v4u*>(bph[i] + (KOFF));                                    \
-            rbl[i] = *reinterpret_cast<const v4u*>(bpl[i] + (KOFF));                                    \
-        }                                                                                                 \
-    }
-#define BD_SEP_STORE(BUF)                                                                                 \
-    {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                    \
-            if (lrow + 32 * j < XPMAX) *reinterpret_cast<v4f*>(Xs + (lrow + 32 * j) * 32 + lc4 * 4) = rx[j]; \
-        if (tid < 80) *reinterpret_cast<v4f*>(Ws + tid * 4) = rw;                                      \
-        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
-            *reinterpret_cast<v4u*>(Bh + (BUF) * B_BYTES + b_st[i]) = rbh[i];                           \
-            *reinterpret_cast<v4u*>(Bl + (BUF) * B_BYTES + b_st[i]) = rbl[i];                           \
-        }                                                                                                 \
-    }
-    // depthwise of the staged slab: Xs, Ws -> split-f16 A tile BUF
-#define BD_SEP_DW(BUF)                                                                                    \
-    {                                                                                                     \
-        float4 wt[9];                                                                                     \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(Ws + t * 32 + lc4 * 4); \
-        const float4 bias4 = *reinterpret_cast<const float4*>(Ws + 9 * 32 + lc4 * 4);                     \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
-            float4 a4 = bias4;                                                                            \
-            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                               \
-                const float4 v = *reinterpret_cast<const float4*>(Xs + xtap[i][t]);                       \
-                a4.x = fmaf(v.x, wt[t].x, a4.x);                                                          \
-                a4.y = fmaf(v.y, wt[t].y, a4.y);                                                          \
-                a4.z = fmaf(v.z, wt[t].z, a4.z);                                                          \
-                a4.w = fmaf(v.w, wt[t].w, a4.w);                                                          \
-            }                                                                                             \
-            a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
-            f16x4 hi, lo;                                                                                 \
-            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
-            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
-            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
-            *reinterpret_cast<f16x4*>(Ah + (BUF) * A_BYTES + a_st[i]) = hi;                               \
-            *reinterpret_cast<f16x4*>(Al + (BUF) * A_BYTES + a_st[i]) = lo;                               \
-        }                                                                                                 \
-    }
-
-    const int frow = lane & 31;
-    const int fh = lane >> 5;
-#define BD_SEP_COMPUTE(BUF)                                                                               \
-    {                                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
-            f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                         \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
-                const int off = (BUF) * A_BYTES + swz64(wr * WM + i * 32 + frow, 2 * s + fh);             \
-                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
-                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
-            }                                                                                             \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
-                const int off = (BUF) * B_BYTES + swz64(wc * WN + j * 32 + frow, 2 * s + fh);             \
-                bh[j] = *reinterpret_cast<const f16x8*>(Bh + off);                                        \
-                bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                        \
-            }                                                                                             \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);     \
-            }                                                                                             \
-        }                                                                                                 \
-    }
-
-    // Software pipeline: the global loads of stage k+2 are issued right after stage k+1 has been written
-    // to LDS, so they have a whole depthwise phase and a whole MFMA phase to land.
-    // (K >= 64, i.e. at least two stages, is guaranteed by the launcher; every load below is
-    // unconditional so that the staging registers never become a stack object.)
-    const int nk = K / 32;
-    BD_SEP_LOAD(0)
-    BD_SEP_STORE(0)
-    BD_SEP_LOAD(32)
-    __syncthreads();
-    BD_SEP_DW(0)
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) {
-        const int buf = kt & 1;
-        BD_SEP_COMPUTE(buf)
-        BD_SEP_STORE(buf ^ 1)               // stage kt+1 (loaded one iteration ago); Xs is free again
-        BD_SEP_LOAD((kt + 2) * 32)
-        __syncthreads();
-        BD_SEP_DW(buf ^ 1)
-        __syncthreads();
-    }
-    {                                       // kt == nk - 2: last stage to stage
-        const int buf = kt & 1;
-        BD_SEP_COMPUTE(buf)
-        BD_SEP_STORE(buf ^ 1)
-        __syncthreads();
-        BD_SEP_DW(buf ^ 1)
-        __syncthreads();
-    }
-    BD_SEP_COMPUTE((nk - 1) & 1)
-#undef BD_SEP_LOAD
-#undef BD_SEP_STORE
-#undef BD_SEP_DW
-#undef BD_SEP_COMPUTE
-
-    const int half = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const long long m = m0 + wr * WM + i * 32 + frow;
-        float* crow = Cout + (size_t)(m < M ? m : 0) * N;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb = n0 + wc * WN + j * 32;
-            store_tile_t(acc[i][j], pw_b + nb, crow + nb, m < M, half);
-        }
-    }
-}
-
-template <int BM, int BN, int WGM, int WGN, int XPMAX>
-void launch_sep(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(XPMAX + 1 + 10) * 128 + 2u * 2u * (BM + BN) * 64;
-    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_s1_kernel<BM, BN, WGM, WGN, XPMAX>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const int tiles_n = L.cout / BN;
-    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
-    hipLaunchKernelGGL((sep_s1_kernel<BM, BN, WGM, WGN, XPMAX>), dim3((unsigned)tiles), dim3(256), lds, stream, X,
-                       L.dw_w, L.dw_b, static_cast<const _Float16*>(L.pw_whi), static_cast<const _Float16*>(L.pw_wlo),
-                       L.pw_b, out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n);
 }
 
 // Workgroup (or persistent tile index) -> (row tile, column tile).  Workgroups go to the 8 XCDs round-robin by ID
@@ -783,7 +528,7 @@ __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned t
 }
 
 // --------------------------------------------------------------------------- fused separable layer, wave-specialised
-// Same computation as sep_s1_kernel, restructured for the CU: a workgroup is 8 waves; waves 4-7 are
+// Depthwise inside the pointwise GEMM, laid out for the CU: a workgroup is 8 waves; waves 4-7 are
 // PRODUCERS (stage the f32 input slab, run the depthwise on the VALU, write the split-f16 A tile of
 // stage k+1) and waves 0-3 are CONSUMERS (stage the split-f16 weights, run the MFMAs of stage k).
 // Waves w and w+4 share a SIMD, so every SIMD has one matrix wave and one vector wave and the two
@@ -793,8 +538,7 @@ __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned t
 // BM = 96 output positions (3 MFMA row tiles; 4 / 1 / 16 whole windows for the 6x4 / 12x8 / 3x2 maps, a
 // band of 6 rows for the 24x16 map), BN = 128 or 256 output channels.  Arithmetic order is that of the
 // unfused kernels: results are bit-identical.
-// (ABL is a leftover template slot of the timing ablations used while tuning - no loads / no depthwise /
-//  no MFMA / one role idle / no store; their results are in DESIGN.md.  Always 0.)
+// (ABL = 1 is the clock-trace instantiation of the developer build, -DBD_KERNEL_TRACE; the shipped library only has 0.)
 // NDW = 3: band tiles of the 24x16 map that OVERLAP: a tile computes 6 rows (BM = 96) but advances 4, so it holds the
 // five rows its two output rows of the next layer's stride-2 depthwise need; that depthwise is applied in the
 // epilogue and only its [2][8][N] result is written (the 24x16 output and the stand-alone depthwise disappear,
@@ -1478,18 +1222,12 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
     const size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
     constexpr size_t lds_pipe_max = lds_pipe0 + (XD && !PWO ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
     constexpr size_t lds_max = lds_pipe_max > lds_tile ? lds_pipe_max : lds_tile;
-    static bool attr_set_dev[64] = {false};   // the attribute is per device; a process may drive several GPUs
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max + (ABL == 1 ? 1024 : 0));
-        attr_set = true;
-    }
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>, (int)lds_max + (ABL == 1 ? 1024 : 0), lds_once);
     constexpr int TSTEP = NDW == 3 ? 64 : BM;
     const int tiles_n = L.cout / BN;
     const long long tiles = ((M + TSTEP - 1) / TSTEP) * tiles_n;
+#ifdef BD_KERNEL_TRACE      // developer build only (-DBD_KERNEL_TRACE): per-barrier clock trace of one workgroup, selected by BD_WS_TRACE
     if constexpr (ABL == 0 && BDIR == 1 && VS == 1 && NDW == 0 && BM == 96) {
         // developer aid: BD_WS_TRACE=1 traces a 512-channel fused layer, =2 the 256-channel pointwise of layer 7
         const char* tr = getenv("BD_WS_TRACE");
@@ -1545,376 +1283,12 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
         }
         return;
     }
+#endif
     hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
                        static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
                        next ? next->dw_b : nullptr, out);
-}
-
-// --------------------------------------------------------------------------- persistent wave-specialised kernel
-// sep_ws_kernel (weights as register fragments, vertical tap sharing, slab ring by LDS-DMA, counted waits) as a
-// PERSISTENT workgroup: one workgroup per CU slot walks tiles b, b + G, b + 2 G ...  A tile of the one-shot kernel
-// spends ~18 % of its life in the prologue (kernel entry, tap loads, first slab round trip, first depthwise) and
-// ~8 % in the epilogue while the rest of the CU idles; for the 4-stage tiles of layer 4 that is half of the time.
-// Here the producer pipeline never stops at a tile boundary: during the last three stages of a tile it requests
-// the first three slabs of the next one, and during the last stage it computes the next tile's first A block.
-// The depthwise taps are loaded once per workgroup.  The output tile goes to HBM through a separate 32-row f32
-// chunk in LDS (three passes for 96 rows), so the epilogue no longer overwrites the pipeline buffers.
-// Covers the plain instantiations (no next-layer depthwise / pooling in the epilogue); arithmetic order is that of
-// sep_ws_kernel, results are bit-identical.  PWO = 1: pointwise only (producers split the slab rows to f16 hi + lo).
-template <int BN, int XPMAX, int BM, int PWO>
-__global__ __launch_bounds__(512, (BM == 64 && BN == 128) ? 4 : 2) void sep_wsp_kernel(
-    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
-    float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n, int tiles) {
-    static_assert((BM == 96 || BM == 64) && XPMAX % 32 == 0, "tile shape");
-    constexpr bool BAND = BM == 64;           // tile = band of rows inside one window (+ halo rows); else whole windows
-    constexpr int WN = BN / 4, TM = BM / 32, TN = WN / 32, LA = BM / 32;
-    constexpr int XS_FLOATS = (XPMAX + 1) * 32;
-    constexpr int A_BYTES = BM * 64;
-    constexpr int NG = XPMAX / 8, GPW = NG / 4, ND = GPW;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* const Xs = reinterpret_cast<float*>(smem_raw);              // [3][XS_FLOATS] slab ring (+ a zero row each)
-    char* const Ah = reinterpret_cast<char*>(Xs + 3 * XS_FLOATS);      // [2][A_BYTES]
-    char* const Al = Ah + 2 * A_BYTES;
-    float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K] depthwise taps + shift (not PWO)
-    float* const Cc = Wall + (PWO ? 0 : 10 * K);                       // [32][BN + 4] output chunk
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = K / 32;                    // even, >= 4 (launcher)
-    const int P = H * W;
-    const int G = gridDim.x;
-    const int t_first = blockIdx.x;           // < tiles (launcher)
-    const unsigned tiles_m = (unsigned)((M + BM - 1) / BM);
-
-    if (wave >= 4) {
-        // ================================================================= producers
-        const int pt = tid - 256;
-        const int lrow = pt >> 3, lc4 = pt & 7;
-        const int pw = wave - 4;
-        // tile-independent part of the position map: slot -> (window in tile, row group, column)
-        const int lw = 31 - __builtin_clz(W);
-        int wl = 0, g = lrow;
-        if (P < BM) {
-            const int lg = 31 - __builtin_clz(P / LA);
-            wl = lrow >> lg;
-            g = lrow & ((1 << lg) - 1);
-        }
-        const int og = g >> lw, ow = g & (W - 1);
-        const int ml0 = wl * P + LA * og * W + ow;
-        int a_st[LA];
-#pragma unroll
-        for (int i = 0; i < LA; ++i) a_st[i] = swz64(PWO ? lrow + 32 * i : ml0 + i * W, lc4 >> 1) + (lc4 & 1) * 8;
-        // tap table of a tile whose first row is row oh_a of its window (0 for whole-window tiles)
-        int xt_a[(LA + 2) * 3];
-#define BP_MAKE_XT(XT, OH_A)                                                                              \
-    {                                                                                                     \
-        const int oh0_ = (OH_A) + LA * og;                                                                \
-        const int xc0_ = ml0 + (BAND && (OH_A) > 0 ? W : 0);                                              \
-        _Pragma("unroll") for (int r = 0; r < LA + 2; ++r) _Pragma("unroll") for (int c = 0; c < 3; ++c) { \
-            const int ih = oh0_ - 1 + r, iw = ow - 1 + c;                                                 \
-            const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;                                       \
-            XT[r * 3 + c] = (ok ? xc0_ + (r - 1) * W + (c - 1) : XPMAX) * 32 + lc4 * 4;                   \
-        }                                                                                                 \
-    }
-        const float* xs_a[GPW];
-        // slab source pointers of tile T (rows past the slab's end re-read its last row; never used)
-#define BP_GEOM(T, XSRC, OH_A)                                                                            \
-    {                                                                                                     \
-        unsigned tm_, tn_;                                                                                \
-        tile_of<BAND>((unsigned)(T), tiles_m, (unsigned)tiles_n, tm_, tn_);                                     \
-        const unsigned m0_ = tm_ * BM;                                                                    \
-        long long x_lo_;                                                                                  \
-        int x_cnt_;                                                                                       \
-        if (PWO || !BAND) {                                                                               \
-            x_lo_ = m0_;                                                                                  \
-            x_cnt_ = (int)((M - m0_) < BM ? (M - m0_) : BM);                                              \
-            OH_A = 0;                                                                                     \
-        } else {                                                                                          \
-            const unsigned n_ = m0_ / (unsigned)P;                                                        \
-            OH_A = (int)(m0_ % (unsigned)P) / W;                                                          \
-            const int oh_b_ = OH_A + BM / W;                                                              \
-            const int r0_ = OH_A > 0 ? OH_A - 1 : 0;                                                      \
-            const int r1_ = oh_b_ < H ? oh_b_ + 1 : H;                                                    \
-            x_lo_ = ((long long)n_ * H + r0_) * W;                                                        \
-            x_cnt_ = (r1_ - r0_) * W;                                                                     \
-        }                                                                                                 \
-        _Pragma("unroll") for (int q = 0; q < GPW; ++q) {                                                 \
-            int row = 8 * (GPW * pw + q) + (lane >> 3);                                                   \
-            row = row < x_cnt_ ? row : x_cnt_ - 1;                                                        \
-            XSRC[q] = X + (size_t)(x_lo_ + row) * K + (lane & 7) * 4 - 256 * q;                           \
-        }                                                                                                 \
-    }
-#define BP_DMA1(Q, XSRC, KOFF, XB)                                                                        \
-    if constexpr ((Q) < GPW)                                                                              \
-        __builtin_amdgcn_global_load_lds(                                                                 \
-            (const __attribute__((address_space(1))) void*)(XSRC[(Q) < GPW ? (Q) : 0] + (KOFF)),          \
-            (__attribute__((address_space(3))) void*)(Xs + (XB) * XS_FLOATS + GPW * pw * 256), 16, 1024 * (Q), 0);
-#define BP_DMA(XSRC, KOFF, XB) { BP_DMA1(0, XSRC, KOFF, XB) BP_DMA1(1, XSRC, KOFF, XB) BP_DMA1(2, XSRC, KOFF, XB) BP_DMA1(3, XSRC, KOFF, XB) }
-#define BP_SYNC(KEEP)                                                                                     \
-    {                                                                                                     \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-        __builtin_amdgcn_s_barrier();                                                                     \
-        asm volatile("" ::: "memory");                                                                    \
-    }
-        // depthwise (or plain split) of ring slot XB, channels KCH .. KCH + 31, into A block AB
-#define BP_WORK(XB, AB, XT, KCH)                                                                          \
-    if constexpr (PWO) {                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
-            const v4f a4 = *reinterpret_cast<const v4f*>(Xs + (XB) * XS_FLOATS + (lrow + 32 * i) * 32 + lc4 * 4); \
-            f16x4 hi, lo;                                                                                 \
-            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
-            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
-            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
-            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
-            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
-        }                                                                                                 \
-    } else {                                                                                              \
-        const float* xs_ = Xs + (XB) * XS_FLOATS;                                                         \
-        const float* ws_ = Wall + (KCH) + lc4 * 4;                                                        \
-        v4f wt[9];                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * K); \
-        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * K);                                     \
-        v4f xv[(LA + 2) * 3];                                                                             \
-        _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t) xv[t] = *reinterpret_cast<const v4f*>(xs_ + XT[t]); \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
-            v4f a4 = bias4;                                                                               \
-            _Pragma("unroll") for (int t = 0; t < 9; ++t) a4 = __builtin_elementwise_fma(xv[i * 3 + t], wt[t], a4); \
-            a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
-            f16x4 hi, lo;                                                                                 \
-            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
-            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
-            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
-            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
-            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
-        }                                                                                                 \
-    }
-        // output rows of chunk I of tile (M0T, N0T): all 8 waves, 16 bytes per lane
-#define BP_STORE_CHUNK(I, M0T, N0T)                                                                       \
-    {                                                                                                     \
-        constexpr int C4_ = BN / 4;                                                                       \
-        _Pragma("unroll") for (int it = 0; it < 32 * C4_ / 512; ++it) {                                   \
-            const int id = tid + 512 * it;                                                                \
-            const int ml = id / C4_, c4_ = id % C4_;                                                      \
-            const long long m = (long long)(M0T) + 32 * (I) + ml;                                         \
-            if (m < M)                                                                                    \
-                *reinterpret_cast<v4f*>(Cout + (size_t)m * N + (N0T) + c4_ * 4) =                         \
-                    *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);                          \
-        }                                                                                                 \
-    }
-        if (pt < 24) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
-        int oh_a = 0;
-        BP_GEOM(t_first, xs_a, oh_a)
-        BP_DMA(xs_a, 0, 0)
-        BP_DMA(xs_a, 32, 1)
-        BP_DMA(xs_a, 64, 2)
-        if constexpr (!PWO) {
-            constexpr int TI = 10;
-            const int n_w = 9 * (K / 4), n_all = 10 * (K / 4);
-            v4f tw_[TI];
-#pragma unroll
-            for (int j = 0; j < TI; ++j) {
-                const int i = pt + 256 * j;
-                if (i < n_all) tw_[j] = *reinterpret_cast<const v4f*>(i < n_w ? dw_w + 4 * (size_t)i : dw_b + 4 * (size_t)(i - n_w));
-            }
-#pragma unroll
-            for (int j = 0; j < TI; ++j) {
-                const int i = pt + 256 * j;
-                if (i < n_all) *reinterpret_cast<v4f*>(Wall + 4 * (size_t)i) = tw_[j];
-            }
-            BP_MAKE_XT(xt_a, oh_a)
-        }
-        BP_SYNC(2 * ND)                       // slab 0 has landed, the taps are written
-        BP_WORK(0, 0, xt_a, 0)
-        BP_SYNC(ND)                           // A[0] written; slab 1 has landed
-        int rs = 1;                           // ring slot of the slab that the next stage's depthwise reads
-        for (int t = t_first; t < tiles; t += G) {
-            const bool has_next = t + G < tiles;
-            for (int k = 0; k < nk; ++k) {
-                // from stage nk-3 on every request is for the next tile: its geometry replaces this tile's
-                if (k == nk - 3 && has_next) BP_GEOM(t + G, xs_a, oh_a)
-                const int r3 = rs == 0 ? 2 : rs - 1;          // slot of the slab consumed during the previous stage
-                const bool issued = k + 3 < nk || has_next;
-                if (issued) BP_DMA(xs_a, (k + 3 < nk ? k + 3 : k + 3 - nk) * 32, r3)
-                if (k + 1 < nk) {
-                    BP_WORK(rs, (k + 1) & 1, xt_a, (k + 1) * 32)
-                } else if (has_next) {        // the next tile's first A block, during this tile's last MFMA stage
-                    if constexpr (!PWO && BAND) BP_MAKE_XT(xt_a, oh_a)
-                    BP_WORK(rs, 0, xt_a, 0)
-                }
-                if (issued) BP_SYNC(ND) else BP_SYNC(0)
-                rs = rs == 2 ? 0 : rs + 1;
-            }
-            // ---- epilogue: the consumers fill the chunk, everybody stores it ----
-            unsigned tm_t, tn_t;
-            tile_of<(BM == 64)>((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
-            const unsigned m0t = tm_t * BM;
-            const int n0t = (int)tn_t * BN;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                __syncthreads();
-                BP_STORE_CHUNK(i, m0t, n0t)
-                __syncthreads();
-            }
-        }
-    } else {
-        // ================================================================= consumers
-        const int wc = wave;
-        const int frow = lane & 31, fh = lane >> 5;
-        f16x8 b0h[TN][2], b0l[TN][2], b1h[TN][2], b1l[TN][2];
-        const _Float16* wph[TN];
-        const _Float16* wpl[TN];
-#define BP_WPTR(N0T)                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                      \
-        const size_t frag = ((size_t)(((N0T) + wc * WN) / 32 + j) * (K / 16) * 64 + lane) * 8;            \
-        wph[j] = Wfhi + frag;                                                                             \
-        wpl[j] = Wflo + frag;                                                                             \
-    }
-#define BP_W_LOAD(BH, BL, KOFF)                                                                           \
-    {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s) {    \
-            BH[j][s] = *reinterpret_cast<const f16x8*>(wph[j] + (KOFF) * 32 + 512 * s);                   \
-            BL[j][s] = *reinterpret_cast<const f16x8*>(wpl[j] + (KOFF) * 32 + 512 * s);                   \
-        }                                                                                                 \
-    }
-#define BP_W_MFMA(BUF, BH, BL)                                                                            \
-    {                                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
-            f16x8 ah[TM], al[TM];                                                                         \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
-                const int off = (BUF) * A_BYTES + swz64(i * 32 + frow, 2 * s + fh);                       \
-                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
-                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
-            }                                                                                             \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], BH[j][s], acc[i][j], 0, 0, 0);  \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BL[j][s], acc[i][j], 0, 0, 0);  \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BH[j][s], acc[i][j], 0, 0, 0);  \
-            }                                                                                             \
-        }                                                                                                 \
-    }
-        {
-            unsigned tm0_, tn0_;
-            tile_of<(BM == 64)>((unsigned)t_first, tiles_m, (unsigned)tiles_n, tm0_, tn0_);
-            BP_WPTR((int)tn0_ * BN)
-        }
-        BP_W_LOAD(b0h, b0l, 0)
-        BP_W_LOAD(b1h, b1l, 32)
-        __syncthreads();
-        __syncthreads();
-        for (int t = t_first; t < tiles; t += G) {
-            unsigned tm_t, tn_t;
-            tile_of<(BM == 64)>((unsigned)t, tiles_m, (unsigned)tiles_n, tm_t, tn_t);
-            const unsigned m0t = tm_t * BM;
-            const int n0t = (int)tn_t * BN;
-            f32x16 acc[TM][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-            int k = 0;
-            for (; k + 2 < nk; k += 2) {
-                BP_W_MFMA(0, b0h, b0l)
-                BP_W_LOAD(b0h, b0l, (k + 2) * 32)
-                __syncthreads();
-                BP_W_MFMA(1, b1h, b1l)
-                BP_W_LOAD(b1h, b1l, (k + 3) * 32)
-                __syncthreads();
-            }
-            BP_W_MFMA(0, b0h, b0l)
-            __syncthreads();
-            BP_W_MFMA(1, b1h, b1l)
-            if (t + G < tiles) {              // the next tile's first two fragment sets, in flight during the epilogue
-                unsigned tmn_, tnn_;
-                tile_of<(BM == 64)>((unsigned)(t + G), tiles_m, (unsigned)tiles_n, tmn_, tnn_);
-                BP_WPTR((int)tnn_ * BN)
-                BP_W_LOAD(b0h, b0l, 0)
-                BP_W_LOAD(b1h, b1l, 32)
-            }
-            __syncthreads();
-            // ---- epilogue: bias + ReLU, 32 rows at a time through the chunk ----
-            float bias_[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bias_[j] = pw_b[n0t + wc * WN + j * 32 + frow];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int nl = wc * WN + j * 32 + frow;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = 4 * fh + (r & 3) + 8 * (r >> 2);
-                        Cc[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + bias_[j], 0.0f);
-                    }
-                }
-                __syncthreads();
-                BP_STORE_CHUNK(i, m0t, n0t)
-                __syncthreads();
-            }
-        }
-    }
-#undef BP_MAKE_XT
-#undef BP_GEOM
-#undef BP_DMA1
-#undef BP_DMA
-#undef BP_SYNC
-#undef BP_WORK
-#undef BP_STORE_CHUNK
-#undef BP_WPTR
-#undef BP_W_LOAD
-#undef BP_W_MFMA
-}
-
-// compute units of the current device (cached per device)
-static int device_cus() {
-    static int cus_dev[64] = {0};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    int& c = cus_dev[dev_ & 63];
-    if (c == 0) {
-        hipDeviceProp_t prop;
-        (void)hipGetDeviceProperties(&prop, dev_);
-        c = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return c;
-}
-
-// Should a launch with this many tiles use the persistent kernel?  Measured on one box (1024-window batches):
-// one analyzer stream 1.181 M windows/s persistent vs 1.155 M one-shot, but with two streams (the default way to
-// run, bench.py and the reference's analyzers_gpu) 1.25 M vs 1.27 M - a persistent workgroup holds 136 KB of LDS
-// per CU for the whole launch, so the other stream's workgroups cannot slip into the gaps, which are exactly what
-// it removes on its own.  So: off unless asked for (BD_PERSISTENT=1, or explicit kernel variant 11).
-static bool persistent_pays(long long tiles, bool pointwise_only = false) {
-    static const char* mode = getenv("BD_PERSISTENT");          // "1": everywhere, "pw": pointwise-only launches
-    const bool on = mode && (mode[0] == '1' || (pointwise_only && mode[0] == 'p'));
-    return on && tiles > device_cus();
-}
-
-template <int BN, int XPMAX, int BM, int PWO>
-void launch_sep_wsp(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
-    const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * BM * 64 + (PWO ? 0 : (size_t)40 * L.cin) + 32u * (BN + 4) * 4;
-    constexpr size_t lds_max = 3u * (XPMAX + 1) * 128 + 4u * BM * 64 + (PWO ? 0u : 40u * 1024u) + 32u * (BN + 4) * 4;
-    static bool attr_set_dev[64] = {false};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    if (!attr_set_dev[dev_ & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_wsp_kernel<BN, XPMAX, BM, PWO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        attr_set_dev[dev_ & 63] = true;
-    }
-    const int tiles_n = L.cout / BN;
-    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
-    const long long slots = (long long)device_cus() * ((BM == 64 && BN == 128) ? 2 : 1);
-    const int grid = (int)(tiles < slots ? tiles : slots);
-    hipLaunchKernelGGL((sep_wsp_kernel<BN, XPMAX, BM, PWO>), dim3((unsigned)grid), dim3(512), lds, stream, X, L.dw_w, L.dw_b,
-                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
-                       L.cout, L.cin, L.h_out, L.w_out, tiles_n, (int)tiles);
 }
 
 // --------------------------------------------------------------------------- 12-wave form for N = 512
@@ -2176,15 +1550,10 @@ template <int XPMAX>
 void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
     const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + (size_t)40 * L.cin + 32u * (512 + 4) * 4;
     constexpr size_t lds_max = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + 40u * 512u + 32u * (512 + 4) * 4;
-    static bool attr_set_dev[64] = {false};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    if (!attr_set_dev[dev_ & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        attr_set_dev[dev_ & 63] = true;
-    }
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&sep_w12_kernel<XPMAX, false>, (int)lds_max, lds_once);
     const long long tiles = (M + 95) / 96;
+#ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=3 traces one workgroup of this kernel
     const char* tr = getenv("BD_WS_TRACE");
     if (tr && tr[0] == '3') {
         static unsigned* dbg = nullptr;
@@ -2214,196 +1583,15 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
             }
         return;
     }
+#endif
     hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
                        static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
                        L.cin, L.h_out, L.w_out, nullptr);
 }
 
-// --------------------------------------------------------------------------- fused stem
-// Layers 1-2 in one kernel: Conv2D 3x3 s2 (1->32) -> depthwise 3x3 s1 -> pointwise 32->64, each with
-// its folded BatchNorm + ReLU (yamnet.py:77-79).  Unfused these three launches move 1.2 GB per 1024
-// windows (conv1 out, depthwise in/out, pointwise in) around the one tensor that has to exist, the
-// layer-2 output; here a workgroup owns 4 output rows of one window, keeps the conv1 band (6 rows) and
-// the depthwise band (4 rows) in LDS, and writes only the [128 positions][64] result.
-// Arithmetic order per element is exactly that of conv1_kernel, depthwise_kernel and the split-f16
-// pointwise kernel, so the result is bit-identical to the unfused path.
-constexpr int kStemRows = 4;
-
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ logmel, int patch_step,
-                                                   const WindowMap map, int w0,
-                                                   const float* __restrict__ c1_w, const float* __restrict__ c1_b,
-                                                   const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-                                                   const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
-                                                   const float* __restrict__ pw_b, float* __restrict__ out) {
-    constexpr int LMR = 2 * kStemRows + 5;      // log-mel rows feeding 6 conv1 rows: 13
-    constexpr int C1R = kStemRows + 2;          // conv1 rows incl. the depthwise halo: 6
-    constexpr int BM = kStemRows * 32;          // 128 output positions
-    __shared__ __attribute__((aligned(16))) float s_lm[LMR][68];
-    __shared__ __attribute__((aligned(16))) float s_c1[C1R][34][32];
-    __shared__ __attribute__((aligned(16))) char s_ah[BM * 64];
-    __shared__ __attribute__((aligned(16))) char s_al[BM * 64];
-    // (the 64 x 32 weight tile is not staged: each lane loads its four MFMA B fragments, 4 x 16 bytes of
-    //  hi and lo, straight from global/L2 - that keeps the workgroup under 1/3 of the CU's LDS)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int win = blockIdx.y;
-    const int oh0 = blockIdx.x * kStemRows;
-    const float* patch = logmel + window_frame(map, w0 + win, patch_step) * BD_MEL_BANDS;
-
-    // ---- phase A: log-mel band, zero halo columns; this lane's weight fragments (used in phase D) ----
-    f16x8 wbh[2], wbl[2];
-    {
-        const int wrow = (wave & 1) * 32 + (lane & 31);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int koff = (2 * s2 + (lane >> 5)) * 8;
-            wbh[s2] = *reinterpret_cast<const f16x8*>(Whi + wrow * 32 + koff);
-            wbl[s2] = *reinterpret_cast<const f16x8*>(Wlo + wrow * 32 + koff);
-        }
-    }
-    for (int i = tid; i < LMR * 17; i += 256) {
-        const int j = i / 17, q = i % 17;
-        const int ih = 2 * oh0 - 2 + j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < 16 && ih >= 0 && ih < BD_PATCH_FRAMES) v = reinterpret_cast<const float4*>(patch + ih * BD_MEL_BANDS)[q];
-        *reinterpret_cast<float4*>(&s_lm[j][q * 4]) = v;      // q == 16: columns 64..67 stay zero (SAME pad right)
-    }
-    for (int i = tid; i < C1R * 2 * 8; i += 256) {
-        const int r = i / 16, side = (i >> 3) & 1, c4 = i & 7;
-        *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-
-    // ---- phase B: conv1 band (rows oh0-1 .. oh0+4) -> s_c1[.][1 + col][ch] ----
-    const int c4 = tid & 7;
-    const int col = tid >> 3;                                  // 0..31
-    {
-        float4 wt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(c1_w + t * 32)[c4];
-        const float4 bias = reinterpret_cast<const float4*>(c1_b)[c4];
-#pragma unroll
-        for (int i = 0; i < C1R; ++i) {
-            const int c1r = oh0 - 1 + i;
-            float4 acc = bias;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const float* row = &s_lm[2 * i + kh][2 * col];
-                const bool ok = 2 * c1r + kh < BD_PATCH_FRAMES;          // SAME pad bottom (row 96)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    if (!ok) continue;
-                    const float v = row[kw];
-                    const float4 w = wt[kh * 3 + kw];
-                    acc.x = fmaf(v, w.x, acc.x);
-                    acc.y = fmaf(v, w.y, acc.y);
-                    acc.z = fmaf(v, w.z, acc.z);
-                    acc.w = fmaf(v, w.w, acc.w);
-                }
-            }
-            const bool valid = c1r >= 0 && c1r < 48;                      // outside: zero padding of the depthwise
-            float4 r4;
-            r4.x = valid ? fmaxf(acc.x, 0.0f) : 0.0f;
-            r4.y = valid ? fmaxf(acc.y, 0.0f) : 0.0f;
-            r4.z = valid ? fmaxf(acc.z, 0.0f) : 0.0f;
-            r4.w = valid ? fmaxf(acc.w, 0.0f) : 0.0f;
-            *reinterpret_cast<float4*>(&s_c1[i][col + 1][c4 * 4]) = r4;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase C: depthwise on the band -> split-f16 A tile [128][32] ----
-    {
-        float4 wt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(dw_w + t * 32)[c4];
-        const float4 bias = reinterpret_cast<const float4*>(dw_b)[c4];
-        float4 acc[kStemRows];
-#pragma unroll
-        for (int r = 0; r < kStemRows; ++r) acc[r] = bias;
-        // taps must be applied per output in (kh, kw) order: walk the 6 band rows once, feeding each
-        // output row r its kh = i - r tap row while keeping that order (r descending => kh ascending per r)
-#pragma unroll
-        for (int r = 0; r < kStemRows; ++r) {
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float4 v = *reinterpret_cast<const float4*>(&s_c1[r + kh][col + kw][c4 * 4]);
-                    const float4 w = wt[kh * 3 + kw];
-                    acc[r].x = fmaf(v.x, w.x, acc[r].x);
-                    acc[r].y = fmaf(v.y, w.y, acc[r].y);
-                    acc[r].z = fmaf(v.z, w.z, acc[r].z);
-                    acc[r].w = fmaf(v.w, w.w, acc[r].w);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < kStemRows; ++r) {
-            float4 v = acc[r];
-            v.x = fmaxf(v.x, 0.0f);
-            v.y = fmaxf(v.y, 0.0f);
-            v.z = fmaxf(v.z, 0.0f);
-            v.w = fmaxf(v.w, 0.0f);
-            f16x4 hi, lo;
-            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-            const int off = swz64(r * 32 + col, c4 >> 1) + (c4 & 1) * 8;
-            *reinterpret_cast<f16x4*>(s_ah + off) = hi;
-            *reinterpret_cast<f16x4*>(s_al + off) = lo;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase D: [128][32] x [32][64] on the f16 matrix cores, 2 x 2 waves, wave tile 64 x 32 ----
-    const int wr = wave >> 1, wc = wave & 1;
-    const int frow = lane & 31, fh = lane >> 5;
-    f32x16 acc2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        f16x8 ah[2], al[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int off = swz64(wr * 64 + i * 32 + frow, 2 * s2 + fh);
-            ah[i] = *reinterpret_cast<const f16x8*>(s_ah + off);
-            al[i] = *reinterpret_cast<const f16x8*>(s_al + off);
-        }
-        const f16x8 bh = wbh[s2];
-        const f16x8 bl = wbl[s2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc2[i], 0, 0, 0);
-            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc2[i], 0, 0, 0);
-            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc2[i], 0, 0, 0);
-        }
-    }
-
-    // ---- phase E: bias + ReLU, store the 128 x 64 block (rows are consecutive NHWC positions).
-    // With 64-channel rows the untransposed map (a wave instruction writes two full 128-byte row halves)
-    // measured faster than 16-byte stores (151 vs 168 us per 1024 windows). ----
-    float* dst = out + ((size_t)win * 48 + oh0) * 32 * 64;
-    const int n = wc * 32 + frow;
-    const float b = pw_b[n];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int mb = wr * 64 + i * 32 + 4 * fh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mb + (r & 3) + 8 * (r >> 2);
-            dst[(size_t)m * 64 + n] = fmaxf(acc2[i][r] + b, 0.0f);
-        }
-    }
-}
-
 // --------------------------------------------------------------------------- fused stem + layer-3 depthwise
-// stem_kernel's chain extended by the stride-2 depthwise of layer 3 (yamnet.py:80): the layer-2 output
+// Layers 1-2 (conv 3x3 s2 -> depthwise 3x3 -> pointwise 32 -> 64) and the stride-2 depthwise of layer 3 (yamnet.py:77-80)
+// in one kernel, in the arithmetic order of conv1_kernel, depthwise_kernel and the split-f16 pointwise kernel: the layer-2 output
 // (the largest tensor of the network, 402 MB per 1024 windows) is never written.  A workgroup owns TWO
 // output rows of layer 3's depthwise in one window; they need five layer-2 rows (one is shared with the
 // neighbouring workgroup and computed twice), which need seven conv1 rows and fifteen log-mel rows.
@@ -2875,9 +2063,7 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
     if (rows <= 0 || rows >= (1LL << 31) || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0) return false;
     // (96 x 128 tiles with two workgroups per CU measured the same: 33.1 vs 32.6 us on layer 7)
-    const bool persistent = L.pw_variant16 == 11 || (L.pw_variant16 == 0 && persistent_pays(((rows + 95) / 96) * (L.cout / 256), true));
-    if (persistent) launch_sep_wsp<256, 96, 96, 1>(in, L, out, rows, stream);
-    else launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
+    launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
     return true;
 }
 
@@ -2908,71 +2094,31 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
     return true;
 }
 
-// Fused depthwise+pointwise for a stride-1 layer; returns false if the layer shape is not covered.
+// Fused depthwise+pointwise for a stride-1 layer; returns false if the layer shape is not covered (the caller then
+// runs the depthwise and the pointwise kernel one after the other).  variant: 0 / 1 = by shape (the default path);
+// 9 = always the 8-wave kernel (the 512 -> 512 layers otherwise run its 12-wave form, 12).
 bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
                             hipStream_t stream) {
-    if (L.stride != 1 || windows <= 0 || L.cin < 64) return false;
+    if (L.stride != 1 || windows <= 0 || L.cin < 128 || L.cin % 64 != 0) return false;
     const long long M = (long long)windows * L.h_out * L.w_out;
     if (M >= (1LL << 31)) return false;       // the kernels' tile arithmetic is 32-bit
     const int P = L.h_out * L.w_out;
-    // ... and the wave-specialised kernel's index arithmetic assumes power-of-two widths and rows in threes
-    const bool ws_shape = (L.w_out & (L.w_out - 1)) == 0 && (P > 96 || L.h_out % 3 == 0);
-    // auto (measured on MI355X): the 12x8, 6x4 and 3x2 maps run best on the wave-specialised kernel with
-    // 96-row x 256-column tiles; the 24x16 map (K = 128, only 4 stages per tile) on the same kernel with
-    // 64-row x 128-column tiles, small enough for two workgroups per CU
-    // (variant 9 = weights as register fragments, producers sharing taps vertically, input slab by LDS-DMA into
-    //  a ring of three; 7 = the same with register-staged slabs; 8 = 7 with 64-channel stages; 3 / 5 = the same
-    //  tiles with LDS-staged weights and one output per tap set - all kept as tested alternatives)
-    // (11 = variant 9 as a persistent workgroup: -5..-15 % per launch when a workgroup gets more than one tile,
-    //  neutral at one tile per CU; the 64-row layer-4 form spills under its 128-VGPR cap; see persistent_pays)
-    if (variant <= 1 && (P == 96 || P == 24 || P == 6) && L.cout % 256 == 0 && L.cin >= 128 && L.cin % 64 == 0)
-        variant = persistent_pays(((M + 95) / 96) * (L.cout / 256)) ? 11 : 9;
-    // 512 -> 512 channels: the 12-wave kernel computes the depthwise once per row tile instead of once per 256 columns
-    static const bool no_w12 = getenv("BD_NO_W12") != nullptr;    // developer switch for A/B timing
-    if (variant == 9 && L.cout == 512 && L.cin <= 512 && P <= 96 && !no_w12) variant = 12;
-    if (variant <= 1 && P == 384 && L.w_out == 16 && L.cout % 128 == 0 && L.cin >= 128 && L.cin % 64 == 0) variant = 9;   // layer 4
-    if (variant >= 3 && L.cin >= 128 && ws_shape) {                // wave-specialised kernels (BM = 96)
-        if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {      // layer 4: bands of 6 or 4 rows (+ halo rows)
-            if (variant == 11) launch_sep_wsp<128, 96, 64, 0>(in, L, out, M, stream);
-            else if (variant == 9) launch_sep_ws<128, 96, 0, 0, 64, 1, 1, 1, 1>(in, L, out, M, stream);
-            else if (variant >= 7) launch_sep_ws<128, 96, 0, 0, 64, 1, 1>(in, L, out, M, stream);
-            else if (variant == 5) launch_sep_ws<128, 96, 0, 0, 64>(in, L, out, M, stream);
-            else launch_sep_ws<128, 128>(in, L, out, M, stream);
-            return true;
-        }
-        if (P == 96 || P == 24 || P == 6) {
-            if (variant == 12 && L.cout == 512 && L.cin % 64 == 0 && L.cin <= 512 && P <= 96) launch_sep_w12<96>(in, L, out, M, stream);
-            else if (variant == 11 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_wsp<256, 96, 96, 0>(in, L, out, M, stream);
-            else if (variant == 9 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
-            else if (variant == 8 && L.cout % 256 == 0 && L.cin % 256 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 2>(in, L, out, M, stream);
-            else if (variant >= 7 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1, 1>(in, L, out, M, stream);
-            else if (variant == 6 && L.cout % 256 == 0 && L.cin % 64 == 0) launch_sep_ws<256, 96, 0, 0, 96, 1>(in, L, out, M, stream);
-            else if (L.cout % 256 == 0 && variant != 4) launch_sep_ws<256, 96>(in, L, out, M, stream);
-            else if (L.cout % 128 == 0) launch_sep_ws<128, 96>(in, L, out, M, stream);
-            else return false;
-            return true;
-        }
-        return false;
-    }
-    if (P == 384 && L.w_out == 16 && L.cout % 64 == 0) {          // layer 4: 24x16, bands of 8 rows
-        if (variant == 2 && L.cout % 128 == 0) launch_sep<128, 128, 2, 2, 160>(in, L, out, M, stream);
-        else launch_sep<128, 64, 2, 2, 160>(in, L, out, M, stream);
+    // the wave-specialised kernel's index arithmetic assumes power-of-two widths and rows in threes
+    if ((L.w_out & (L.w_out - 1)) != 0 || !(P > 96 || L.h_out % 3 == 0)) return false;
+    if (variant != 9 && variant != 12 && variant > 1) return false;
+    // measured on MI355X: the 12x8, 6x4 and 3x2 maps run best with 96-row x 256-column tiles; the 24x16 map (K = 128,
+    // only 4 stages per tile) with 64-row x 128-column tiles, small enough for two workgroups per CU
+    if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {          // layer 4: bands of 4 rows (+ halo rows)
+        launch_sep_ws<128, 96, 0, 0, 64, 1, 1, 1, 1>(in, L, out, M, stream);
         return true;
     }
-    if ((P == 96 || P == 24 || P == 6) && L.cout % 128 == 0) {    // layers 6, 8-12, 14: whole windows, 96 rows
-        if (variant == 2 && L.cout % 256 == 0) launch_sep<96, 256, 1, 4, 96>(in, L, out, M, stream);
-        else launch_sep<96, 128, 1, 4, 96>(in, L, out, M, stream);
+    if ((P == 96 || P == 24 || P == 6) && L.cout % 256 == 0) {
+        // 512 -> 512 channels: the 12-wave kernel computes the depthwise once per row tile instead of once per 256 columns
+        if (variant != 9 && L.cout == 512 && L.cin <= 512) launch_sep_w12<96>(in, L, out, M, stream);
+        else launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
         return true;
     }
     return false;
-}
-
-void launch_stem(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                 const float* c1_b, const SepLayer& L2, float* out, hipStream_t stream) {
-    if (windows <= 0) return;
-    hipLaunchKernelGGL(stem_kernel, dim3(48 / kStemRows, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
-                       c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, out);
 }
 
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
@@ -2987,13 +2133,18 @@ void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int
 void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-    static unsigned* dbg = nullptr;          // developer aid: BD_STEM_TRACE=1 prints a phase-level clock trace
+#ifdef BD_KERNEL_TRACE      // developer build only: BD_STEM_TRACE=1 prints a phase-level clock trace of one workgroup
+    static unsigned* dbg = nullptr;
     static int shots = 0;
     if (!dbg && getenv("BD_STEM_TRACE")) (void)hipMalloc(&dbg, 64);
+#else
+    unsigned* const dbg = nullptr;
+#endif
     hipLaunchKernelGGL(stem3_kernel<true>, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
                        c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
                        static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out,
                        static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_b, dbg);
+#ifdef BD_KERNEL_TRACE
     if (dbg) {
         (void)hipStreamSynchronize(stream);
         unsigned h[16];
@@ -3002,6 +2153,7 @@ void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int
             fprintf(stderr, "[trace] stem (layers 1-3), one workgroup, cycles: weights+setup %u | A log-mel band %u | B conv1 %u | C depthwise2 %u | D gemm2 %u | E tile %u | F depthwise3 %u | G gemm3 %u | H store %u | total %u\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[9] - h[8], h[9] - h[0]);
     }
+#endif
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,

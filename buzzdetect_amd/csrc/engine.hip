@@ -50,10 +50,9 @@ struct bd_engine {
     int n_classes = 0;
     int group_windows = kDefaultGroup;
     int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA
-    int frontend_variant = 0;         // 0 = radix-4 x 4 passes, 1 = radix-16 x 16 (one LDS transpose)
-    bool fuse_stem = true;            // layers 1-2 as one kernel (split-f16 mode only)
+    bool fuse_stem = true;            // layers 1-2 and the depthwise of layer 3 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
-    bool fuse_stem3 = true;           // the stem also applies layer 3's depthwise (needs fuse_stem)
+    bool fuse_stem3 = true;           // (always equal to fuse_stem: the layers 1-2 only kernel is gone)
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     int sep_variant = 0;
@@ -216,7 +215,6 @@ int build_tables(const float* mel, bd::FeTables* t) {
         const double a = -2.0 * M_PI * k / 512.0;
         t->tw512[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
-    int max_len = 1;
     for (int m = 0; m < BD_MEL_BANDS; ++m) {
         const int first = bd::kMelStart[m], len = bd::kMelLen[m];
         for (int k = 0; k < BD_SPECTRUM_BINS; ++k) {
@@ -226,15 +224,8 @@ int build_tables(const float* mel, bd::FeTables* t) {
                 return fail(BD_EWEIGHTS, "mel matrix has a non-zero outside the 64-band YAMNet filterbank pattern "
                                          "(linear_to_mel_weight_matrix(64, 257, 16000, 125, 7500)); not a YAMNet front end");
         }
-        t->band_start[m] = first;
-        t->band_len[m] = len;
-        if (len > max_len) max_len = len;
-        for (int j = 0; j < len; ++j) {
-            t->band_w[j][m] = mel[(first + j) * BD_MEL_BANDS + m];
-            t->melw[bd::mel_offset(m) + j] = mel[(first + j) * BD_MEL_BANDS + m];
-        }
+        for (int j = 0; j < len; ++j) t->melw[bd::mel_offset(m) + j] = mel[(first + j) * BD_MEL_BANDS + m];
     }
-    t->max_len = max_len;
     return BD_OK;
 }
 
@@ -508,7 +499,7 @@ int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t ho
     if (h->profiling) Scope::mark(h, (hipStream_t)stream, -1);
     {
         Scope sc(h, (hipStream_t)stream, 0);
-        bd::launch_logmel(pcm_dev, n_samples, g.n_frames, logmel_dev, h->d_tables, (hipStream_t)stream, h->frontend_variant);
+        bd::launch_logmel(pcm_dev, n_samples, g.n_frames, logmel_dev, h->d_tables, (hipStream_t)stream);
     }
     BD_HIP(hipGetLastError());
     return BD_OK;
@@ -660,8 +651,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
     for (int c = 0; c < n_chunks; ++c) {       // one front-end launch per chunk: its padding is its own
         Scope sc(e, stream, 0);
         bd::launch_logmel(pcm + plan.sample_base[c], chunk_samples[c], plan.frames[c],
-                          logmel + (int64_t)plan.map.frame_base[c] * BD_MEL_BANDS, e->d_tables, stream,
-                          e->frontend_variant);
+                          logmel + (int64_t)plan.map.frame_base[c] * BD_MEL_BANDS, e->d_tables, stream);
     }
     const float* const lm = logmel;
     for (int64_t w0 = 0; w0 < g.n_windows; w0 += group) {
@@ -671,7 +661,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
         // from the sized assignment: A = 98 304 floats/window, B = 49 152
         float* buf_a = buf_a0;
         float* buf_b = buf_b0;
-        // layers 1-2 run as one fused kernel (split-f16 mode) unless a test taps inside them
+        // layers 1-3 run as one fused kernel (split-f16 mode) unless a test taps inside them
         const bool fuse_stem = e->fuse_stem && e->pointwise_mode == 1 && (stop_stage < 0 || stop_stage >= 2);
         const float* last = buf_a;
         int64_t last_floats = 0;
@@ -699,14 +689,6 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             last_floats = (int64_t)gw * 24 * 16 * 64;
             first_layer = 1;
             skip_dw3 = true;
-        } else if (fuse_stem) {
-            {
-                Scope sc(e, stream, 3);
-                bd::launch_stem(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, e->sep[0], buf_a, stream);
-            }
-            last_floats = (int64_t)gw * 48 * 32 * 64;
-            stopped = stop_stage == 2;
-            first_layer = 1;
         } else {
             {
                 Scope sc(e, stream, 1);
@@ -860,14 +842,11 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
     return BD_OK;
 }
 
-int bd_set_frontend_variant(bd_handle h, int32_t variant) {
-    if (!h || variant < 0 || variant > 1) return fail(BD_EINVAL, "bd_set_frontend_variant: variant must be 0 or 1");
-    h->frontend_variant = variant;
-    return BD_OK;
-}
-
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
+    if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
+    if (separable != 0 && separable != 1 && separable != 9 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 9 or 12");
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_stem4 = stem >= 3;

@@ -5,20 +5,24 @@
 // folded in as "samples past n_valid read as zero".  Nothing of [T,400] / [T,257] is ever
 // written to HBM.
 //
-// logmel_kernel: one 512-thread workgroup per CU walks groups of 64 STFT frames.
-//   FFT phase   sixteen lanes own a frame (four frames per wavefront, two rounds per group): the frame is
-//               read straight from global memory as 200 packed complex points z[n] = x[2n] + i x[2n+1]
-//               (+56 zeros), Hann-windowed, and transformed as 256 = 16 x 16: DFT-16 over n1 in
-//               registers, twiddle, ONE transpose through the wave's own LDS tile, DFT-16 over n2 in
-//               registers.  The packed spectrum goes through the same tile once more in natural order
-//               so that every lane can pick up the mirrored bins Z[256 - k] of half of its own bins and
-//               split BOTH X[k] and X[256 - k] out of one (Z[k], Z[256 - k]) pair.  |X| lands in a
-//               [64 frames][244] f32 tile.  Wave-level ordering only, no workgroup barrier.
-//   mel phase   lane = frame: each of the eight waves owns a run of mel bands (balanced by non-zeros);
+// logmel_kernel: one 1024-thread workgroup per CU (four waves per SIMD) walks groups of 64 STFT frames.
+//   FFT phase   sixteen lanes own a frame, a wave four frames: the frame is read straight from global memory
+//               (buffer resource: samples past the end read as zero) as 200 packed complex points
+//               z[n] = x[2n] + i x[2n+1] (+56 zeros), Hann-windowed, and transformed as 256 = 16 x 16:
+//               DFT-16 over n1 in registers, twiddle, ONE transpose through the wave's own LDS tile, DFT-16
+//               over n2 in registers - all on packed f32 pairs (v_pk_add/mul/fma with op_sel / neg modifiers).
+//               The upper half of the packed spectrum goes through the tile once more in natural order so
+//               that every lane can pick up the mirrored bins Z[256 - k] of half of its own bins and split
+//               BOTH X[k] and X[256 - k] out of one (Z[k], Z[256 - k]) pair.  |X| lands in a
+//               [64 frames][244] f32 tile.  Wave-level ordering only, no workgroup barrier inside the phase;
+//               the next group's samples are requested before the barrier that ends it.
+//   mel phase   lane = frame: each of the sixteen waves owns a run of mel bands (balanced by non-zeros);
 //               a band is a short run of bins, so its weights are wave-uniform and come in through
 //               scalar loads - 461 v_fmac per 64 frames instead of 18 per frame and lane, and every LDS
-//               read is a conflict-free 16-byte row read.  log() and a [64][64] staging tile follow.
-//   output      coalesced 256-byte rows of the [T,64] log-mel buffer.
+//               read is a conflict-free 16-byte row read.  log(), then the row is staged in the LDS region
+//               of the wave that will store it.
+//   output      coalesced 256-byte rows of the [T,64] log-mel buffer (buffer stores: rows past T are dropped).
+// Measured (profiles/r02_*): 37 us per 98 304 frames = 2.4 TB/s algorithmic; HBM traffic = algorithmic bytes.
 //
 // Algorithmic HBM traffic: 640 B read (160 new samples) + 256 B written per frame.
 #include "bd_internal.h"
@@ -30,194 +34,6 @@ namespace bd {
 
 namespace {
 
-constexpr int kWaves = 4;
-constexpr int kFramesPerWave = 4;
-constexpr int kGroupFrames = kWaves * kFramesPerWave;                         // 16 frames per pass
-constexpr int kGroupSamples = (kGroupFrames - 1) * BD_STFT_HOP + BD_STFT_WINDOW;  // 2800
-constexpr int kMelTaps = kMelMaxLen;   // mel weights a lane keeps in registers (bd_create refuses longer bands; YAMNet: 17)
-static_assert(kMelTaps % 6 == 0, "the mel loop runs in batches of six");
-
-// Each wavefront works on its own z / mag tile, and LDS executes one wave's DS instructions in order,
-// so passes of a frame only need their LDS traffic drained and the compiler kept from reordering
-// across the point - not a workgroup barrier.
-__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// Bank swizzle of the 256-entry float2 FFT tile.  The Stockham passes write with strides 4, 16 and 64 (index =
-// 4 l + r, 16 g + k + 4 r, 64 q + k + 16 r) and read contiguously; unswizzled, the strided ds_write_b64 are
-// 4-way bank-conflicted per half-wave and the kernel is LDS-bound.  XOR-ing the slot's low five bits with two
-// parities of index bits 5..7 makes every write and every contiguous read conflict-free (searched exhaustively
-// over the GF(2) maps of those bits; the mirrored read of the real-FFT split keeps a 2-way conflict).
-// Because only low bits change, each access pattern is "per-lane base ^ small constant".
-__device__ __forceinline__ constexpr int zsw_mask(int b5, int b6, int b7) { return ((b5 ^ b6) * 21) ^ ((b5 ^ b7) * 10); }
-__device__ __forceinline__ int zsw(int i) { return i ^ zsw_mask((i >> 5) & 1, (i >> 6) & 1, (i >> 7) & 1); }
-
-// forward DFT-4 of (u0..u3) -> (X0..X3) in place
-__device__ __forceinline__ void dft4(float2& u0, float2& u1, float2& u2, float2& u3) {
-    const float2 a = make_float2(u0.x + u2.x, u0.y + u2.y);
-    const float2 b = make_float2(u0.x - u2.x, u0.y - u2.y);
-    const float2 c = make_float2(u1.x + u3.x, u1.y + u3.y);
-    const float2 d = make_float2(u1.y - u3.y, -(u1.x - u3.x));   // -i * (u1 - u3)
-    u0 = make_float2(a.x + c.x, a.y + c.y);
-    u1 = make_float2(b.x + d.x, b.y + d.y);
-    u2 = make_float2(a.x - c.x, a.y - c.y);
-    u3 = make_float2(b.x - d.x, b.y - d.y);
-}
-
-__global__ __launch_bounds__(256, 4) void logmel_r4_kernel(const float* __restrict__ pcm, long long n_valid,
-                                                     long long n_frames, float* __restrict__ out,
-                                                     const FeTables* __restrict__ tab, unsigned* __restrict__ dbg) {
-#define FE_TS(I) if (dbg && blockIdx.x == 3 && threadIdx.x == 0 && group == blockIdx.x && fi == 1) dbg[I] = (unsigned)__builtin_readcyclecounter();
-    __shared__ __attribute__((aligned(16))) float s_pcm[kGroupSamples];
-    __shared__ __attribute__((aligned(16))) float2 s_z[kWaves][256];
-    __shared__ __attribute__((aligned(16))) float s_mag[kWaves][BD_SPECTRUM_BINS + 7];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    // Everything a lane needs from the constant tables is fixed for the whole kernel (its butterfly index,
-    // its bins, its band), so it lives in registers: per frame the LDS only carries the data itself.
-    float2 hann2[4];                      // Hann taps of the lane's four packed input points
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n2 = 2 * (lane + 64 * r);
-        hann2[r] = n2 < BD_STFT_WINDOW ? make_float2(tab->hann[n2], tab->hann[n2 + 1]) : make_float2(0.f, 0.f);
-    }
-    float2 tw[3][3];                      // twiddles of passes p = 4, 16, 64 for inputs 1..3
-    {
-        int pi = 0;
-#pragma unroll
-        for (int p = 4; p <= 64; p *= 4, ++pi) {
-            const int tstep = (lane & (p - 1)) * (64 / p);
-#pragma unroll
-            for (int r = 1; r <= 3; ++r) tw[pi][r - 1] = tab->tw256[(r * tstep) & 255];
-        }
-    }
-    float2 tws[4];                        // real-FFT split twiddles exp(-2 pi i k / 512), k = lane + 64 r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tws[r] = tab->tw512[lane + 64 * r];
-    // swizzled tile indices: contiguous accesses lane + 64 r, pass-1 / p=4 / p=16 write bases, mirrored reads
-    const int zi_lin = lane ^ ((lane >> 5) * 31);                    // (zi_lin ^ zsw_mask(0, r & 1, r >> 1)) + 64 r
-    const int zi_w1 = zsw(4 * lane);                                 // ^ r
-    const int zi_w4 = zsw(((lane & ~3) << 2) + (lane & 3));          // ^ 4 r
-    const int zi_w16 = zsw(((lane & ~15) << 2) + (lane & 15));       // ^ 16 r ^ (r >= 2 ? 31 : 0)
-#define BD_ZLIN(R) ((zi_lin ^ zsw_mask(0, (R) & 1, (R) >> 1)) + 64 * (R))
-    const int band_start = tab->band_start[lane];
-    const int band_len = tab->band_len[lane];
-    float bw[kMelTaps];                   // the band's mel weights (zero past band_len)
-#pragma unroll
-    for (int j = 0; j < kMelTaps; ++j) bw[j] = j < band_len ? tab->band_w[j][lane] : 0.0f;
-
-    float2* z = s_z[wave];
-    float* mag = s_mag[wave];
-    if (lane < 7) mag[BD_SPECTRUM_BINS + lane] = 0.0f;   // padding read by the fixed-length mel loop
-
-    const long long n_groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
-    for (long long group = blockIdx.x; group < n_groups; group += gridDim.x) {
-        __syncthreads();   // previous pass done with s_pcm
-        const long long base = group * (long long)(kGroupFrames * BD_STFT_HOP);
-        for (int i = tid; i < kGroupSamples; i += 256) {
-            const long long idx = base + i;
-            s_pcm[i] = idx < n_valid ? pcm[idx] : 0.0f;
-        }
-        __syncthreads();
-
-        for (int fi = 0; fi < kFramesPerWave; ++fi) {
-            const int fl = wave + kWaves * fi;
-            const long long frame = group * kGroupFrames + fl;
-            const float* x = s_pcm + fl * BD_STFT_HOP;
-
-            FE_TS(0)
-            // ---- pass 1 (p = 1): windowed samples straight from the PCM tile, no twiddles ----
-            float2 u[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n2 = 2 * (lane + 64 * r);   // z[n] = x[2n] + i x[2n+1]; zero past 400
-                if (n2 < BD_STFT_WINDOW) {
-                    const float2 xv = *reinterpret_cast<const float2*>(x + n2);
-                    u[r] = make_float2(xv.x * hann2[r].x, xv.y * hann2[r].y);
-                } else {
-                    u[r] = make_float2(0.0f, 0.0f);
-                }
-            }
-            dft4(u[0], u[1], u[2], u[3]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[zi_w1 ^ r] = u[r];
-            wave_lds_sync();
-
-            FE_TS(1)
-            // ---- passes 2..4 (p = 4, 16, 64) ----
-            {
-                int pi = 0;
-#pragma unroll
-                for (int p = 4; p <= 64; p *= 4, ++pi) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) u[r] = z[BD_ZLIN(r)];
-                    u[1] = cmul(u[1], tw[pi][0]);
-                    u[2] = cmul(u[2], tw[pi][1]);
-                    u[3] = cmul(u[3], tw[pi][2]);
-                    dft4(u[0], u[1], u[2], u[3]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = p == 4 ? (zi_w4 ^ (4 * r)) : p == 16 ? (zi_w16 ^ (16 * r) ^ ((r >> 1) * 31)) : BD_ZLIN(r);
-                        z[j] = u[r];
-                    }
-                    wave_lds_sync();
-                }
-            }
-
-            FE_TS(2)
-            // ---- split the packed transform into the real spectrum, take magnitudes ----
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = lane + 64 * r;
-                const float2 zk = z[BD_ZLIN(r)];
-                const float2 zm = z[zsw((256 - (lane + 64 * r)) & 255)];
-                const float ex = 0.5f * (zk.x + zm.x);
-                const float ey = 0.5f * (zk.y - zm.y);
-                const float ox = 0.5f * (zk.y + zm.y);    // O = -i/2 * (Zk - conj(Zm))
-                const float oy = -0.5f * (zk.x - zm.x);
-                const float2 t = tws[r];
-                const float xr = ex + (t.x * ox - t.y * oy);
-                const float xi = ey + (t.x * oy + t.y * ox);
-                // v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf: its scale / class-test / select fix-ups were
-                // ~56 of a frame's ~245 vector instructions, and |X| only feeds log(mel + 0.001)
-                mag[k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
-            }
-            if (lane == 0) mag[256] = fabsf(z[0].x - z[0].y);
-            wave_lds_sync();
-
-            FE_TS(3)
-            // ---- banded mel reduction + log ----
-            // All kMelTaps reads are in bounds (band_start + 17 <= 257 + 6 of zero padding) and the weight is zero past
-            // band_len, where fmaf(m, 0, acc) returns acc exactly (m finite, acc >= +0): so no guards - twenty
-            // independent LDS reads in flight, then twenty FMAs.  With a uniform and a per-lane branch around every tap
-            // the compiler serialised read -> wait -> fma twenty times (1640 of a frame's 4570 cycles).
-            float acc = 0.0f;
-#pragma unroll
-            for (int j0 = 0; j0 < kMelTaps; j0 += 6) {        // three batches of six: the register budget is 128
-                float mv[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) mv[j] = mag[band_start + j0 + j];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc = fmaf(mv[j], bw[j0 + j], acc);
-            }
-            FE_TS(4)
-            if (frame < n_frames) out[frame * BD_MEL_BANDS + lane] = logf(acc + 0.001f);
-            wave_lds_sync();   // mag / z reads of this frame retire before the next frame overwrites them
-            FE_TS(5)
-        }
-    }
-#undef BD_ZLIN
-#undef FE_TS
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The default front end (see the header comment): 16 lanes per frame, 256 = 16 x 16, lane = frame mel.
 namespace fe {
 
 constexpr int kThreads = 1024;         // one workgroup per CU, four waves per SIMD (128 VGPRs): a wave issues one vector
@@ -498,7 +314,9 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restric
     for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
         // ---------------- FFT phase: this wave's four frames ----------------
         {
+#ifdef BD_FE_TRACE
             constexpr int round = 0;
+#endif
             const int fl = wave * 4 + fq;                      // frame within the group
             v2f u[16];
             FE_STAMP(round * 8 + 0)
@@ -718,15 +536,8 @@ void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const
 }
 
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
-                   const FeTables* tables, hipStream_t stream, int variant) {
+                   const FeTables* tables, hipStream_t stream) {
     if (n_frames <= 0) return;
-    if (variant == 1) {          // radix-4 x 4 passes, one wave per frame (reference formulation)
-        const int64_t groups = (n_frames + kGroupFrames - 1) / kGroupFrames;
-        const int grid = (int)(groups < 4096 ? groups : 4096);
-        hipLaunchKernelGGL(logmel_r4_kernel, dim3(grid), dim3(256), 0, stream, pcm, (long long)n_valid,
-                           (long long)n_frames, logmel, tables, (unsigned*)nullptr);
-        return;
-    }
     const int64_t groups = (n_frames + fe::kGroup - 1) / fe::kGroup;
     const int grid = (int)(groups < 256 ? groups : 256);      // one 149 KB, 16-wave workgroup per CU
 #ifdef BD_FE_TRACE

@@ -118,13 +118,10 @@ class HipEngine:
         """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class)."""
         _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1}[mode]))
 
-    def set_frontend_variant(self, variant: int) -> None:
-        """0 = radix-4 x 4-pass FFT, 1 = radix-16 x 16 FFT (one LDS transpose)."""
-        _lib.check(self._lib.bd_set_frontend_variant(self._handle, int(variant)))
-
     def set_fusion(self, stem=True, separable=True) -> None:
-        """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, 1 = layers 1-2 only,
-        False = off) and fused depthwise+pointwise kernels (True / variant number / False)."""
+        """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, False = off) and fused
+        depthwise+pointwise kernels (True = default path, 9 / 12 = plain fused layers on the 8-wave / 12-wave
+        kernel, False = one kernel per op)."""
         stem_code = 3 if stem is True else int(stem)
         _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))
 

@@ -176,21 +176,18 @@ BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int3
    1 = split-f16 (default): every f32 operand carried as hi + lo halves, three f16 MFMAs per product,
    f32 accumulate; same accuracy class as f32, ~5x the matrix-core rate. */
 BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
-/* Front-end FFT formulation: 0 = radix-4, four passes through LDS; 1 = radix-16 x radix-16 with one LDS
-   transpose (same definition; float summation order differs). */
-BD_API int bd_set_frontend_variant(bd_handle h, int32_t variant);
 
 /* Kernel fusion in mode 1 (both on by default; 0 = one kernel per op, the layout the stage taps use):
-   stem == 1       layers 1-2 (conv, depthwise, pointwise) as one kernel, timed in profile slot 3;
-   stem == 2       that kernel also applies layer 3's stride-2 depthwise and writes only its
-                   output (the 402 MB layer-2 tensor never reaches HBM); timed in profile slot 4;
-   stem >= 3       (default) ... and layer 3's pointwise convolution: layers 1-3 are one kernel that
+   stem == 2       layers 1-2 (conv, depthwise, pointwise) and layer 3's stride-2 depthwise as one kernel that
+                   writes only the depthwise output (the 402 MB layer-2 tensor never reaches HBM); profile slot 4;
+   stem == 3       (default) ... and layer 3's pointwise convolution: layers 1-3 are one kernel that
                    reads log-mel patches and writes the [24][16][128] layer-3 output; profile slot 5;
    separable != 0  stride-1 layers 4, 6, 8-12, 14: depthwise computed inside the pointwise GEMM, timed
-                   in the layer's pointwise slot (>= 2: explicit kernel variants, tuning only).  With 1
-                   (default) layers 6 and 12 also apply the NEXT layer's stride-2 depthwise in their
-                   epilogue, so depthwise 7 and 13 have no launch of their own.
-   Fused and unfused paths give bit-identical results. */
+                   in the layer's pointwise slot.  With 1 (default) layers 4, 6 and 12 also apply the NEXT
+                   layer's stride-2 depthwise in their epilogue, so depthwise 5, 7 and 13 have no launch of
+                   their own, and layer 14 average-pools in its epilogue.  9 / 12: plain fused layers on the
+                   8-wave kernel only / with the 12-wave kernel for 512 -> 512 channels (test hook).
+   Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);
 /* whi/wlo: [n][k] f16 halves of wt (wt ~= whi + wlo) */
 BD_API int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, const void* wlo_dev,

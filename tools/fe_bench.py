@@ -1,5 +1,5 @@
 """Time the front-end kernel alone: 98 304 frames (the 1024-window batch), HIP events around N launches.
-    python tools/fe_bench.py [variant] [reps]"""
+    python tools/fe_bench.py [reps]"""
 import os
 import sys
 
@@ -11,10 +11,8 @@ from buzzdetect_amd.engine import HipEngine  # noqa: E402
 from oracle import yamnet_oracle as O  # noqa: E402
 from buzzdetect_amd import weights as W  # noqa: E402
 
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+reps = int(sys.argv[-1]) if len(sys.argv) > 1 else 200
 eng = HipEngine()
-eng.set_frontend_variant(variant)
 hop = 15360
 n = hop * 1024
 gen = torch.Generator(device="cuda").manual_seed(5)
@@ -41,5 +39,5 @@ for rep in range(3):
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / reps
-    print(f"variant {variant}: {us:.1f} us per {t} frames = {t * 896 / us / 1e6:.2f} TB/s algorithmic "
+    print(f"logmel_kernel: {us:.1f} us per {t} frames = {t * 896 / us / 1e6:.2f} TB/s algorithmic "
           f"({t * 896 / us / 1e6 / 8 * 100:.1f} % of 8 TB/s)")

@@ -3,7 +3,7 @@
 # Run through gpurun from the repository root; output under gpurun_out/prof_fe_*; summarise with tools/summarize_pmc.py.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-S="python3 $R/tools/fe_bench.py 0 10"
+S="python3 $R/tools/fe_bench.py 10"
 rm -rf $R/gpurun_out/prof_fe_sq1 $R/gpurun_out/prof_fe_sq2 $R/gpurun_out/prof_fe_fetch $R/gpurun_out/prof_fe_write
 timeout -k 10 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS -d $R/gpurun_out/prof_fe_sq1 --output-format csv -- $S > $R/gpurun_out/prof_fe_sq1.log 2>&1 &&
 timeout -k 10 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES SQ_ACTIVE_INST_ANY -d $R/gpurun_out/prof_fe_sq2 --output-format csv -- $S > $R/gpurun_out/prof_fe_sq2.log 2>&1 &&
