@@ -1,0 +1,438 @@
+"""The feeder around the hot path: reader threads -> bounded queue -> analyzer threads -> writer thread.
+
+Same shape and semantics as the reference's worker pipeline (src/pipeline/coordination.py:26-194,
+src/stream/worker.py:109-165, src/inference/worker.py:9-92, src/write/worker.py:67-87), built so that an engine
+that consumes ~45 MB/s of 16-bit PCM per 10 k windows/s is not left waiting:
+
+    readers     one recording at a time each: chunk list (resume aware), chunk -> a slot of a ring of PINNED host
+                buffers (16-bit PCM as it lies in the file, anything else converted to float32), bounded queue
+                (depth 2 x readers, coordination.py:84-102).  NumPy's copy releases the GIL.
+    analyzers   `analyzers` threads per GPU (the reference's analyzers_gpu; docs/source/tuning.rst:111), each
+                constructing and initialising ITS OWN engine in-thread (src/inference/worker.py:21,78) on its own
+                HIP stream: async H2D from the pinned slot, device-side downmix / resample / s16 -> f32, up to 64
+                chunks (~1024 windows) per launch set, async D2H of the logits into pinned memory.
+    writer      waits for the batch's event, formats rows (fastcsv: the bytes pandas would write), appends to the
+                partial file, finalises a recording when its last chunk has been written.
+    logging     logger "buzzdetect", level PROGRESS = INFO - 5 (src/pipeline/loglevels.py): the reference's two
+                analyzer lines, "analyzed <file>, chunk (a, b) in <t>s (rate: <r>)" and
+                "BUFFER BOTTLENECK: analyzer <id> received assignment after <t>s".
+
+An exception in ANY stage poisons the pipeline: the first one is kept, every queue is released, `run` re-raises it
+after all threads have ended (the reference's workers die silently and leave the others blocked).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import queue
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import framing, results
+from .wavio import WavFormatError, WavTrack
+
+PROGRESS = logging.INFO - 5
+logging.addLevelName(PROGRESS, "PROGRESS")
+log = logging.getLogger("buzzdetect")
+
+EXIT = "exit"
+BATCH_WINDOWS = 1024              # windows gathered per launch set
+BATCH_CHUNKS = 64                 # bd_predict_batch's limit
+FILE_SIZE_MINIMUM = 5000          # src/config.py:20
+BOTTLENECK_SECONDS = 0.01         # src/inference/worker.py:86
+
+
+class PipelineAborted(Exception):
+    """Raised inside a worker that finds the pipeline poisoned by another stage."""
+
+
+@dataclass
+class FileJob:
+    path: str
+    ident: str
+    shortpath: str
+    rf: results.ResultFile
+    fresh: bool = True            # no partial results existed when the reader opened it
+    outstanding: int = 0          # chunks queued and not yet written
+    queued_all: bool = False
+    in_order: bool = True         # rows were appended in start order so far
+    last_start: float = -1.0
+
+
+@dataclass
+class ChunkTask:
+    job: FileJob
+    chunk: Tuple[float, float]
+    slot: int
+    nbytes: int
+    frames: int
+    channels: int
+    rate: int
+    s16: bool
+
+
+@dataclass
+class WriteItem:
+    tasks: List[ChunkTask]
+    host: "np.ndarray"            # [total windows, classes] pinned, filled when `done` has happened
+    counts: List[int]
+    done: object                  # torch.cuda.Event
+    analyzer: int
+    t_start: float
+
+
+@dataclass
+class Report:
+    files_total: int = 0
+    files_done: int = 0
+    files_skipped: int = 0
+    chunks: int = 0
+    windows: int = 0
+    audio_seconds: float = 0.0
+    messages: List[str] = field(default_factory=list)
+
+
+class PinnedRing:
+    """A fixed number of pinned host buffers handed out to readers and given back by analyzers once the H2D copy that
+    reads them has completed.  Buffers grow to the largest chunk seen."""
+
+    def __init__(self, slots: int):
+        import torch
+        self._torch = torch
+        self._free: "queue.Queue[int]" = queue.Queue()
+        self._buf: List[Optional["torch.Tensor"]] = [None] * slots
+        for i in range(slots):
+            self._free.put(i)
+
+    def acquire(self, nbytes: int, aborted: threading.Event):
+        while True:
+            if aborted.is_set():
+                raise PipelineAborted()
+            try:
+                slot = self._free.get(timeout=0.2)
+                break
+            except queue.Empty:
+                continue
+        buf = self._buf[slot]
+        if buf is None or buf.numel() < nbytes:
+            self._buf[slot] = buf = self._torch.empty(max(nbytes, 1 << 20), dtype=self._torch.uint8, pin_memory=True)
+        return slot, buf
+
+    def buffer(self, slot: int):
+        return self._buf[slot]
+
+    def release(self, slot: int) -> None:
+        self._free.put(slot)
+
+
+class Pipeline:
+    def __init__(self, *, make_engine: Callable[[], object], classes: Sequence[str], framehop_s: float, hop: int, step: int,
+                 chunklength: float, framelength_s: float, digits_time: int, digits_results: int, classes_out,
+                 threshold: Optional[float], readers: int = 4, analyzers: int = 2, device=None):
+        import torch
+        self.torch = torch
+        self.make_engine = make_engine
+        self.classes, self.classes_out, self.threshold = list(classes), classes_out, threshold
+        self.framehop_s, self.hop, self.step = framehop_s, hop, step
+        self.chunklength, self.framelength_s = chunklength, framelength_s
+        self.digits_time, self.digits_results = digits_time, digits_results
+        self.n_readers, self.n_analyzers = max(1, readers), max(1, analyzers)
+        self.device = device
+        self.q_files: "queue.Queue" = queue.Queue()
+        self.q_analyze: "queue.Queue" = queue.Queue(maxsize=2 * self.n_readers)      # coordination.py:129-138
+        self.q_write: "queue.Queue" = queue.Queue()
+        self.ring = PinnedRing(4 * self.n_readers + 16 * self.n_analyzers)     # queue + readers' hands + batches being copied
+        self.aborted = threading.Event()
+        self.error: Optional[BaseException] = None
+        self.lock = threading.Lock()
+        self.report = Report()
+
+    # ------------------------------------------------------------------ failure handling
+    def fail(self, exc: BaseException, who: str) -> None:
+        with self.lock:
+            if self.error is None and not isinstance(exc, PipelineAborted):
+                self.error = exc
+                log.error(f"{who}: {type(exc).__name__}: {exc}; stopping the analysis")
+        self.aborted.set()
+
+    def _put(self, q: "queue.Queue", item) -> None:
+        while True:
+            if self.aborted.is_set():
+                raise PipelineAborted()
+            try:
+                q.put(item, timeout=0.2)
+                return
+            except queue.Full:
+                continue
+
+    def _get(self, q: "queue.Queue"):
+        while True:
+            if self.aborted.is_set():
+                raise PipelineAborted()
+            try:
+                return q.get(timeout=0.2)
+            except queue.Empty:
+                continue
+
+    # ------------------------------------------------------------------ readers
+    def _read_file(self, rid: int, job: FileJob) -> None:
+        if job.rf.complete:
+            log.debug(f"streamer {rid}: Skipping {job.shortpath}; already analyzed")
+            with self.lock:
+                self.report.files_skipped += 1
+            return
+        if os.path.getsize(job.path) < FILE_SIZE_MINIMUM:
+            log.debug(f"streamer {rid}: Skipping {job.shortpath}; below minimum analyzeable size")
+            with self.lock:
+                self.report.files_skipped += 1
+            return
+        try:
+            track = WavTrack(job.path)
+        except (WavFormatError, OSError) as exc:           # one unreadable recording does not stop the others
+            log.warning(f"streamer {rid}: {exc}; skipping")
+            with self.lock:
+                self.report.messages.append(f"unreadable, skipped: {job.shortpath} ({exc})")
+                self.report.files_skipped += 1
+            return
+        try:
+            job.fresh = not os.path.exists(job.rf.path_partial)
+            chunks = job.rf.pending_chunks(track.duration, self.chunklength, self.framelength_s)
+            if not chunks:
+                with self.lock:
+                    self.report.files_skipped += 1
+                return
+            log.info(f"streamer {rid}: buffering {job.shortpath}")
+            sent = 0
+            for chunk in chunks:
+                a, b = framing.chunk_sample_range(chunk, track.samplerate)
+                track.seek(a)
+                want = b - a
+                if track.is_s16:
+                    data = track.read_s16(want)
+                else:
+                    data = track.read(want)
+                got = data.shape[0]
+                if got == 0:
+                    break
+                stop = got < want
+                if stop:                                   # short read: truncate the chunk, finish the file
+                    chunk = (chunk[0], round(chunk[0] + got / track.samplerate, 1))
+                nbytes = data.size * data.dtype.itemsize
+                slot, buf = self.ring.acquire(nbytes, self.aborted)
+                try:
+                    buf.numpy()[:nbytes] = data.reshape(-1).view(np.uint8)       # the one host copy; releases the GIL
+                    with self.lock:
+                        job.outstanding += 1
+                        self.report.chunks += 1
+                        self.report.audio_seconds += float(chunk[1] - chunk[0])
+                    self._put(self.q_analyze, ChunkTask(job, (float(chunk[0]), float(chunk[1])), slot, nbytes, got,
+                                                        track.channels, track.samplerate, track.is_s16))
+                except BaseException:
+                    self.ring.release(slot)
+                    raise
+                sent += 1
+                if stop:
+                    break
+            finish = False
+            with self.lock:
+                job.queued_all = True
+                finish = sent > 0 and job.outstanding == 0     # everything already written while we were reading
+                if sent == 0:
+                    self.report.files_skipped += 1
+            if finish:
+                self._put(self.q_write, job)
+        finally:
+            track.close()
+
+    def _reader(self, rid: int) -> None:
+        try:
+            while True:
+                job = self._get(self.q_files)
+                if job == EXIT:
+                    return
+                self._read_file(rid, job)
+        except PipelineAborted:
+            pass
+        except BaseException as exc:                       # noqa: BLE001 - every failure must poison the pipeline
+            self.fail(exc, f"streamer {rid}")
+
+    # ------------------------------------------------------------------ analyzers
+    def _analyzer(self, aid: int) -> None:
+        torch = self.torch
+        held: List[int] = []
+        try:
+            log.info(f"analyzer {aid}: launching")
+            engine = self.make_engine()                    # per-thread engine, initialised in-thread
+            device = engine.device
+            stream = torch.cuda.Stream(device)
+            n_classes = engine.n_classes
+            log.info(f"analyzer {aid}: processing on GPU")
+            t_wait = time.perf_counter()
+            finished = False
+            while not finished:
+                task = self._get(self.q_analyze)
+                if task == EXIT:
+                    break
+                waited = time.perf_counter() - t_wait
+                if waited > BOTTLENECK_SECONDS:
+                    log.debug(f"analyzer {aid}: BUFFER BOTTLENECK: analyzer {aid} received assignment after {round(waited, 1)}s")
+                t_start = time.perf_counter()
+                batch = [task]
+                windows = engine.num_windows(self._out_samples(task), self.hop, self.step)
+                while windows < BATCH_WINDOWS and len(batch) < BATCH_CHUNKS:
+                    try:
+                        nxt = self.q_analyze.get_nowait()
+                    except queue.Empty:
+                        break
+                    if nxt == EXIT:
+                        finished = True
+                        break
+                    batch.append(nxt)
+                    windows += engine.num_windows(self._out_samples(nxt), self.hop, self.step)
+                held = [t.slot for t in batch]
+                with torch.cuda.stream(stream):
+                    pcms = []
+                    for t in batch:
+                        pinned = self.ring.buffer(t.slot)[: t.nbytes]
+                        dev = torch.empty(t.nbytes, dtype=torch.uint8, device=device)
+                        dev.copy_(pinned, non_blocking=True)
+                        view = dev.view(torch.int16 if t.s16 else torch.float32).view(t.frames, t.channels)
+                        if t.s16 or t.rate != 16000 or t.channels > 1:
+                            pcms.append(engine.resample(view, t.rate, 16000))     # also s16 -> f32 and the channel mean
+                        else:
+                            pcms.append(view[:, 0])
+                    copied = torch.cuda.Event()
+                    copied.record(stream)
+                    res = engine.predict_batch(pcms, self.framehop_s)
+                    counts = [len(r) for r in res]
+                    total = sum(counts)
+                    host = torch.empty((max(total, 1), n_classes), dtype=torch.float32, pin_memory=True)[:total]
+                    if total:
+                        # the per-chunk results are consecutive row blocks of one device tensor
+                        base = res[0].tensor
+                        whole = torch.as_strided(base, (total, n_classes), (n_classes, 1), base.storage_offset())
+                        host.copy_(whole, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                self._put(self.q_write, WriteItem(batch, host.numpy(), counts, done, aid, t_start))
+                copied.synchronize()                       # the pinned slots have been read: hand them back
+                for s in held:
+                    self.ring.release(s)
+                held = []
+                t_wait = time.perf_counter()
+            log.debug(f"analyzer {aid}: terminating")
+        except PipelineAborted:
+            pass
+        except BaseException as exc:                       # noqa: BLE001
+            self.fail(exc, f"analyzer {aid}")
+        finally:
+            for s in held:
+                self.ring.release(s)
+
+    def _out_samples(self, t: ChunkTask) -> int:
+        """16 kHz samples the chunk becomes (resample_poly's length)."""
+        if t.rate == 16000:
+            return t.frames
+        from math import gcd
+        g = gcd(16000, t.rate)
+        up, down = 16000 // g, t.rate // g
+        return (t.frames * up + down - 1) // down
+
+    # ------------------------------------------------------------------ writer
+    def _finalize(self, job: FileJob) -> None:
+        if not os.path.exists(job.rf.path_partial):
+            return
+        if job.fresh and job.in_order:
+            job.rf.finalize_sorted()
+        else:
+            job.rf.finalize()
+        with self.lock:
+            self.report.files_done += 1
+
+    def _writer(self) -> None:
+        try:
+            log.info("writer: launching")
+            while True:
+                item = self._get(self.q_write)
+                if item == EXIT:
+                    break
+                if isinstance(item, FileJob):              # a recording whose chunks were all written before its reader finished
+                    self._finalize(item)
+                    continue
+                item.done.synchronize()
+                seconds = time.perf_counter() - item.t_start
+                audio = sum(t.chunk[1] - t.chunk[0] for t in item.tasks)
+                rate = audio / seconds if seconds > 0 else float("inf")
+                at = 0
+                for t, n in zip(item.tasks, item.counts):
+                    rows = item.host[at:at + n]
+                    at += n
+                    if self.threshold is None:
+                        head, body = results.activation_csv(rows, self.classes, self.framehop_s, self.digits_time, t.chunk[0],
+                                                            self.classes_out, self.digits_results)
+                    else:
+                        head, body = results.detection_csv(rows, self.threshold, self.classes, self.framehop_s,
+                                                           self.digits_time, t.chunk[0])
+                    t.job.rf.append_text(head, body)
+                    log.log(PROGRESS, f"analyzer {item.analyzer}: analyzed {t.job.shortpath}, chunk "
+                                      f"({t.chunk[0]:.{self.digits_time}f}, {t.chunk[1]:.{self.digits_time}f}) "
+                                      f"in {seconds:.2f}s (rate: {rate:.1f})")
+                    finish = False
+                    with self.lock:
+                        self.report.windows += n
+                        if t.chunk[0] < t.job.last_start:
+                            t.job.in_order = False
+                        t.job.last_start = t.chunk[0]
+                        t.job.outstanding -= 1
+                        finish = t.job.queued_all and t.job.outstanding == 0
+                    if finish:
+                        self._finalize(t.job)
+            log.debug("writer: terminating")
+        except PipelineAborted:
+            pass
+        except BaseException as exc:                       # noqa: BLE001
+            self.fail(exc, "writer")
+
+    # ------------------------------------------------------------------ driver
+    def run(self, jobs: Sequence[FileJob]) -> Report:
+        self.report.files_total += len(jobs)
+        for j in jobs:
+            self.q_files.put(j)
+        for _ in range(self.n_readers):
+            self.q_files.put(EXIT)
+        readers = [threading.Thread(target=self._reader, args=(i,), name=f"streamer-{i}", daemon=True) for i in range(self.n_readers)]
+        analyzers = [threading.Thread(target=self._analyzer, args=(i,), name=f"analyzer-{i}", daemon=True) for i in range(self.n_analyzers)]
+        writer = threading.Thread(target=self._writer, name="writer", daemon=True)
+        for t in readers + analyzers + [writer]:
+            t.start()
+        for t in readers:
+            t.join()
+        log.debug("coordinator: streamers done")
+        for _ in analyzers:
+            self._force_put(self.q_analyze, EXIT)
+        for t in analyzers:
+            t.join()
+        log.debug("coordinator: analyzers done")
+        self._force_put(self.q_write, EXIT)
+        writer.join()
+        log.debug("coordinator: writer done")
+        if self.error is not None:
+            raise self.error
+        return self.report
+
+    def _force_put(self, q: "queue.Queue", item) -> None:
+        """Sentinels must get through even when the pipeline is poisoned and the queue is full of abandoned work."""
+        while True:
+            try:
+                q.put(item, timeout=0.2)
+                return
+            except queue.Full:
+                if self.aborted.is_set():
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        pass

@@ -1,0 +1,106 @@
+"""PCM / float WAV files as memory maps: the streamer's view of a recording.
+
+The reference reads audio through soundfile / PyAV (src/stream/audio.py:24-44: ``seek(frame)``, ``read(n, float32)``
+-> ``[n, channels]`` in [-1, 1)); codecs are out of scope here, uncompressed WAV is not.  The file is parsed once
+(RIFF chunks; PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE with either sub-format), the ``data``
+chunk is mapped, and a chunk of a recording is a slice of that map: 16-bit data goes to the device as it lies in the
+file (the device stage scales by 1/32768 like libsndfile's float read), everything else is converted to float32 on
+the way into the pinned staging buffer.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+FORMAT_PCM, FORMAT_FLOAT, FORMAT_EXTENSIBLE = 1, 3, 0xFFFE
+
+
+class WavFormatError(ValueError):
+    pass
+
+
+class WavTrack:
+    def __init__(self, path: str):
+        self.path = path
+        with open(path, "rb") as f:
+            head = f.read(12)
+            if len(head) < 12 or head[:4] not in (b"RIFF", b"RF64") or head[8:12] != b"WAVE":
+                raise WavFormatError(f"{path}: not a RIFF/WAVE file")
+            fmt = None
+            data_off = data_len = None
+            size = f.seek(0, 2)
+            f.seek(12)
+            while f.tell() + 8 <= size:
+                cid, clen = struct.unpack("<4sI", f.read(8))
+                at = f.tell()
+                if cid == b"fmt ":
+                    fmt = f.read(min(clen, 40))
+                elif cid == b"data":
+                    data_off, data_len = at, min(clen, size - at)      # a recorder that died mid-file leaves a long count
+                    break
+                f.seek(at + clen + (clen & 1))
+        if fmt is None or len(fmt) < 16 or data_off is None:
+            raise WavFormatError(f"{path}: missing fmt or data chunk")
+        tag, channels, rate, _, block, bits = struct.unpack("<HHIIHH", fmt[:16])
+        if tag == FORMAT_EXTENSIBLE and len(fmt) >= 26:
+            tag = struct.unpack("<H", fmt[24:26])[0]
+        if tag not in (FORMAT_PCM, FORMAT_FLOAT) or channels < 1 or rate < 1:
+            raise WavFormatError(f"{path}: unsupported WAVE format tag {tag:#x}")
+        width = bits // 8
+        if (tag == FORMAT_PCM and width not in (1, 2, 3, 4)) or (tag == FORMAT_FLOAT and width not in (4, 8)) or block != width * channels:
+            raise WavFormatError(f"{path}: unsupported sample layout ({bits} bits, block align {block})")
+        self.samplerate, self.channels = int(rate), int(channels)
+        self._tag, self._width = tag, width
+        self.frames = data_len // block
+        self._map = np.memmap(path, dtype=np.uint8, mode="r", offset=data_off, shape=(self.frames * block,)) if self.frames else np.zeros(0, np.uint8)
+        self._pos = 0
+
+    @property
+    def duration(self) -> float:
+        return self.frames / self.samplerate
+
+    @property
+    def is_s16(self) -> bool:
+        return self._tag == FORMAT_PCM and self._width == 2
+
+    def seek(self, frame: int) -> None:
+        self._pos = min(max(int(frame), 0), self.frames)
+
+    def _raw(self, n: int) -> np.ndarray:
+        n = max(0, min(int(n), self.frames - self._pos))
+        block = self._width * self.channels
+        out = self._map[self._pos * block:(self._pos + n) * block]
+        self._pos += n
+        return out
+
+    def read_s16(self, n: int) -> np.ndarray:
+        """[frames, channels] int16 view of the file (16-bit files only): no copy, no conversion."""
+        if not self.is_s16:
+            raise WavFormatError("read_s16 on a file that is not 16-bit PCM")
+        return self._raw(n).view("<i2").reshape(-1, self.channels)
+
+    def read(self, n: int, keep_s16: bool = False) -> np.ndarray:
+        """[frames, channels] float32 in [-1, 1) (libsndfile's scaling); with ``keep_s16`` 16-bit files come back as the
+        int16 view instead (the device stage scales by 1/32768 itself, halving the host-to-device bytes)."""
+        if keep_s16 and self.is_s16:
+            return self.read_s16(n)
+        raw = self._raw(n)
+        if self._tag == FORMAT_FLOAT:
+            a = raw.view("<f4" if self._width == 4 else "<f8").astype(np.float32)
+        elif self._width == 2:
+            a = raw.view("<i2").astype(np.float32) / 32768.0
+        elif self._width == 4:
+            a = (raw.view("<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+        elif self._width == 1:
+            a = (raw.astype(np.float32) - 128.0) / 128.0
+        else:
+            b = raw.reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v >= 1 << 23, v - (1 << 24), v)
+            a = (v.astype(np.float64) / 8388608.0).astype(np.float32)
+        return a.reshape(-1, self.channels)
+
+    def close(self) -> None:
+        self._map = np.zeros(0, np.uint8)      # the mapping goes away with its last view
+        self.frames = 0

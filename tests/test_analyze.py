@@ -93,3 +93,145 @@ def test_analyze_writes_reference_format_and_resumes(engine, weights_bundle, tmp
     d = pd.read_csv(out2 / "site" / "mono16_buzzdetect.csv")
     assert list(d.columns) == ["start", "detections_ins_buzz"] and set(d["detections_ins_buzz"]) <= {0, 1}
     assert R.threshold_for_precision("model_general_v3", 0.95) == pytest.approx(-1.205)
+
+
+# --------------------------------------------------------------------------------------------------- WAV parsing (CPU)
+def _riff(fmt_chunk: bytes, data: bytes, extra: bytes = b"") -> bytes:
+    import struct
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt_chunk)) + fmt_chunk + extra + b"data" + struct.pack("<I", len(data)) + data
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_wav_parser_formats_the_stdlib_reader_rejects(tmp_path):
+    """WAVE_FORMAT_EXTENSIBLE, IEEE float and 24-bit files (python's wave module refuses the first two), an odd-sized
+    LIST chunk before the data, and a data chunk whose count runs past the end of the file (recorder died)."""
+    import struct
+    from buzzdetect_amd.wavio import WavFormatError, WavTrack
+    x = (np.arange(64, dtype=np.float32).reshape(32, 2) - 30) / 40
+    # IEEE float 32, stereo, 48 kHz
+    fmt = struct.pack("<HHIIHH", 3, 2, 48000, 48000 * 8, 8, 32)
+    (tmp_path / "f32.wav").write_bytes(_riff(fmt, x.astype("<f4").tobytes(), extra=b"LIST" + struct.pack("<I", 3) + b"abc\0"))
+    t = WavTrack(str(tmp_path / "f32.wav"))
+    assert (t.samplerate, t.channels, t.frames, t.is_s16) == (48000, 2, 32, False)
+    assert np.array_equal(t.read(32), x)
+    # extensible PCM 16-bit: sub-format tag 1 at offset 24 of the fmt chunk
+    s = (x * 20000).astype("<i2")
+    fmt = struct.pack("<HHIIHH", 0xFFFE, 2, 16000, 16000 * 4, 4, 16) + struct.pack("<HHI", 22, 16, 3) + struct.pack("<H", 1) + b"\0" * 14
+    (tmp_path / "ext.wav").write_bytes(_riff(fmt, s.tobytes()))
+    t = WavTrack(str(tmp_path / "ext.wav"))
+    assert t.is_s16 and t.frames == 32
+    t.seek(3)
+    assert np.array_equal(t.read_s16(4), s[3:7])
+    t.seek(30)
+    assert t.read(10).shape == (2, 2)                       # short read at the end
+    assert np.allclose(t.read(0), np.zeros((0, 2)))
+    # 24-bit mono
+    v = np.array([0, 1, -1, 8388607, -8388608, 4194304], dtype=np.int64)
+    raw = b"".join(int(i & 0xFFFFFF).to_bytes(3, "little") for i in v)
+    fmt = struct.pack("<HHIIHH", 1, 1, 16000, 48000, 3, 24)
+    (tmp_path / "p24.wav").write_bytes(_riff(fmt, raw))
+    got = WavTrack(str(tmp_path / "p24.wav")).read(6)[:, 0]
+    assert np.allclose(got, v / 8388608.0)
+    # data count beyond the file end: frames follow the bytes that exist
+    blob = bytearray(_riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), s.tobytes()))
+    blob[blob.index(b"data") + 4: blob.index(b"data") + 8] = struct.pack("<I", 10_000_000)
+    (tmp_path / "cut.wav").write_bytes(bytes(blob))
+    assert WavTrack(str(tmp_path / "cut.wav")).frames == 64
+    for bad in (b"RIFF\0\0\0\0WAVX", _riff(struct.pack("<HHIIHH", 85, 1, 16000, 2000, 1, 0), b"\0" * 64)):   # not WAVE; MP3-in-WAV
+        (tmp_path / "bad.wav").write_bytes(bad)
+        with pytest.raises(WavFormatError):
+            WavTrack(str(tmp_path / "bad.wav"))
+
+
+# --------------------------------------------------------------------------------------------------- pipeline (GPU)
+def _three_recordings(audio):
+    (audio / "a").mkdir(parents=True)
+    write_wav(audio / "a" / "one.wav", O.synthetic_audio(16000 * 31 + 77, seed=1), 16000)
+    write_wav(audio / "two.wav", O.synthetic_audio(16000 * 12, seed=2), 16000)
+    t = np.arange(32000 * 9) / 32000.0
+    write_wav(audio / "three32k.wav", 0.4 * np.sin(2 * np.pi * 440 * t), 32000)
+
+
+@pytest.mark.gpu
+def test_pipeline_two_analyzers_equals_one_and_logs_the_reference_lines(engine, tmp_path, caplog, monkeypatch):
+    """Two analyzer threads, each with its own engine and stream, fed by four readers, write exactly the files a single
+    analyzer writes; the log carries the reference's PROGRESS rate line for every chunk (src/inference/worker.py:54-64)."""
+    import logging
+    import re
+    from buzzdetect_amd.analyze import analyze
+    from buzzdetect_amd.pipeline import PROGRESS
+    audio = tmp_path / "audio"
+    _three_recordings(audio)
+    ref = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "one"), engine=engine)
+    # slow readers (as decoding compressed audio is for the reference): the analyzers must report that they starve
+    import time
+    from buzzdetect_amd import wavio
+    fast_read = wavio.WavTrack.read_s16
+    monkeypatch.setattr(wavio.WavTrack, "read_s16", lambda self, n: (time.sleep(0.05), fast_read(self, n))[1])
+    with caplog.at_level(logging.DEBUG, logger="buzzdetect"):
+        rep = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "two"),
+                      analyzers_gpu=2, n_streamers=4)
+    assert (rep.files_done, rep.chunks, rep.windows) == (ref.files_done, ref.chunks, ref.windows) == (3, rep.chunks, rep.windows)
+    assert rep.chunks == 7 + 3 + 2 and rep.files_done == 3
+    for rel in ("a/one", "two", "three32k"):
+        a = (tmp_path / "one" / f"{rel}_buzzdetect.csv").read_bytes()
+        b = (tmp_path / "two" / f"{rel}_buzzdetect.csv").read_bytes()
+        assert a == b and a.count(b"\n") > 3
+        assert not (tmp_path / "two" / f"{rel}_buzzpart.csv").exists()
+    progress = [r.getMessage() for r in caplog.records if r.levelno == PROGRESS]
+    assert len(progress) == rep.chunks
+    pat = re.compile(r"^analyzer [01]: analyzed (a/one|two|three32k)\.wav, chunk \(\d+\.\d\d, \d+\.\d\d\) in \d+\.\d\ds \(rate: \d+\.\d\)$")
+    assert all(pat.match(m) for m in progress), progress[:3]
+    assert any("analyzed a/one.wav, chunk (4.80, 9.60)" in m for m in progress)
+    msgs = [r.getMessage() for r in caplog.records]
+    assert sum("launching" in m and m.startswith("analyzer") for m in msgs) == 2
+    assert any(re.match(r"^analyzer \d: BUFFER BOTTLENECK: analyzer \d received assignment after \d+\.\ds$", m) for m in msgs)
+
+
+@pytest.mark.gpu
+def test_pipeline_failure_in_any_stage_stops_everything(engine, tmp_path, monkeypatch):
+    """A stage that raises poisons the pipeline: analyze() re-raises the first exception instead of hanging with the other
+    stages blocked on their queues (the reference's known hole); an unreadable recording is skipped, not fatal."""
+    import threading
+    from buzzdetect_amd import results as R
+    from buzzdetect_amd.analyze import analyze
+    audio = tmp_path / "audio"
+    _three_recordings(audio)
+    (audio / "broken.wav").write_bytes(b"RIFF" + b"\0" * 6000)
+    rep = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "ok"), engine=engine)
+    assert rep.files_done == 3 and rep.files_skipped == 1 and any("broken.wav" in m for m in rep.messages)
+
+    calls = {"n": 0}
+    real = R.activation_csv
+
+    def boom(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise OSError("disk full (injected)")
+        return real(*a, **k)
+
+    monkeypatch.setattr(R, "activation_csv", boom)
+    out = {}
+
+    def run():
+        try:
+            analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "bad"), engine=engine)
+        except BaseException as exc:          # noqa: BLE001
+            out["exc"] = exc
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "analyze() hung after a stage failed"
+    assert isinstance(out.get("exc"), OSError) and "disk full" in str(out["exc"])
+    monkeypatch.setattr(R, "activation_csv", real)
+
+    def bad_engine():
+        raise RuntimeError("no such device (injected)")
+
+    from buzzdetect_amd.pipeline import FileJob, Pipeline
+    pipe = Pipeline(make_engine=bad_engine, classes=engine.classes, framehop_s=0.96, hop=15360, step=96, chunklength=4.8,
+                    framelength_s=0.96, digits_time=2, digits_results=2, classes_out="all", threshold=None, readers=2, analyzers=2)
+    jobs = [FileJob(path=str(audio / "two.wav"), ident="two", shortpath="two.wav", rf=R.ResultFile(str(tmp_path / "x" / "two")))]
+    with pytest.raises(RuntimeError, match="no such device"):
+        pipe.run(jobs)

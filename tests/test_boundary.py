@@ -120,3 +120,39 @@ def test_plugin_halfhop_and_free_hop_on_gpu(dropin_cwd, weights_bundle):
     emb = e.embed(x).numpy()
     ref3 = O.embed(x, b["blob"], b["mel_keras3"], O.hop_samples(0.3), O.patch_step(0.3), np.float64)
     assert emb.shape == ref3.shape and np.abs(emb - ref3).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_worker_thread_contract_two_analyzers_on_one_device(dropin_cwd, weights_bundle):
+    """src/inference/worker.py:21,78 and docs/source/tuning.rst:111: every analyzer THREAD constructs its own model
+    (initialize=False), initialises it in-thread, and only ever calls predict from that thread; two of them share a GPU.
+    Rows must be bit-equal to what a single thread computes, on every repetition."""
+    import threading
+    from oracle import yamnet_oracle as O
+    from src.inference.models import load_model
+    chunks = [O.synthetic_audio(15360 * (3 + i) + 100 * i, seed=40 + i) for i in range(6)]
+    solo = load_model("model_general_v3", framehop_prop=1.0, initialize=True)
+    want = [solo.predict(c).numpy().copy() for c in chunks]
+    got, errors = {}, []
+    start = threading.Barrier(2)
+
+    def worker(wid):
+        try:
+            model = load_model("model_general_v3", framehop_prop=1.0, initialize=False)      # WorkerInferer.__init__
+            start.wait(30)
+            model.initialize()                                                                # WorkerInferer.run, in-thread
+            for rep in range(5):
+                for i, c in enumerate(chunks):
+                    got[(wid, rep, i)] = model.predict(c).numpy().copy()
+        except BaseException as exc:              # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert len(got) == 2 * 5 * len(chunks)
+    for (wid, rep, i), rows in got.items():
+        assert np.array_equal(rows, want[i]), (wid, rep, i)

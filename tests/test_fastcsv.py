@@ -1,0 +1,67 @@
+"""fastcsv / activation_csv / detection_csv must produce the bytes of the reference's pandas formatting."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from buzzdetect_amd import fastcsv, results as R
+
+CLASSES = ["ambient_background", "ambient_rain", "ins_buzz", "mech_plane"]
+
+
+def pandas_bytes(table: pd.DataFrame) -> bytes:
+    return table.to_csv(index=False).encode()
+
+
+@pytest.mark.parametrize("seed,scale", [(0, 1.0), (1, 8.0), (2, 300.0), (3, 0.004), (4, 30000.0)])
+def test_activation_rows_equal_pandas(seed, scale):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((977, len(CLASSES))) * scale).astype(np.float32)
+    x[3, 1] = -0.001            # rounds to -0.0: pandas writes "-0.0"
+    x[4, 2] = 0.004999
+    x[5, 0] = 12.5
+    x[6, 3] = -7.0
+    for start, hop in ((0.0, 0.96), (199.68, 0.96), (86000.0, 0.48), (0.48, 0.48)):
+        head, body = R.activation_csv(x, CLASSES, hop, 2, start, "all", 2)
+        ref = pandas_bytes(R.activation_table(x, CLASSES, hop, 2, start, "all", 2))
+        assert head + body == ref
+        head, body = R.activation_csv(x, CLASSES, hop, 2, start, ["ins_buzz", "ambient_rain"], 2)
+        assert head + body == pandas_bytes(R.activation_table(x, CLASSES, hop, 2, start, ["ins_buzz", "ambient_rain"], 2))
+
+
+def test_values_outside_the_fast_form_fall_back_to_pandas():
+    x = np.zeros((5, len(CLASSES)), np.float32)
+    for bad in (np.nan, np.inf, -np.inf, 2.5e6, -1e9):
+        y = x.copy()
+        y[2, 1] = bad
+        assert fastcsv.rows(np.arange(5) * 0.96, y.round(2)) is None
+        head, body = R.activation_csv(y, CLASSES, 0.96, 2, 0.0)
+        assert head + body == pandas_bytes(R.activation_table(y, CLASSES, 0.96, 2, 0.0))
+    # a start beyond 100 000 s (27.8 h into a recording) also goes through pandas
+    head, body = R.activation_csv(x, CLASSES, 0.96, 2, 123456.0)
+    assert head + body == pandas_bytes(R.activation_table(x, CLASSES, 0.96, 2, 123456.0))
+    assert fastcsv.rows(np.zeros(0), np.zeros((0, 3), np.float32)) == b""
+
+
+def test_detection_rows_equal_pandas():
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((300, len(CLASSES))).astype(np.float32) * 2
+    for thr in (-1.205, 0.0, 5.0):
+        head, body = R.detection_csv(x, thr, CLASSES, 0.96, 2, 600.0)
+        assert head + body == pandas_bytes(R.detection_table(x, thr, CLASSES, 0.96, 2, 600.0))
+
+
+def test_sorted_partial_file_survives_the_finalize_round_trip(tmp_path):
+    """finalize() = read partial, sort by start, write complete.  For rows appended in start order that is the
+    identity on the bytes, which is what lets the writer rename instead (ResultFile.finalize_sorted)."""
+    rng = np.random.default_rng(11)
+    a, b = R.ResultFile(str(tmp_path / "a")), R.ResultFile(str(tmp_path / "b"))
+    for chunk in range(4):
+        x = (rng.standard_normal((208, len(CLASSES))) * 6).astype(np.float32)
+        x[0, 0] = -0.001
+        head, body = R.activation_csv(x, CLASSES, 0.96, 2, round(chunk * 199.68, 2))
+        a.append_text(head, body)
+        b.append_text(head, body)
+    a.finalize()
+    b.finalize_sorted()
+    assert open(a.path_complete, "rb").read() == open(b.path_complete, "rb").read()
+    assert not (tmp_path / "a_buzzpart.csv").exists() and not (tmp_path / "b_buzzpart.csv").exists()
