@@ -26,8 +26,8 @@ from .wavio import WavTrack  # noqa: F401  (re-exported: the streamer's reader)
 
 AnalyzeReport = Report
 EXTENSIONS = (".wav",)
-STREAMERS_PER_ANALYZER = 2        # the reference runs 8 decoding streamers per GPU analyzer (coordination.py:129-138);
-                                  # reading uncompressed PCM needs far fewer
+STREAMERS_PER_ANALYZER = 3        # the reference runs 8 decoding streamers per GPU analyzer (coordination.py:129-138);
+                                  # reading uncompressed PCM (~8 GB/s per thread) needs fewer
 
 
 def build_ident(path: str, root_dir: str) -> str:
@@ -50,13 +50,15 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
             framehop_prop: float = 1, chunklength: float = 200, dir_audio: str = "audio_in",
             dir_out: Optional[str] = None, embeddername: str = "yamnet_k2", engine=None,
             rank: Optional[int] = None, world_size: Optional[int] = None, analyzers_gpu: int = 2,
-            n_streamers: Optional[int] = None) -> AnalyzeReport:
+            n_streamers: Optional[int] = None, engines: Optional[list] = None) -> AnalyzeReport:
     """Analyse every ``.wav`` under ``dir_audio``; write ``<ident>_buzzdetect.csv`` under ``dir_out``.
 
     ``classes_out`` / ``precision`` choose activations vs detections exactly as in the reference;
     ``rank`` / ``world_size`` default to the torch.distributed environment (one process per GPU);
     ``analyzers_gpu`` analyzer threads (each with its own engine and HIP stream) are fed by ``n_streamers`` reader
-    threads.  ``engine``: use this engine on ONE analyzer thread instead (tests, embedding in another loop)."""
+    threads.  ``engine``: use this engine on ONE analyzer thread instead (tests, embedding in another loop);
+    ``engines``: prebuilt engines, one per analyzer thread (a caller that analyses folder after folder keeps them: building
+    an engine folds and uploads the weights, ~0.1 s)."""
     from .engine import HipEngine, hop_samples, patch_step   # device code is only needed once there is work to do
 
     dist = None
@@ -75,7 +77,9 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
     framelength_s, digits_time, digits_results = 0.96, 2, 2
     framehop_s = framelength_s * framehop_prop
     chunklength = framing.round_chunklength(chunklength, framelength_s, digits_time)
-    probe = engine or HipEngine(embeddername=embeddername, modelname=modelname)
+    if engines:
+        engine = None
+    probe = engine or (engines[0] if engines else HipEngine(embeddername=embeddername, modelname=modelname))
     classes = probe.classes
     device_index = probe.device_index
     if classes_out == "all":
@@ -105,6 +109,13 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
 
     if engine is not None:
         analyzers, make_engine = 1, (lambda: engine)
+    elif engines:
+        analyzers, pool = len(engines), list(engines)
+        pool_lock = __import__("threading").Lock()
+
+        def make_engine():
+            with pool_lock:
+                return pool.pop()
     else:
         analyzers = max(1, int(analyzers_gpu))
         first = [probe]

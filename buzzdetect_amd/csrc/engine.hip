@@ -63,9 +63,14 @@ struct bd_engine {
     bd::SepLayer sep[13];
     const float* head_wt = nullptr;   // [n_classes][1024]
     const float* head_b = nullptr;
-    // resampler: taps of the last (up, down) pair used, kept on the device
-    int rs_up = 0, rs_down = 0, rs_half = 0;
-    float* d_taps = nullptr;
+    // resampler: the filters of every (up, down) pair used so far, kept on the device until bd_destroy (nothing is
+    // freed or re-uploaded on a rate change: hipFree would synchronise the device under the caller's streams)
+    struct Taps {
+        int up, down, half;
+        float* dev;
+        std::vector<float> host;      // source of the asynchronous upload; must outlive it
+    };
+    std::vector<Taps> taps;
     // profiling
     bool profiling = false;
     std::vector<Event2> pending;
@@ -466,7 +471,7 @@ int bd_destroy(bd_handle h) {
     for (auto& ev : h->free_events) (void)hipEventDestroy(ev.ev);
     if (h->d_pool) (void)hipFree(h->d_pool);
     if (h->d_tables) (void)hipFree(h->d_tables);
-    if (h->d_taps) (void)hipFree(h->d_taps);
+    for (auto& t : h->taps) (void)hipFree(t.dev);
     delete h;
     return BD_OK;
 }
@@ -537,19 +542,28 @@ static int resample_any(bd_handle h, const void* in_dev, bool s16, int64_t n_in,
     rational_ratio(rate_in, rate_out, &up, &down);
     if (up > 4096 || down > 4096) return fail(BD_EINVAL, "bd_resample: rate ratio does not reduce to <= 4096");
     BD_HIP(hipSetDevice(h->device));
-    if (h->rs_up != up || h->rs_down != down) {           // (re)design; the copy is stream-ordered
-        int half;
-        const std::vector<float> taps = design_taps(up, down, &half);
-        if (h->d_taps) BD_HIP(hipFree(h->d_taps));
-        h->d_taps = nullptr;
-        BD_HIP(hipMalloc(&h->d_taps, taps.size() * sizeof(float)));
-        BD_HIP(hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
-        h->rs_up = up;
-        h->rs_down = down;
-        h->rs_half = half;
+    const bd_engine::Taps* filt = nullptr;
+    if (up != 1 || down != 1) {                            // (up = down = 1: no filter, the kernel only converts)
+        for (const auto& t : h->taps)
+            if (t.up == up && t.down == down) filt = &t;
+        if (!filt) {                                       // first use of this ratio: design, upload in stream order
+            if (h->taps.size() >= 64) return fail(BD_EINVAL, "bd_resample: more than 64 distinct rate ratios on one engine");
+            if (h->taps.capacity() < 64) h->taps.reserve(64);      // entries never move: uploads read from them
+            bd_engine::Taps t;
+            t.up = up;
+            t.down = down;
+            t.host = design_taps(up, down, &t.half);
+            t.dev = nullptr;
+            BD_HIP(hipMalloc(&t.dev, t.host.size() * sizeof(float)));
+            h->taps.push_back(std::move(t));
+            filt = &h->taps.back();
+            BD_HIP(hipMemcpyAsync(filt->dev, filt->host.data(), filt->host.size() * sizeof(float), hipMemcpyHostToDevice,
+                                  (hipStream_t)stream));
+        }
     }
     const int64_t n_out = (n_in * up + down - 1) / down;
-    bd::launch_resample(in_dev, s16, n_in, channels, h->d_taps, h->rs_half, up, down, out_dev, n_out, (hipStream_t)stream);
+    bd::launch_resample(in_dev, s16, n_in, channels, filt ? filt->dev : nullptr, filt ? filt->half : 0, up, down, out_dev, n_out,
+                        (hipStream_t)stream);
     BD_HIP(hipGetLastError());
     return BD_OK;
 }

@@ -488,35 +488,85 @@ __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ 
 // as one device pass).  y[j] = sum_i mono[i] * h[j*down - i*up + half], h = Kaiser(5.0)-windowed sinc of
 // 2*half + 1 taps scaled by `up` (the scipy.signal.resample_poly design; the reference's soxr_hq is a
 // different low-pass, so this stage is "parity unpinned" against the reference and pinned against its own
-// CPU restatement).  One thread per output sample, taps walked in increasing input index.
+// CPU restatement).  Taps are walked in increasing input index.
+//
+// resample_kernel: a workgroup owns a tile of consecutive outputs.  It stages the channel mean of the input span
+// the tile needs (coalesced, converted once) and the filter in LDS, then every thread walks its outputs' taps out
+// of LDS: each input sample is read from HBM once per tile instead of (taps / down) times, and the filter never.
+// convert_kernel: the rate-preserving case (up = down = 1, where resample_poly returns its input): channel mean
+// and s16 -> f32 only, 16 bytes stored per lane.
+// Algorithmic HBM traffic per output sample: channels * sizeof(T) * down / up read + 4 B written.
 __device__ __forceinline__ float pcm_to_float(float v) { return v; }
 __device__ __forceinline__ float pcm_to_float(short v) { return (float)v * (1.0f / 32768.0f); }   // as libsndfile's float read
 
 template <typename T>
-__global__ __launch_bounds__(256) void resample_kernel(const T* __restrict__ in, long long n_in, int channels,
-                                                       const float* __restrict__ h, int half, int up, int down,
-                                                       float* __restrict__ out, long long n_out) {
-    for (long long j = blockIdx.x * 256LL + threadIdx.x; j < n_out; j += gridDim.x * 256LL) {
+__device__ __forceinline__ float mono_at(const T* __restrict__ in, long long i, int channels) {
+    if (channels == 1) return pcm_to_float(in[i]);
+    if (channels == 2) return (pcm_to_float(in[2 * i]) + pcm_to_float(in[2 * i + 1])) * 0.5f;
+    float m = 0.0f;
+    for (int ch = 0; ch < channels; ++ch) m += pcm_to_float(in[i * channels + ch]);
+    return m / (float)channels;
+}
+
+constexpr int kRsThreads = 256;
+constexpr int kRsPerThread = 8;                               // outputs per thread
+constexpr int kRsTile = kRsThreads * kRsPerThread;            // 2048 outputs per workgroup
+constexpr int kRsMaxSpan = 8192;                              // input samples staged per tile (32 KB)
+constexpr int kRsMaxTaps = 8192;                              // filter taps staged (32 KB); longer filters stay in global memory
+
+template <typename T, bool TAPS_IN_LDS>
+__global__ __launch_bounds__(kRsThreads) void resample_kernel(const T* __restrict__ in, long long n_in, int channels,
+                                                              const float* __restrict__ h, int half, int up, int down,
+                                                              float* __restrict__ out, long long n_out, int tile) {
+    __shared__ float s_x[kRsMaxSpan];
+    __shared__ float s_h[TAPS_IN_LDS ? kRsMaxTaps : 1];
+    const int tid = threadIdx.x;
+    const long long j0 = (long long)blockIdx.x * tile;
+    const long long j1 = j0 + tile < n_out ? j0 + tile : n_out;
+    // input span of the tile: i in [ceil((j0*down - half) / up), floor(((j1-1)*down + half) / up)], clamped to the signal
+    long long lo = j0 * down - half;
+    long long i_lo = lo >= 0 ? (lo + up - 1) / up : -((-lo) / up);
+    long long i_hi = ((j1 - 1) * down + half) / up;
+    if (i_lo < 0) i_lo = 0;
+    if (i_hi > n_in - 1) i_hi = n_in - 1;
+    const int span = (int)(i_hi - i_lo + 1);
+    for (int k = tid; k < span; k += kRsThreads) s_x[k] = mono_at(in, i_lo + k, channels);
+    if (TAPS_IN_LDS)
+        for (int k = tid; k < 2 * half + 1; k += kRsThreads) s_h[k] = h[k];
+    __syncthreads();
+    for (int q = 0; q < kRsPerThread; ++q) {
+        const long long j = j0 + tid + q * kRsThreads;
+        if (j >= j1 || tid + q * kRsThreads >= tile) break;
         const long long c = j * down;                       // position on the up-sampled grid
-        long long i0 = (c - half + up - 1) / up;            // ceil((c - half) / up), c - half may be negative
-        if (c - half < 0) i0 = -((half - c) / up);
-        long long i1 = (c + half) / up;
-        if (i0 < 0) i0 = 0;
-        if (i1 > n_in - 1) i1 = n_in - 1;
+        long long a = c - half;
+        long long ia = a >= 0 ? (a + up - 1) / up : -((-a) / up);
+        long long ib = (c + half) / up;
+        if (ia < i_lo) ia = i_lo;
+        if (ib > i_hi) ib = i_hi;
+        int t = (int)(c - ia * up + half);                  // tap of the first input sample; steps down by `up`
         float acc = 0.0f;
-        for (long long i = i0; i <= i1; ++i) {
-            float m = 0.0f;
-            if (channels == 1) {
-                m = pcm_to_float(in[i]);
-            } else if (channels == 2) {
-                m = (pcm_to_float(in[2 * i]) + pcm_to_float(in[2 * i + 1])) * 0.5f;
-            } else {
-                for (int ch = 0; ch < channels; ++ch) m += pcm_to_float(in[i * channels + ch]);
-                m = m / (float)channels;
-            }
-            acc = fmaf(m, h[c - i * up + half], acc);
-        }
+        for (int k = (int)(ia - i_lo); k <= (int)(ib - i_lo); ++k, t -= up)
+            acc = fmaf(s_x[k], TAPS_IN_LDS ? s_h[t] : h[t], acc);
         out[j] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convert_kernel(const T* __restrict__ in, long long n, int channels,
+                                                      float* __restrict__ out) {
+    const long long quads = (n + 3) / 4;
+    for (long long q = blockIdx.x * 256LL + threadIdx.x; q < quads; q += gridDim.x * 256LL) {
+        const long long i = 4 * q;
+        if (i + 3 < n) {
+            float4 v;
+            v.x = mono_at(in, i, channels);
+            v.y = mono_at(in, i + 1, channels);
+            v.z = mono_at(in, i + 2, channels);
+            v.w = mono_at(in, i + 3, channels);
+            *reinterpret_cast<float4*>(out + i) = v;
+        } else {
+            for (long long k = i; k < n; ++k) out[k] = mono_at(in, k, channels);
+        }
     }
 }
 
@@ -525,14 +575,26 @@ __global__ __launch_bounds__(256) void resample_kernel(const T* __restrict__ in,
 void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const float* taps, int half, int up,
                      int down, float* out, int64_t n_out, hipStream_t stream) {
     if (n_out <= 0) return;
-    const int64_t blocks = (n_out + 255) / 256;
-    const int grid = (int)(blocks < 65536 ? blocks : 65536);
-    if (s16)
-        hipLaunchKernelGGL(resample_kernel<short>, dim3(grid), dim3(256), 0, stream, static_cast<const short*>(in),
-                           (long long)n_in, channels, taps, half, up, down, out, (long long)n_out);
-    else
-        hipLaunchKernelGGL(resample_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in),
-                           (long long)n_in, channels, taps, half, up, down, out, (long long)n_out);
+    if (up == 1 && down == 1) {                               // same rate: channel mean + conversion only
+        const int64_t blocks = ((n_out + 3) / 4 + 255) / 256;
+        const int grid = (int)(blocks < 65536 ? blocks : 65536);
+        if (s16) hipLaunchKernelGGL(convert_kernel<short>, dim3(grid), dim3(256), 0, stream, static_cast<const short*>(in), (long long)n_out, channels, out);
+        else hipLaunchKernelGGL(convert_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in), (long long)n_out, channels, out);
+        return;
+    }
+    // outputs per workgroup: as many as the staged input span allows (span = tile * down / up + 2 * half / up + 2)
+    int64_t tile = ((int64_t)(kRsMaxSpan - 4 - 2 * (int64_t)half / up) * up) / down;
+    if (tile > kRsTile) tile = kRsTile;
+    if (tile < 1) tile = 1;
+    const int64_t grid = (n_out + tile - 1) / tile;
+    const bool lds_taps = 2 * half + 1 <= kRsMaxTaps;
+#define BD_RS_LAUNCH(T, L)                                                                                      \
+    hipLaunchKernelGGL((resample_kernel<T, L>), dim3((unsigned)grid), dim3(kRsThreads), 0, stream,             \
+                       static_cast<const T*>(in), (long long)n_in, channels, taps, half, up, down, out,         \
+                       (long long)n_out, (int)tile)
+    if (s16) { if (lds_taps) BD_RS_LAUNCH(short, true); else BD_RS_LAUNCH(short, false); }
+    else { if (lds_taps) BD_RS_LAUNCH(float, true); else BD_RS_LAUNCH(float, false); }
+#undef BD_RS_LAUNCH
 }
 
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,

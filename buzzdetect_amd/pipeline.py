@@ -4,15 +4,19 @@ Same shape and semantics as the reference's worker pipeline (src/pipeline/coordi
 src/stream/worker.py:109-165, src/inference/worker.py:9-92, src/write/worker.py:67-87), built so that an engine
 that consumes ~45 MB/s of 16-bit PCM per 10 k windows/s is not left waiting:
 
-    readers     one recording at a time each: chunk list (resume aware), chunk -> a slot of a ring of PINNED host
-                buffers (16-bit PCM as it lies in the file, anything else converted to float32), bounded queue
-                (depth 2 x readers, coordination.py:84-102).  NumPy's copy releases the GIL.
+    planner     walks the recordings: skip rules, header, chunk list (resume aware) -> read units.
+    readers     `readers` threads take read units of ANY recording (a single 24 h file is read by all of them):
+                positioned read straight into a slot of a ring of PINNED host buffers (16-bit PCM as it lies in
+                the file, anything else converted to float32), bounded queue (depth 2 x readers,
+                coordination.py:84-102).  The read releases the GIL.
     analyzers   `analyzers` threads per GPU (the reference's analyzers_gpu; docs/source/tuning.rst:111), each
                 constructing and initialising ITS OWN engine in-thread (src/inference/worker.py:21,78) on its own
                 HIP stream: async H2D from the pinned slot, device-side downmix / resample / s16 -> f32, up to 64
                 chunks (~1024 windows) per launch set, async D2H of the logits into pinned memory.
     writer      waits for the batch's event, formats rows (fastcsv: the bytes pandas would write), appends to the
-                partial file, finalises a recording when its last chunk has been written.
+                partial file (resume safety), finalises a recording when its last chunk has been written: a
+                recording started from nothing is written out sorted from the rows kept in memory - what the
+                reference's read-sort-rewrite produces, without pandas.
     logging     logger "buzzdetect", level PROGRESS = INFO - 5 (src/pipeline/loglevels.py): the reference's two
                 analyzer lines, "analyzed <file>, chunk (a, b) in <t>s (rate: <r>)" and
                 "BUFFER BOTTLENECK: analyzer <id> received assignment after <t>s".
@@ -56,11 +60,17 @@ class FileJob:
     ident: str
     shortpath: str
     rf: results.ResultFile
-    fresh: bool = True            # no partial results existed when the reader opened it
-    outstanding: int = 0          # chunks queued and not yet written
-    queued_all: bool = False
-    in_order: bool = True         # rows were appended in start order so far
-    last_start: float = -1.0
+    fresh: bool = True            # no partial results existed when the planner opened it
+    outstanding: int = 0          # chunks planned and not yet written (or dropped)
+    track: Optional[WavTrack] = None
+    header: bytes = b""
+    bodies: List[Tuple[float, bytes]] = field(default_factory=list)      # (chunk start, rows) of a fresh recording
+
+
+@dataclass
+class ReadUnit:
+    job: FileJob
+    chunk: Tuple[float, float]
 
 
 @dataclass
@@ -143,6 +153,7 @@ class Pipeline:
         self.n_readers, self.n_analyzers = max(1, readers), max(1, analyzers)
         self.device = device
         self.q_files: "queue.Queue" = queue.Queue()
+        self.q_units: "queue.Queue" = queue.Queue(maxsize=8 * self.n_readers)
         self.q_analyze: "queue.Queue" = queue.Queue(maxsize=2 * self.n_readers)      # coordination.py:129-138
         self.q_write: "queue.Queue" = queue.Queue()
         self.ring = PinnedRing(4 * self.n_readers + 16 * self.n_analyzers)     # queue + readers' hands + batches being copied
@@ -178,86 +189,96 @@ class Pipeline:
             except queue.Empty:
                 continue
 
-    # ------------------------------------------------------------------ readers
-    def _read_file(self, rid: int, job: FileJob) -> None:
+    # ------------------------------------------------------------------ planner + readers
+    def _skip(self, who: str, job: FileJob, why: str, level=logging.DEBUG, message: Optional[str] = None) -> None:
+        log.log(level, f"{who}: {why}")
+        with self.lock:
+            self.report.files_skipped += 1
+            if message:
+                self.report.messages.append(message)
+
+    def _plan_file(self, job: FileJob) -> None:
         if job.rf.complete:
-            log.debug(f"streamer {rid}: Skipping {job.shortpath}; already analyzed")
-            with self.lock:
-                self.report.files_skipped += 1
-            return
+            return self._skip("planner", job, f"Skipping {job.shortpath}; already analyzed")
         if os.path.getsize(job.path) < FILE_SIZE_MINIMUM:
-            log.debug(f"streamer {rid}: Skipping {job.shortpath}; below minimum analyzeable size")
-            with self.lock:
-                self.report.files_skipped += 1
-            return
+            return self._skip("planner", job, f"Skipping {job.shortpath}; below minimum analyzeable size")
         try:
             track = WavTrack(job.path)
         except (WavFormatError, OSError) as exc:           # one unreadable recording does not stop the others
-            log.warning(f"streamer {rid}: {exc}; skipping")
-            with self.lock:
-                self.report.messages.append(f"unreadable, skipped: {job.shortpath} ({exc})")
-                self.report.files_skipped += 1
-            return
-        try:
-            job.fresh = not os.path.exists(job.rf.path_partial)
-            chunks = job.rf.pending_chunks(track.duration, self.chunklength, self.framelength_s)
-            if not chunks:
-                with self.lock:
-                    self.report.files_skipped += 1
-                return
-            log.info(f"streamer {rid}: buffering {job.shortpath}")
-            sent = 0
-            for chunk in chunks:
-                a, b = framing.chunk_sample_range(chunk, track.samplerate)
-                track.seek(a)
-                want = b - a
-                if track.is_s16:
-                    data = track.read_s16(want)
-                else:
-                    data = track.read(want)
-                got = data.shape[0]
-                if got == 0:
-                    break
-                stop = got < want
-                if stop:                                   # short read: truncate the chunk, finish the file
-                    chunk = (chunk[0], round(chunk[0] + got / track.samplerate, 1))
-                nbytes = data.size * data.dtype.itemsize
-                slot, buf = self.ring.acquire(nbytes, self.aborted)
-                try:
-                    buf.numpy()[:nbytes] = data.reshape(-1).view(np.uint8)       # the one host copy; releases the GIL
-                    with self.lock:
-                        job.outstanding += 1
-                        self.report.chunks += 1
-                        self.report.audio_seconds += float(chunk[1] - chunk[0])
-                    self._put(self.q_analyze, ChunkTask(job, (float(chunk[0]), float(chunk[1])), slot, nbytes, got,
-                                                        track.channels, track.samplerate, track.is_s16))
-                except BaseException:
-                    self.ring.release(slot)
-                    raise
-                sent += 1
-                if stop:
-                    break
-            finish = False
-            with self.lock:
-                job.queued_all = True
-                finish = sent > 0 and job.outstanding == 0     # everything already written while we were reading
-                if sent == 0:
-                    self.report.files_skipped += 1
-            if finish:
-                self._put(self.q_write, job)
-        finally:
+            return self._skip("planner", job, f"{exc}; skipping", logging.WARNING,
+                              f"unreadable, skipped: {job.shortpath} ({exc})")
+        job.fresh = not os.path.exists(job.rf.path_partial)
+        chunks = job.rf.pending_chunks(track.duration, self.chunklength, self.framelength_s)
+        if not chunks:
             track.close()
+            return self._skip("planner", job, f"Skipping {job.shortpath}; nothing left to analyze")
+        log.info(f"planner: buffering {job.shortpath}")
+        job.track = track
+        job.outstanding = len(chunks)                      # known before the first unit is out: no finalisation race
+        for chunk in chunks:
+            self._put(self.q_units, ReadUnit(job, (float(chunk[0]), float(chunk[1]))))
 
-    def _reader(self, rid: int) -> None:
+    def _planner(self) -> None:
         try:
             while True:
                 job = self._get(self.q_files)
                 if job == EXIT:
                     return
-                self._read_file(rid, job)
+                self._plan_file(job)
         except PipelineAborted:
             pass
         except BaseException as exc:                       # noqa: BLE001 - every failure must poison the pipeline
+            self.fail(exc, "planner")
+
+    def _drop(self, job: FileJob) -> None:
+        """A planned chunk that yields no rows (the file ends before it): count it as done."""
+        with self.lock:
+            job.outstanding -= 1
+            finish = job.outstanding == 0
+        if finish:
+            self._put(self.q_write, job)
+
+    def _read_unit(self, unit: ReadUnit) -> None:
+        job, chunk, track = unit.job, unit.chunk, unit.job.track
+        a, b = framing.chunk_sample_range(chunk, track.samplerate)
+        want = min(b, track.frames) - a
+        if want <= 0:
+            return self._drop(job)
+        raw_bytes = want * track.bytes_per_frame
+        out_bytes = raw_bytes if track.is_s16 else want * track.channels * 4
+        slot, buf = self.ring.acquire(max(raw_bytes, out_bytes), self.aborted)
+        try:
+            host = buf.numpy()
+            got = track.read_raw_into(a, want, host)       # the one host copy; releases the GIL
+            if got == 0:
+                self.ring.release(slot)
+                return self._drop(job)
+            if got < b - a:                                # short read: truncate the chunk (src/stream/worker.py:119-127)
+                chunk = (chunk[0], round(chunk[0] + got / track.samplerate, 1))
+            if track.is_s16:
+                nbytes = got * track.bytes_per_frame
+            else:                                          # any other sample format: float32 on the host
+                f32 = track.convert(host[: got * track.bytes_per_frame].copy())
+                nbytes = f32.size * 4
+                host[:nbytes] = f32.reshape(-1).view(np.uint8)
+            with self.lock:
+                self.report.chunks += 1
+                self.report.audio_seconds += float(chunk[1] - chunk[0])
+            self._put(self.q_analyze, ChunkTask(job, chunk, slot, nbytes, got, track.channels, track.samplerate, track.is_s16))
+        except BaseException:
+            self.ring.release(slot)
+            raise
+
+    def _reader(self, rid: int) -> None:
+        try:
+            while True:
+                unit = self._get(self.q_units)
+                if unit == EXIT:
+                    return
+                self._read_unit(unit)
+        except PipelineAborted:
+            pass
+        except BaseException as exc:                       # noqa: BLE001
             self.fail(exc, f"streamer {rid}")
 
     # ------------------------------------------------------------------ analyzers
@@ -305,8 +326,6 @@ class Pipeline:
                             pcms.append(engine.resample(view, t.rate, 16000))     # also s16 -> f32 and the channel mean
                         else:
                             pcms.append(view[:, 0])
-                    copied = torch.cuda.Event()
-                    copied.record(stream)
                     res = engine.predict_batch(pcms, self.framehop_s)
                     counts = [len(r) for r in res]
                     total = sum(counts)
@@ -318,10 +337,9 @@ class Pipeline:
                         host.copy_(whole, non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(stream)
+                # the pinned slots go back to the ring when the batch's event has fired (the writer waits for it anyway):
+                # this thread never blocks on the device and can queue the next batch at once
                 self._put(self.q_write, WriteItem(batch, host.numpy(), counts, done, aid, t_start))
-                copied.synchronize()                       # the pinned slots have been read: hand them back
-                for s in held:
-                    self.ring.release(s)
                 held = []
                 t_wait = time.perf_counter()
             log.debug(f"analyzer {aid}: terminating")
@@ -344,12 +362,24 @@ class Pipeline:
 
     # ------------------------------------------------------------------ writer
     def _finalize(self, job: FileJob) -> None:
+        if job.track is not None:
+            job.track.close()
+            job.track = None
         if not os.path.exists(job.rf.path_partial):
             return
-        if job.fresh and job.in_order:
-            job.rf.finalize_sorted()
+        if job.fresh and job.bodies:
+            # the reference reads the partial file, sorts by start and writes the complete one (src/write/worker.py:82-86);
+            # for a recording this run started from nothing, the same bytes come from the rows kept in memory
+            job.bodies.sort(key=lambda sb: sb[0])
+            tmp = job.rf.path_complete + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(job.header)
+                f.writelines(b for _, b in job.bodies)
+            os.replace(tmp, job.rf.path_complete)
+            os.remove(job.rf.path_partial)
         else:
             job.rf.finalize()
+        job.bodies = []
         with self.lock:
             self.report.files_done += 1
 
@@ -360,10 +390,12 @@ class Pipeline:
                 item = self._get(self.q_write)
                 if item == EXIT:
                     break
-                if isinstance(item, FileJob):              # a recording whose chunks were all written before its reader finished
+                if isinstance(item, FileJob):              # a recording whose last planned chunk turned out to be empty
                     self._finalize(item)
                     continue
                 item.done.synchronize()
+                for t in item.tasks:                       # the H2D copies that read the pinned slots are long done
+                    self.ring.release(t.slot)
                 seconds = time.perf_counter() - item.t_start
                 audio = sum(t.chunk[1] - t.chunk[0] for t in item.tasks)
                 rate = audio / seconds if seconds > 0 else float("inf")
@@ -378,17 +410,17 @@ class Pipeline:
                         head, body = results.detection_csv(rows, self.threshold, self.classes, self.framehop_s,
                                                            self.digits_time, t.chunk[0])
                     t.job.rf.append_text(head, body)
+                    if t.job.fresh:
+                        t.job.header = head
+                        t.job.bodies.append((t.chunk[0], body))
                     log.log(PROGRESS, f"analyzer {item.analyzer}: analyzed {t.job.shortpath}, chunk "
                                       f"({t.chunk[0]:.{self.digits_time}f}, {t.chunk[1]:.{self.digits_time}f}) "
                                       f"in {seconds:.2f}s (rate: {rate:.1f})")
                     finish = False
                     with self.lock:
                         self.report.windows += n
-                        if t.chunk[0] < t.job.last_start:
-                            t.job.in_order = False
-                        t.job.last_start = t.chunk[0]
                         t.job.outstanding -= 1
-                        finish = t.job.queued_all and t.job.outstanding == 0
+                        finish = t.job.outstanding == 0
                     if finish:
                         self._finalize(t.job)
             log.debug("writer: terminating")
@@ -402,13 +434,16 @@ class Pipeline:
         self.report.files_total += len(jobs)
         for j in jobs:
             self.q_files.put(j)
-        for _ in range(self.n_readers):
-            self.q_files.put(EXIT)
+        self.q_files.put(EXIT)
+        planner = threading.Thread(target=self._planner, name="planner", daemon=True)
         readers = [threading.Thread(target=self._reader, args=(i,), name=f"streamer-{i}", daemon=True) for i in range(self.n_readers)]
         analyzers = [threading.Thread(target=self._analyzer, args=(i,), name=f"analyzer-{i}", daemon=True) for i in range(self.n_analyzers)]
         writer = threading.Thread(target=self._writer, name="writer", daemon=True)
-        for t in readers + analyzers + [writer]:
+        for t in [planner] + readers + analyzers + [writer]:
             t.start()
+        planner.join()
+        for _ in readers:
+            self._force_put(self.q_units, EXIT)
         for t in readers:
             t.join()
         log.debug("coordinator: streamers done")

@@ -1,14 +1,15 @@
-"""PCM / float WAV files as memory maps: the streamer's view of a recording.
+"""PCM / float WAV files by positioned reads: the streamer's view of a recording.
 
 The reference reads audio through soundfile / PyAV (src/stream/audio.py:24-44: ``seek(frame)``, ``read(n, float32)``
 -> ``[n, channels]`` in [-1, 1)); codecs are out of scope here, uncompressed WAV is not.  The file is parsed once
-(RIFF chunks; PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE with either sub-format), the ``data``
-chunk is mapped, and a chunk of a recording is a slice of that map: 16-bit data goes to the device as it lies in the
-file (the device stage scales by 1/32768 like libsndfile's float read), everything else is converted to float32 on
-the way into the pinned staging buffer.
+(RIFF chunks; PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE with either sub-format) and then read with
+positioned reads (``os.preadv`` straight into the caller's buffer: no intermediate copy, no page faults of a mapping, the
+GIL is released): 16-bit data goes to the device as it lies in the file (the device stage scales by 1/32768 like
+libsndfile's float read), everything else is converted to float32 on the way into the pinned staging buffer.
 """
 from __future__ import annotations
 
+import os
 import struct
 
 import numpy as np
@@ -53,8 +54,12 @@ class WavTrack:
         self.samplerate, self.channels = int(rate), int(channels)
         self._tag, self._width = tag, width
         self.frames = data_len // block
-        self._map = np.memmap(path, dtype=np.uint8, mode="r", offset=data_off, shape=(self.frames * block,)) if self.frames else np.zeros(0, np.uint8)
+        self._data_off, self._block = data_off, block
+        self._fd = os.open(path, os.O_RDONLY)
         self._pos = 0
+
+    def __del__(self):
+        self.close()
 
     @property
     def duration(self) -> float:
@@ -69,23 +74,47 @@ class WavTrack:
 
     def _raw(self, n: int) -> np.ndarray:
         n = max(0, min(int(n), self.frames - self._pos))
-        block = self._width * self.channels
-        out = self._map[self._pos * block:(self._pos + n) * block]
+        data = os.pread(self._fd, n * self._block, self._data_off + self._pos * self._block) if n else b""
+        n = len(data) // self._block                       # a file cut short after its header was written
         self._pos += n
-        return out
+        return np.frombuffer(data, np.uint8, n * self._block)
 
     def read_s16(self, n: int) -> np.ndarray:
-        """[frames, channels] int16 view of the file (16-bit files only): no copy, no conversion."""
+        """[frames, channels] int16 as it lies in the file (16-bit files only): no conversion."""
         if not self.is_s16:
             raise WavFormatError("read_s16 on a file that is not 16-bit PCM")
         return self._raw(n).view("<i2").reshape(-1, self.channels)
+
+    def read_raw_into(self, frame: int, n: int, out: np.ndarray) -> int:
+        """``n`` frames from ``frame`` on, as they lie in the file, into the uint8 buffer ``out`` (positioned read; does
+        not move the seek position, so several threads may share one track).  Returns the frames actually read."""
+        frame = min(max(int(frame), 0), self.frames)
+        n = max(0, min(int(n), self.frames - frame))
+        want = n * self._block
+        if want == 0:
+            return 0
+        view = memoryview(out)[:want]
+        got, at = 0, self._data_off + frame * self._block
+        while got < want:
+            r = os.preadv(self._fd, [view[got:]], at + got)
+            if r <= 0:
+                break
+            got += r
+        return got // self._block
+
+    @property
+    def bytes_per_frame(self) -> int:
+        return self._block
 
     def read(self, n: int, keep_s16: bool = False) -> np.ndarray:
         """[frames, channels] float32 in [-1, 1) (libsndfile's scaling); with ``keep_s16`` 16-bit files come back as the
         int16 view instead (the device stage scales by 1/32768 itself, halving the host-to-device bytes)."""
         if keep_s16 and self.is_s16:
             return self.read_s16(n)
-        raw = self._raw(n)
+        return self.convert(self._raw(n))
+
+    def convert(self, raw: np.ndarray) -> np.ndarray:
+        """Bytes as read by ``read_raw_into`` -> [frames, channels] float32 in [-1, 1) (any supported format)."""
         if self._tag == FORMAT_FLOAT:
             a = raw.view("<f4" if self._width == 4 else "<f8").astype(np.float32)
         elif self._width == 2:
@@ -102,5 +131,6 @@ class WavTrack:
         return a.reshape(-1, self.channels)
 
     def close(self) -> None:
-        self._map = np.zeros(0, np.uint8)      # the mapping goes away with its last view
-        self.frames = 0
+        fd, self._fd = getattr(self, "_fd", None), None
+        if fd is not None:
+            os.close(fd)

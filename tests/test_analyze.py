@@ -166,8 +166,8 @@ def test_pipeline_two_analyzers_equals_one_and_logs_the_reference_lines(engine, 
     # slow readers (as decoding compressed audio is for the reference): the analyzers must report that they starve
     import time
     from buzzdetect_amd import wavio
-    fast_read = wavio.WavTrack.read_s16
-    monkeypatch.setattr(wavio.WavTrack, "read_s16", lambda self, n: (time.sleep(0.05), fast_read(self, n))[1])
+    fast_read = wavio.WavTrack.read_raw_into
+    monkeypatch.setattr(wavio.WavTrack, "read_raw_into", lambda self, a, n, out: (time.sleep(0.05), fast_read(self, a, n, out))[1])
     with caplog.at_level(logging.DEBUG, logger="buzzdetect"):
         rep = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "two"),
                       analyzers_gpu=2, n_streamers=4)
