@@ -73,6 +73,8 @@ PROTOTYPES = {
                                      C.c_int32, C.c_void_p]),
     "bd_set_pointwise_variant": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "bd_set_pointwise_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bd_range_flag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),
+    "bd_range_flag_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "bd_set_fusion": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "bd_debug_pointwise_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -68,7 +68,8 @@ struct SepLayer {
     const void* pw_fhi;  // pw_whi in MFMA B-fragment order: [cout/32][cin/16][64 lanes][8]
     const void* pw_flo;  // pw_wlo, same order
     int pw_variant16;    // tile choice for the split-f16 kernel (0 = by shape)
-    int pw_mode;         // 0 = exact f32 MFMA, 1 = split-f16 MFMA (3 products)
+    int pw_mode;         // 0 = exact f32 MFMA, 1 = split-f16 MFMA (3 products), 2 = plain f16 MFMA (1 product)
+    unsigned* range_flag;  // the engine's sticky "an activation left the f16 range" word (modes 1 and 2)
 };
 
 // ---- launchers (each enqueues exactly one kernel on `stream`) ----
@@ -85,7 +86,8 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
 int launch_pointwise_variant(const float* A, const float* Wt, const float* bias, float* C, long long M, int N,
                              int K, int variant, hipStream_t stream);
 int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* bias, float* C,
-                                   long long M, int N, int K, int variant, hipStream_t stream);
+                                   long long M, int N, int K, int variant, hipStream_t stream, bool plain = false,
+                                   unsigned* range_flag = nullptr);
 bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
                             hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,

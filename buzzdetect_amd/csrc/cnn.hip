@@ -26,6 +26,22 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Range guard of the f16 arithmetic modes.  Every activation is split as hi = f16(a), lo = f16(a - hi): beyond the f16
+// range (65 504) hi is +inf and the result is garbage that the following ReLU can even hide (max(NaN, 0) = 0).  The
+// kernels keep a running max |a| of what they convert (two v_max3 per four values) and raise the engine's sticky flag
+// when it is out of range; the host reads the flag with the results and repeats the chunk in exact-f32 mode.
+constexpr float kF16Max = 65504.0f;
+__device__ __forceinline__ float range_of(float m, float4 v) {
+    return fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+}
+typedef float v4f_range __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float range_of(float m, v4f_range v) {
+    return fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+}
+__device__ __forceinline__ void range_report(float m, unsigned* __restrict__ flag) {
+    if (flag && !(m <= kF16Max)) *flag = 1u;  // also true for NaN (flag == nullptr: the handle-less debug entry points)
+}
+
 // hipFuncSetAttribute(max dynamic LDS) once per kernel instantiation and device; safe when several analyzer threads
 // (one engine each, src/inference/worker.py:21) make their first launch at the same time.
 constexpr int kMaxDevices = 64;
@@ -334,10 +350,12 @@ __device__ __forceinline__ void store_tile_t(const f32x16& acc, const float* __r
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool PLAIN>
 __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
     const float* __restrict__ A, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
-    const float* __restrict__ bias, float* __restrict__ C, long long M, int N, int K, int tiles_n) {
+    const float* __restrict__ bias, float* __restrict__ C, long long M, int N, int K, int tiles_n,
+    unsigned* __restrict__ range_flag) {
+    float rmax = 0.0f;
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -407,6 +425,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
     {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                 \
             const float4 v = ra[i];                                                                      \
+            rmax = range_of(rmax, v);                                                                    \
             f16x4 hi, lo;                                                                                \
             hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;  \
             lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);              \
@@ -437,8 +456,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
                 bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                       \
             }                                                                                            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);    \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);    \
+                if constexpr (!PLAIN) {                                                                  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0); \
+                }                                                                                        \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);    \
             }                                                                                            \
         }                                                                                                \
@@ -472,19 +493,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
             store_tile_t(acc[i][j], bias + nb, crow + nb, m < M, half);
         }
     }
+    range_report(rmax, range_flag);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool PLAIN>
+void launch_pw16_(const float* A, const _Float16* Whi, const _Float16* Wlo, const float* bias, float* C,
+                  long long M, int N, int K, unsigned* range_flag, hipStream_t stream) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr size_t lds = 2u * 2u * (BM + BN) * 64;
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&pointwise_f16x3_kernel<BM, BN, WGM, WGN, PLAIN>, (int)lds, lds_once);
+    const int tiles_n = N / BN;
+    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL((pointwise_f16x3_kernel<BM, BN, WGM, WGN, PLAIN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A,
+                       Whi, Wlo, bias, C, M, N, K, tiles_n, range_flag);
 }
 
 template <int BM, int BN, int WGM, int WGN>
 void launch_pw16(const float* A, const _Float16* Whi, const _Float16* Wlo, const float* bias, float* C,
-                 long long M, int N, int K, hipStream_t stream) {
-    constexpr int NT = WGM * WGN * 64;
-    constexpr size_t lds = 2u * 2u * (BM + BN) * 64;
-    static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&pointwise_f16x3_kernel<BM, BN, WGM, WGN>, (int)lds, lds_once);
-    const int tiles_n = N / BN;
-    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
-    hipLaunchKernelGGL((pointwise_f16x3_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A,
-                       Whi, Wlo, bias, C, M, N, K, tiles_n);
+                 long long M, int N, int K, bool plain, unsigned* range_flag, hipStream_t stream) {
+    if (plain) launch_pw16_<BM, BN, WGM, WGN, true>(A, Whi, Wlo, bias, C, M, N, K, range_flag, stream);
+    else launch_pw16_<BM, BN, WGM, WGN, false>(A, Whi, Wlo, bias, C, M, N, K, range_flag, stream);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -551,12 +580,14 @@ __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned t
 // MFMA B fragments (16 bytes of hi, 16 of lo per k-step and column tile) straight from global/L2 into a
 // double-buffered register set, one stage ahead.  The engine keeps a copy of the split weights in fragment
 // order, so each of those loads is one contiguous KiB per wave.
-template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD, int PWO>
+template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD, int PWO, bool PLAIN>
 __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
     float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n,
-    const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out2) {
+    const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out2,
+    unsigned* __restrict__ range_flag) {
+    float rmax = 0.0f;                        // largest |activation| this thread has split into f16 halves (producers)
     static_assert(BM == 96 || BM == 64, "tile height");
     static_assert(KS == 1 || (KS == 2 && BDIR == 1), "64-channel stages need the weights out of LDS");
     static_assert(XD == 0 || (BDIR == 1 && KS == 1 && XPMAX % 32 == 0), "slab DMA is issued by the fragment-loading consumers");
@@ -744,6 +775,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
                 a4 = __builtin_elementwise_fma(v, wt[t], a4);      /* v_pk_fma_f32: two IEEE fmas per issue */ \
             }                                                                                             \
             a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
+            rmax = range_of(rmax, a4);                                                                    \
             f16x4 hi, lo;                                                                                 \
             hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
             lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
@@ -798,6 +830,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
 #define BD_P_CVT(XB, AB)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                      \
         const v4f a4 = *reinterpret_cast<const v4f*>(Xs + (XB) * XS_FLOATS + (lrow + 32 * i) * 32 + lc4 * 4); \
+        rmax = range_of(rmax, a4);                                                                        \
         f16x4 hi, lo;                                                                                     \
         hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;   \
         lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);                 \
@@ -974,8 +1007,10 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
         _Pragma("unroll") for (int n = 0; n < 2 * TM; ++n) {                                              \
             if (n + 1 < 2 * TM) BD_W_AFRAG(ahx[(n + 1) & 1], alx[(n + 1) & 1], BUF, n + 1)                \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
-                acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alx[n & 1], BH[j][n / TM], acc[n % TM][j], 0, 0, 0); \
-                acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahx[n & 1], BL[j][n / TM], acc[n % TM][j], 0, 0, 0); \
+                if constexpr (!PLAIN) {                                                                   \
+                    acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alx[n & 1], BH[j][n / TM], acc[n % TM][j], 0, 0, 0); \
+                    acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahx[n & 1], BL[j][n / TM], acc[n % TM][j], 0, 0, 0); \
+                }                                                                                         \
                 acc[n % TM][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahx[n & 1], BH[j][n / TM], acc[n % TM][j], 0, 0, 0); \
             }                                                                                             \
         }                                                                                                 \
@@ -1045,8 +1080,10 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
                 bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                        \
             }                                                                                             \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);     \
+                if constexpr (!PLAIN) {                                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                }                                                                                         \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);     \
             }                                                                                             \
         }                                                                                                 \
@@ -1201,6 +1238,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
                     *reinterpret_cast<const v4f*>(Ct + ml * (BN + 4) + c4 * 4);
         }
     }
+    range_report(rmax, range_flag);
     if constexpr (ABL == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's stores have left the wave
         BD_PROBE2(9)
@@ -1213,9 +1251,13 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
     }
 }
 
-template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0, int KS = 1, int XD = 0, int PWO = 0>
+template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0, int KS = 1, int XD = 0, int PWO = 0,
+          bool PLAIN = false>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
                    const SepLayer* next = nullptr) {
+    if constexpr (!PLAIN && ABL == 0) {       // mode 2: the same kernel with one MFMA per product
+        if (L.pw_mode == 2) return launch_sep_ws<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, true>(X, L, out, M, stream, next);
+    }
     constexpr size_t lds_pipe0 = (XD ? 3u : 2u * KS) * (XPMAX + 1) * 128 + (XD ? 0u : 2u * KS * 1280) + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
     const size_t lds_pipe = lds_pipe0 + (XD && !PWO ? (size_t)40 * L.cin : 0);   // XD: + taps and shift of all input channels
     constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4;
@@ -1223,7 +1265,7 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
     constexpr size_t lds_pipe_max = lds_pipe0 + (XD && !PWO ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
     constexpr size_t lds_max = lds_pipe_max > lds_tile ? lds_pipe_max : lds_tile;
     static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>, (int)lds_max + (ABL == 1 ? 1024 : 0), lds_once);
+    allow_dynamic_lds(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>, (int)lds_max + (ABL == 1 ? 1024 : 0), lds_once);
     constexpr int TSTEP = NDW == 3 ? 64 : BM;
     const int tiles_n = L.cout / BN;
     const long long tiles = ((M + TSTEP - 1) / TSTEP) * tiles_n;
@@ -1232,7 +1274,7 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
         // developer aid: BD_WS_TRACE=1 traces a 512-channel fused layer, =2 the 256-channel pointwise of layer 7
         const char* tr = getenv("BD_WS_TRACE");
         if (tr && ((tr[0] == '1' && !PWO && L.cin == 512) || (tr[0] == '2' && PWO && L.cin == 256))) {
-            launch_sep_ws<BN, XPMAX, 1, NDW, BM, BDIR, VS, KS, XD, PWO>(X, L, out, M, stream, next);
+            launch_sep_ws<BN, XPMAX, 1, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>(X, L, out, M, stream, next);
             return;
         }
     }
@@ -1241,10 +1283,10 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
         static int shots = 0;
         if (!dbg) (void)hipMalloc(&dbg, 1024 + 8192);
         (void)hipMemsetAsync(dbg, 0, 1024 + 8192, stream);
-        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, L.dw_w,
+        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
                        static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
-                       out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, nullptr, nullptr, reinterpret_cast<float*>(dbg));
+                       out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, nullptr, nullptr, reinterpret_cast<float*>(dbg), L.range_flag);
         (void)hipStreamSynchronize(stream);
         static unsigned h[256 + 2048];
         (void)hipMemcpy(h, dbg, 1024 + 8192, hipMemcpyDeviceToHost);
@@ -1284,11 +1326,11 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
         return;
     }
 #endif
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
                        L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
                        static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
-                       next ? next->dw_b : nullptr, out);
+                       next ? next->dw_b : nullptr, out, L.range_flag);
 }
 
 // --------------------------------------------------------------------------- 12-wave form for N = 512
@@ -1299,11 +1341,13 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
 // Twelve waves per CU leave 168 registers per wave, 96 of them accumulators: A fragments are read per 32-row tile
 // and weight fragments per 16-deep k step, double-buffered.  The output goes out in three 32-row chunks.
 // Plain instantiation only (no epilogue fusion); same products in the same order: bit-identical.
-template <int XPMAX, bool TRACE>
+template <int XPMAX, bool TRACE, bool PLAIN>
 __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
-    float* __restrict__ Cout, long long M, int K, int H, int W, unsigned* __restrict__ dbg) {
+    float* __restrict__ Cout, long long M, int K, int H, int W, unsigned* __restrict__ dbg,
+    unsigned* __restrict__ range_flag) {
+    float rmax = 0.0f;
     constexpr int BM = 96, BN = 512, N = 512;
     constexpr int TM = 3, TN = 2, LA = 3;
     constexpr int XS_FLOATS = (XPMAX + 1) * 32;
@@ -1393,6 +1437,7 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
             v4f a4 = bias4;                                                                               \
             _Pragma("unroll") for (int t = 0; t < 9; ++t) a4 = __builtin_elementwise_fma(xv[i * 3 + t], wt[t], a4); \
             a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
+            rmax = range_of(rmax, a4);                                                                    \
             f16x4 hi, lo;                                                                                 \
             hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
             lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
@@ -1476,8 +1521,10 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
     }
 #define W12_STEP(I, AH, AL, BH, BL)                                                                       \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                      \
-        acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH[j], acc[I][j], 0, 0, 0);                \
-        acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL[j], acc[I][j], 0, 0, 0);                \
+        if constexpr (!PLAIN) {                                                                           \
+            acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH[j], acc[I][j], 0, 0, 0);            \
+            acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL[j], acc[I][j], 0, 0, 0);            \
+        }                                                                                                 \
         acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH[j], acc[I][j], 0, 0, 0);                \
     }
         W12_BLOAD(bh0, bl0, 0)
@@ -1543,15 +1590,19 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
         }
         __syncthreads();
     }
+    range_report(rmax, range_flag);
 #undef W12_TS
 }
 
-template <int XPMAX>
+template <int XPMAX, bool PLAIN = false>
 void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
+    if constexpr (!PLAIN) {                   // mode 2: the same kernel with one MFMA per product
+        if (L.pw_mode == 2) return launch_sep_w12<XPMAX, true>(X, L, out, M, stream);
+    }
     const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + (size_t)40 * L.cin + 32u * (512 + 4) * 4;
     constexpr size_t lds_max = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + 40u * 512u + 32u * (512 + 4) * 4;
     static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&sep_w12_kernel<XPMAX, false>, (int)lds_max, lds_once);
+    allow_dynamic_lds(&sep_w12_kernel<XPMAX, false, PLAIN>, (int)lds_max, lds_once);
     const long long tiles = (M + 95) / 96;
 #ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=3 traces one workgroup of this kernel
     const char* tr = getenv("BD_WS_TRACE");
@@ -1560,13 +1611,13 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
         static int shots = 0;
         if (!dbg) {
             (void)hipMalloc(&dbg, 512);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX, true, PLAIN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         }
         (void)hipMemsetAsync(dbg, 0, 512, stream);
-        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
+        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
                            static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
-                           L.cin, L.h_out, L.w_out, dbg);
+                           L.cin, L.h_out, L.w_out, dbg, L.range_flag);
         (void)hipStreamSynchronize(stream);
         unsigned h[128];
         (void)hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
@@ -1584,9 +1635,9 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
         return;
     }
 #endif
-    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
+    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
                        static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
-                       L.cin, L.h_out, L.w_out, nullptr);
+                       L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
 }
 
 // --------------------------------------------------------------------------- fused stem + layer-3 depthwise
@@ -1604,7 +1655,7 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
 //   F' depthwise 3 -> split-f16 A tile [32][64] in LDS   G  [32][64] x [64][128] on the matrix cores (wave w:
 //   columns 32 w .. 32 w + 31, weights as register fragments from the fragment-order copy)   H  bias + ReLU -> HBM
 // Arithmetic order per element equals conv1_kernel / depthwise_kernel / pointwise_f16x3_kernel.
-template <bool PW3>
+template <bool PW3, bool PLAIN>
 __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__ logmel, int patch_step,
                                                     const WindowMap map, int w0,
                                                     const float* __restrict__ c1_w, const float* __restrict__ c1_b,
@@ -1613,7 +1664,9 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                                                     const float* __restrict__ pw_b, const float* __restrict__ dw3_w,
                                                     const float* __restrict__ dw3_b, float* __restrict__ out,
                                                     const _Float16* __restrict__ W3fhi, const _Float16* __restrict__ W3flo,
-                                                    const float* __restrict__ pw3_b, unsigned* __restrict__ dbg) {
+                                                    const float* __restrict__ pw3_b, unsigned* __restrict__ dbg,
+                                                    unsigned* __restrict__ range_flag) {
+    float rmax = 0.0f;
 #define ST_TS(I) if (dbg && blockIdx.x == 5 && blockIdx.y == 7 && threadIdx.x == 0) dbg[I] = (unsigned)__builtin_readcyclecounter();
     ST_TS(0)
     constexpr int R2 = 5;                       // layer-2 rows in the tile
@@ -1761,6 +1814,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             acc.y = fmaxf(acc.y, 0.0f);
             acc.z = fmaxf(acc.z, 0.0f);
             acc.w = fmaxf(acc.w, 0.0f);
+            rmax = range_of(rmax, acc);
             f16x4 hi, lo;
             hi[0] = (_Float16)acc.x; hi[1] = (_Float16)acc.y; hi[2] = (_Float16)acc.z; hi[3] = (_Float16)acc.w;
             lo[0] = (_Float16)(acc.x - (float)hi[0]); lo[1] = (_Float16)(acc.y - (float)hi[1]);
@@ -1801,8 +1855,10 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                 const f16x8 al = *reinterpret_cast<const f16x8*>(s_al + off);
                 // operands swapped: the accumulators hold the TRANSPOSED tile (lane = position, four consecutive
                 // channels per register quad), so phase E writes 16 bytes at a time; same products, same k order
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], al, acc2[i], 0, 0, 0);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbl[s2], ah, acc2[i], 0, 0, 0);
+                if constexpr (!PLAIN) {
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], al, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbl[s2], ah, acc2[i], 0, 0, 0);
+                }
                 acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], ah, acc2[i], 0, 0, 0);
             }
         }
@@ -1859,6 +1915,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         acc.z = fmaxf(acc.z, 0.0f);
         acc.w = fmaxf(acc.w, 0.0f);
         if constexpr (PW3) {
+            rmax = range_of(rmax, acc);
             f16x4 hi, lo;
             hi[0] = (_Float16)acc.x; hi[1] = (_Float16)acc.y; hi[2] = (_Float16)acc.z; hi[3] = (_Float16)acc.w;
             lo[0] = (_Float16)(acc.x - (float)hi[0]); lo[1] = (_Float16)(acc.y - (float)hi[1]);
@@ -1883,8 +1940,10 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             const int off = (q >> 1) * 32 * 64 + swz64(frow, 2 * (q & 1) + fh);
             const f16x8 ah = *reinterpret_cast<const f16x8*>(smem + OFF_A3H + off);
             const f16x8 al = *reinterpret_cast<const f16x8*>(smem + OFF_A3L + off);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w3h[q], acc3, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3l[q], acc3, 0, 0, 0);
+            if constexpr (!PLAIN) {
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w3h[q], acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3l[q], acc3, 0, 0, 0);
+            }
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3h[q], acc3, 0, 0, 0);
         }
         ST_TS(8)
@@ -1900,6 +1959,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ST_TS(9)
     }
+    range_report(rmax, range_flag);
 #undef ST_TS
 }
 
@@ -2036,22 +2096,23 @@ static int pick_f16x3_variant(long long M, int N, int K) {
 }
 
 int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* bias, float* C,
-                                   long long M, int N, int K, int variant, hipStream_t stream) {
+                                   long long M, int N, int K, int variant, hipStream_t stream, bool plain,
+                                   unsigned* range_flag) {
     if (M <= 0) return 0;
     if (K % 32 != 0 || N % 64 != 0) return -1;
     const _Float16* wh = static_cast<const _Float16*>(Whi);
     const _Float16* wl = static_cast<const _Float16*>(Wlo);
     if (variant == 0) variant = pick_f16x3_variant(M, N, K);
     switch (variant) {
-        case 1: if (N % 128) return -1; launch_pw16<128, 128, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 2: launch_pw16<128, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 3: if (N % 128) return -1; launch_pw16<256, 128, 4, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 4: if (N % 256) return -1; launch_pw16<128, 256, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 5: launch_pw16<256, 64, 4, 1>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 6: if (N % 128) return -1; launch_pw16<64, 128, 1, 4>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 7: if (N % 256) return -1; launch_pw16<128, 256, 2, 4>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 8: launch_pw16<64, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
-        case 9: if (N % 256) return -1; launch_pw16<256, 256, 4, 2>(A, wh, wl, bias, C, M, N, K, stream); break;
+        case 1: if (N % 128) return -1; launch_pw16<128, 128, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 2: launch_pw16<128, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 3: if (N % 128) return -1; launch_pw16<256, 128, 4, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 4: if (N % 256) return -1; launch_pw16<128, 256, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 5: launch_pw16<256, 64, 4, 1>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 6: if (N % 128) return -1; launch_pw16<64, 128, 1, 4>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 7: if (N % 256) return -1; launch_pw16<128, 256, 2, 4>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 8: launch_pw16<64, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 9: if (N % 256) return -1; launch_pw16<256, 256, 4, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
         default: return -1;
     }
     return 0;
@@ -2068,10 +2129,11 @@ bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLay
 }
 
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
-    if (L.pw_mode == 1 && (L.pw_variant16 == 0 || L.pw_variant16 >= 10) && launch_pointwise_ws(in, out, rows, L, stream)) return;
-    if (L.pw_mode == 1)
+    const bool f16 = L.pw_mode == 1 || L.pw_mode == 2;
+    if (f16 && (L.pw_variant16 == 0 || L.pw_variant16 >= 10) && launch_pointwise_ws(in, out, rows, L, stream)) return;
+    if (f16)
         launch_pointwise_f16x3_variant(in, L.pw_whi, L.pw_wlo, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant16,
-                                       stream);
+                                       stream, L.pw_mode == 2, L.range_flag);
     else
         launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
 }
@@ -2124,9 +2186,14 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-    hipLaunchKernelGGL(stem3_kernel<false>, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
-                       c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out, nullptr, nullptr, nullptr, nullptr);
+#define BD_STEM3(PLAIN)                                                                                              \
+    hipLaunchKernelGGL((stem3_kernel<false, PLAIN>), dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,  \
+                       c1_w, c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),                            \
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out, nullptr, nullptr, nullptr,  \
+                       nullptr, L2.range_flag)
+    if (L2.pw_mode == 2) BD_STEM3(true);
+    else BD_STEM3(false);
+#undef BD_STEM3
 }
 
 // Layers 1-3 complete: out = [windows][24][16][128], the layer-3 output.
@@ -2140,10 +2207,15 @@ void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int
 #else
     unsigned* const dbg = nullptr;
 #endif
-    hipLaunchKernelGGL(stem3_kernel<true>, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w,
-                       c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out,
-                       static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_b, dbg);
+#define BD_STEM4(PLAIN)                                                                                              \
+    hipLaunchKernelGGL((stem3_kernel<true, PLAIN>), dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,   \
+                       c1_w, c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),                            \
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out,                          \
+                       static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_b, dbg,    \
+                       L2.range_flag)
+    if (L2.pw_mode == 2) BD_STEM4(true);
+    else BD_STEM4(false);
+#undef BD_STEM4
 #ifdef BD_KERNEL_TRACE
     if (dbg) {
         (void)hipStreamSynchronize(stream);

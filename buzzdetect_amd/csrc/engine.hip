@@ -49,7 +49,8 @@ struct bd_engine {
     int device = 0;
     int n_classes = 0;
     int group_windows = kDefaultGroup;
-    int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA
+    int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA, 2 = plain f16 MFMA
+    unsigned* d_range_flag = nullptr; // sticky: an activation exceeded the f16 range in mode 1 / 2 (bd_range_flag)
     bool fuse_stem = true;            // layers 1-2 and the depthwise of layer 3 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
     bool fuse_stem3 = true;           // (always equal to fuse_stem: the layers 1-2 only kernel is gone)
@@ -420,11 +421,14 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
     e->n_classes = w->n_classes;
     hipError_t err = hipMalloc(&e->d_pool, host.size() * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&e->d_tables, sizeof(bd::FeTables));
+    if (err == hipSuccess) err = hipMalloc(&e->d_range_flag, 256);
+    if (err == hipSuccess) err = hipMemset(e->d_range_flag, 0, 256);
     if (err == hipSuccess) err = hipMemcpy(e->d_pool, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(e->d_tables, &tables, sizeof(tables), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
         if (e->d_pool) (void)hipFree(e->d_pool);
         if (e->d_tables) (void)hipFree(e->d_tables);
+        if (e->d_range_flag) (void)hipFree(e->d_range_flag);
         delete e;
         return fail(BD_EHIP, std::string("bd_create: ") + hipGetErrorString(err));
     }
@@ -452,6 +456,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         L.pw_flo = e->d_pool + off_pw_flo[l];
         L.pw_variant16 = 0;
         L.pw_mode = e->pointwise_mode;
+        L.range_flag = e->d_range_flag;
         h = L.h_out;
         wd = L.w_out;
         cin = L.cout;
@@ -471,6 +476,7 @@ int bd_destroy(bd_handle h) {
     for (auto& ev : h->free_events) (void)hipEventDestroy(ev.ev);
     if (h->d_pool) (void)hipFree(h->d_pool);
     if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->d_range_flag) (void)hipFree(h->d_range_flag);
     for (auto& t : h->taps) (void)hipFree(t.dev);
     delete h;
     return BD_OK;
@@ -676,7 +682,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
         float* buf_a = buf_a0;
         float* buf_b = buf_b0;
         // layers 1-3 run as one fused kernel (split-f16 mode) unless a test taps inside them
-        const bool fuse_stem = e->fuse_stem && e->pointwise_mode == 1 && (stop_stage < 0 || stop_stage >= 2);
+        const bool fuse_stem = e->fuse_stem && e->pointwise_mode != 0 && (stop_stage < 0 || stop_stage >= 2);
         const float* last = buf_a;
         int64_t last_floats = 0;
         bool stopped = false;
@@ -716,7 +722,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             const bd::SepLayer& L = e->sep[l];
             // last layer: the global average pool rides in the fused kernel's epilogue; only [windows][1024] is
             // written (into the caller's embedding buffer if there is one, else into buf_b)
-            if (l == 12 && e->fuse_sep && e->fuse_next_dw && e->pointwise_mode == 1 && e->sep_variant <= 1 &&
+            if (l == 12 && e->fuse_sep && e->fuse_next_dw && e->pointwise_mode != 0 && e->sep_variant <= 1 &&
                 stop_stage < 0 && skip_dw_layer != l) {
                 float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
                 if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream)) {
@@ -732,7 +738,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
             // ... and when the NEXT layer is a stride-2 one, its depthwise is applied in that kernel's epilogue
             // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
-            if (e->fuse_sep && e->fuse_next_dw && e->pointwise_mode == 1 && e->sep_variant <= 1 && l + 1 < 13 &&
+            if (e->fuse_sep && e->fuse_next_dw && e->pointwise_mode != 0 && e->sep_variant <= 1 && l + 1 < 13 &&
                 (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
                 bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, e->sep[l + 1], stream)) {
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
@@ -741,7 +747,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
                 last_floats = (int64_t)gw * e->sep[l + 1].h_out * e->sep[l + 1].w_out * L.cout;
                 continue;
             }
-            if (e->fuse_sep && e->pointwise_mode == 1 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
+            if (e->fuse_sep && e->pointwise_mode != 0 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
                 bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
@@ -851,7 +857,7 @@ int bd_debug_pointwise(const float* a_dev, const float* wt_dev, const float* bia
 
 int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
     if (!h || layer < 2 || layer > 14) return fail(BD_EINVAL, "bd_set_pointwise_variant: layer must be 2..14");
-    if (h->sep[layer - 2].pw_mode == 1) h->sep[layer - 2].pw_variant16 = variant;
+    if (h->sep[layer - 2].pw_mode != 0) h->sep[layer - 2].pw_variant16 = variant;
     else h->sep[layer - 2].pw_variant = variant;
     return BD_OK;
 }
@@ -870,8 +876,28 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     return BD_OK;
 }
 
+int bd_range_flag(bd_handle h, int32_t* flag_host, int32_t reset, void* stream) {
+    if (!h || !flag_host) return fail(BD_EINVAL, "bd_range_flag: null argument");
+    BD_HIP(hipSetDevice(h->device));
+    unsigned v = 0;
+    BD_HIP(hipMemcpyAsync(&v, h->d_range_flag, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (reset && v) BD_HIP(hipMemsetAsync(h->d_range_flag, 0, sizeof(v), (hipStream_t)stream));
+    *flag_host = (int32_t)v;
+    return BD_OK;
+}
+
+int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* stream) {
+    if (!h || !dst) return fail(BD_EINVAL, "bd_range_flag_copy: null argument");
+    BD_HIP(hipSetDevice(h->device));
+    BD_HIP(hipMemcpyAsync(dst, h->d_range_flag, sizeof(int32_t), hipMemcpyDefault, (hipStream_t)stream));
+    if (reset) BD_HIP(hipMemsetAsync(h->d_range_flag, 0, sizeof(int32_t), (hipStream_t)stream));
+    return BD_OK;
+}
+
 int bd_set_pointwise_mode(bd_handle h, int32_t mode) {
-    if (!h || (mode != 0 && mode != 1)) return fail(BD_EINVAL, "bd_set_pointwise_mode: mode must be 0 (f32) or 1 (split f16)");
+    if (!h || mode < 0 || mode > 2)
+        return fail(BD_EINVAL, "bd_set_pointwise_mode: mode must be 0 (f32), 1 (split f16) or 2 (plain f16)");
     h->pointwise_mode = mode;
     for (auto& L : h->sep) L.pw_mode = mode;
     return BD_OK;

@@ -34,12 +34,18 @@ def patch_step(framehop_s: float) -> int:
 
 class DeviceResult:
     """What ``predict``/``embed`` hand back: a device tensor that also answers ``.numpy()``,
-    the one method the reference's writer calls on results (src/write/worker.py:69)."""
+    the one method the reference's writer calls on results (src/write/worker.py:69).
 
-    def __init__(self, tensor: torch.Tensor, stream: torch.cuda.Stream):
+    ``redo``: how to recompute the rows in exact-f32 arithmetic; ``.numpy()`` uses it when the engine reports that an
+    activation left the f16 range while these rows were computed (``HipEngine.range_exceeded``)."""
+
+    def __init__(self, tensor: torch.Tensor, stream: torch.cuda.Stream, engine: "Optional[HipEngine]" = None,
+                 redo=None):
         self.tensor = tensor
         self._stream = stream
         self._host: Optional[np.ndarray] = None
+        self._engine = engine
+        self._redo = redo
 
     @property
     def shape(self) -> Tuple[int, ...]:
@@ -48,6 +54,13 @@ class DeviceResult:
     def numpy(self) -> np.ndarray:
         if self._host is None:
             self._stream.synchronize()
+            if self._engine is not None and self._redo is not None and self._engine.range_exceeded(self._stream):
+                # an activation beyond 65 504 went through the f16 matrix path: these rows may be garbage (and a ReLU
+                # can hide it).  Compute them again with exact f32 products.
+                self._engine.overflow_reruns += 1
+                self.tensor = self._redo()
+                torch.cuda.current_stream(self.tensor.device).synchronize()
+            self._redo = None
             self._host = self.tensor.cpu().numpy()
         return self._host
 
@@ -92,6 +105,8 @@ class HipEngine:
             self.n_classes = int(hb.size)
         _lib.check(self._lib.bd_create(C.byref(self._handle), self.device_index, C.byref(w)))
         self._workspace: Optional[torch.Tensor] = None
+        self._mode = "f16x3"
+        self.overflow_reruns = 0          # results recomputed in exact f32 because an activation left the f16 range
         # host staging for NumPy inputs: a ring of pinned buffers, each guarded by the event of the async
         # H2D copy that last read it (a single shared buffer would be overwritten while a copy is in flight)
         self._pinned: list = [None] * 4
@@ -114,9 +129,37 @@ class HipEngine:
     def set_group_windows(self, windows: int) -> None:
         _lib.check(self._lib.bd_set_group_windows(self._handle, int(windows)))
 
+    POINTWISE_MODES = ("f32", "f16x3", "f16")
+
     def set_pointwise_mode(self, mode: str) -> None:
-        """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class)."""
-        _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1}[mode]))
+        """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class); 'f16' = plain f16
+        operands, one MFMA per product (config 5; ~1e-3 on the logits)."""
+        _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1, "f16": 2}[mode]))
+        self._mode = mode
+
+    def range_exceeded(self, stream: Optional[torch.cuda.Stream] = None, reset: bool = True) -> bool:
+        """Did any launch since the last reset convert an activation beyond the f16 range (modes 'f16x3' / 'f16')?
+        Waits for ``stream``."""
+        flag = C.c_int32(0)
+        s = stream or self._stream()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_range_flag(self._handle, C.byref(flag), 1 if reset else 0, s.cuda_stream))
+        return bool(flag.value)
+
+    def range_flag_to(self, dst: torch.Tensor, reset: bool = False) -> None:
+        """Enqueue (no wait) a copy of the range word into ``dst`` (int32, device or pinned host) on the current stream."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_range_flag_copy(self._handle, dst.data_ptr(), 1 if reset else 0,
+                                                    self._stream().cuda_stream))
+
+    def _exact(self, fn):
+        """Run ``fn`` with exact-f32 products, whatever mode the engine is in."""
+        mode = getattr(self, "_mode", "f16x3")
+        self.set_pointwise_mode("f32")
+        try:
+            return fn()
+        finally:
+            self.set_pointwise_mode(mode)
 
     def set_fusion(self, stem=True, separable=True) -> None:
         """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, False = off) and fused
@@ -286,19 +329,33 @@ class HipEngine:
                                                   logits.data_ptr(), stream.cuda_stream))
         x.record_stream(stream)
         counts = [int(v) for v in per]
-        out = [DeviceResult(t, stream) for t in torch.split(logits, counts)]
+        f16 = self._mode != "f32"
+
+        def redo_chunk(i: int, embeddings: bool):
+            def run():
+                e, l = self._exact(lambda: self.run(parts[i], hop, step, embeddings, not embeddings))
+                return e if embeddings else l
+            return run if f16 else None
+
+        out = [DeviceResult(t, stream, self, redo_chunk(i, False)) for i, t in enumerate(torch.split(logits, counts))]
         if want_embeddings:
-            return out, [DeviceResult(t, stream) for t in torch.split(emb, counts)]
+            return out, [DeviceResult(t, stream, self, redo_chunk(i, True)) for i, t in enumerate(torch.split(emb, counts))]
         return out
 
     def embed(self, samples, framehop_s: float) -> DeviceResult:
-        emb, _ = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), True, False)
-        return DeviceResult(emb, self._stream())
+        hop, step = hop_samples(framehop_s), patch_step(framehop_s)
+        x = self.to_device(samples)
+        emb, _ = self.run(x, hop, step, True, False)
+        redo = (lambda: self._exact(lambda: self.run(x, hop, step, True, False))[0]) if self._mode != "f32" else None
+        return DeviceResult(emb, self._stream(), self, redo)
 
     def predict(self, samples, framehop_s: float, out: Optional[torch.Tensor] = None) -> DeviceResult:
         """``out``: optional caller-owned ``[W, n_classes]`` device rows to write the logits into."""
-        _, logits = self.run(samples, hop_samples(framehop_s), patch_step(framehop_s), False, True, out=out)
-        return DeviceResult(logits, self._stream())
+        hop, step = hop_samples(framehop_s), patch_step(framehop_s)
+        x = self.to_device(samples)
+        _, logits = self.run(x, hop, step, False, True, out=out)
+        redo = (lambda: self._exact(lambda: self.run(x, hop, step, False, True, out=out))[1]) if self._mode != "f32" else None
+        return DeviceResult(logits, self._stream(), self, redo)
 
     def stage_tap(self, samples, hop: int, step: int, stage: int, windows: int) -> torch.Tensor:
         """Test hook: NHWC activation after CNN stage ``stage`` for the first ``windows`` windows."""

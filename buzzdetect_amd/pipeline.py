@@ -294,8 +294,36 @@ class Pipeline:
             log.info(f"analyzer {aid}: processing on GPU")
             t_wait = time.perf_counter()
             finished = False
+            pending = None                                  # the batch before the current one: (item, range word, its PCM)
+
+            def settle(p) -> None:
+                """Forward a batch to the writer once it is known to be sound: the f16 matrix path cannot represent an
+                activation beyond 65 504 (engine.range_exceeded); such a batch is computed again with exact f32 products.
+                Runs while the NEXT batch occupies the GPU, so the wait costs nothing."""
+                item, word, pcms = p
+                item.done.synchronize()
+                if int(word[0]) != 0:
+                    log.warning(f"analyzer {aid}: an activation left the f16 range; recomputing {len(item.tasks)} chunk(s) in exact f32")
+                    with torch.cuda.stream(stream):
+                        again = engine._exact(lambda: engine.predict_batch(pcms, self.framehop_s))
+                        base = again[0].tensor
+                        total = sum(item.counts)
+                        whole = torch.as_strided(base, (total, n_classes), (n_classes, 1), base.storage_offset())
+                        torch.from_numpy(item.host).copy_(whole, non_blocking=True)
+                        engine.range_flag_to(word, reset=True)
+                        item.done = torch.cuda.Event()
+                        item.done.record(stream)
+                    engine.overflow_reruns += 1
+                self._put(self.q_write, item)
+
             while not finished:
-                task = self._get(self.q_analyze)
+                try:
+                    task = self.q_analyze.get_nowait()
+                except queue.Empty:                        # nothing to overlap with: do not sit on a finished batch
+                    if pending is not None:
+                        settle(pending)
+                        pending = None
+                    task = self._get(self.q_analyze)
                 if task == EXIT:
                     break
                 waited = time.perf_counter() - t_wait
@@ -335,13 +363,20 @@ class Pipeline:
                         base = res[0].tensor
                         whole = torch.as_strided(base, (total, n_classes), (n_classes, 1), base.storage_offset())
                         host.copy_(whole, non_blocking=True)
+                    word = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                    engine.range_flag_to(word)
                     done = torch.cuda.Event()
                     done.record(stream)
-                # the pinned slots go back to the ring when the batch's event has fired (the writer waits for it anyway):
-                # this thread never blocks on the device and can queue the next batch at once
-                self._put(self.q_write, WriteItem(batch, host.numpy(), counts, done, aid, t_start))
+                # the pinned slots go back to the ring when the batch's event has fired (the writer waits for it anyway);
+                # the batch itself goes to the writer one batch later, after its range word has been looked at
+                item = WriteItem(batch, host.numpy(), counts, done, aid, t_start)
                 held = []
+                if pending is not None:
+                    settle(pending)
+                pending = (item, word, pcms)
                 t_wait = time.perf_counter()
+            if pending is not None:
+                settle(pending)
             log.debug(f"analyzer {aid}: terminating")
         except PipelineAborted:
             pass

@@ -174,8 +174,19 @@ BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int3
 
 /* Arithmetic of the 1x1 convolutions: 0 = v_mfma_f32_32x32x2_f32 (exact f32 products),
    1 = split-f16 (default): every f32 operand carried as hi + lo halves, three f16 MFMAs per product,
-   f32 accumulate; same accuracy class as f32, ~5x the matrix-core rate. */
+   f32 accumulate; same accuracy class as f32, ~5x the matrix-core rate;
+   2 = plain f16 operands, ONE MFMA per product, f32 accumulate (BASELINE config 5's arithmetic): outside the
+   reference's 1e-4 logit tolerance by design (~1e-3), for callers that trade accuracy for rate. */
 BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
+/* Modes 1 and 2 carry activations as f16: one beyond 65 504 (the network has plain ReLU, yamnet.py:36-74, nothing bounds
+   it) would become +inf and the result garbage.  The kernels track the largest magnitude they convert and set a sticky
+   per-engine device word when it leaves the f16 range.  bd_range_flag copies that word to *flag_host (1 = some launch
+   since the last reset overflowed: repeat those chunks in mode 0) and, with reset != 0, clears it.  It waits for `stream`
+   - call it where the results are read anyway.  (Folded weights beyond +-60 000 are refused at bd_create.) */
+BD_API int bd_range_flag(bd_handle h, int32_t* flag_host, int32_t reset, void* stream);
+/* The same without waiting: enqueues a copy of the word to `dst` (device memory or PINNED host memory) on `stream`,
+   then, with reset != 0, its clearing.  For pipelines that read results through their own events. */
+BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* stream);
 
 /* Kernel fusion in mode 1 (both on by default; 0 = one kernel per op, the layout the stage taps use):
    stem == 2       layers 1-2 (conv, depthwise, pointwise) and layer 3's stride-2 depthwise as one kernel that

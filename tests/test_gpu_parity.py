@@ -448,3 +448,75 @@ def test_back_to_back_numpy_inputs_do_not_race(engine):
     pending = [engine.predict(x, 0.96) for x in xs]                # enqueued back to back
     for w, p in zip(want, pending):
         assert np.array_equal(p.numpy(), w)
+
+
+# --------------------------------------------------------------------------- f16 range guard, plain-f16 mode
+def _loud_blob(weights_bundle, layer_gain=30000.0):
+    """The synthetic embedder with the depthwise kernel of layer 6 scaled up: its outputs (a few units with the seeded
+    weights) reach the 1e4..1e5 range, beyond what an f16 'hi' half can hold."""
+    import json
+    import os
+    from buzzdetect_amd import weights as W
+    blob = weights_bundle["blob"].copy()
+    with open(os.path.join(os.path.dirname(W.__file__), "data", "embedder_manifest.json")) as f:
+        man = json.load(f)
+    entries = man["tensors"] if isinstance(man, dict) and "tensors" in man else man
+    hit = [e for e in entries if "layer_with_weights-18/depthwise_kernel" in (e.get("name") or e.get("key") or "")]
+    assert len(hit) == 1, "manifest layout changed"
+    off, n = hit[0]["offset"] // 4, int(np.prod(hit[0]["shape"]))
+    blob[off:off + n] *= layer_gain
+    return blob
+
+
+def test_activation_beyond_the_f16_range_is_detected_and_recomputed_in_f32(weights_bundle):
+    """Plain ReLU bounds nothing (yamnet.py:36-74).  With a loud layer the split-f16 path would produce inf / NaN (or a
+    ReLU-masked zero); the engine must notice, and `.numpy()` must hand back the exact-f32 result instead."""
+    from buzzdetect_amd.engine import HipEngine
+    blob = _loud_blob(weights_bundle)
+    b = weights_bundle
+    x = O.synthetic_audio(HOP * 6 + 15600, seed=77)
+    eng = HipEngine(embedder_blob=blob)
+    try:
+        eng.set_pointwise_mode("f32")
+        exact = eng.predict(x, 0.96).numpy().copy()
+        assert np.isfinite(exact).all() and not eng.range_exceeded()
+        ref = O.predict(x, blob, b["mel"], b["head_kernel"], b["head_bias"], HOP, STEP, np.float64)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(exact - ref).max() < 1e-4 * scale
+        for mode in ("f16x3", "f16"):
+            eng.set_pointwise_mode(mode)
+            raw = eng.predict(x, 0.96)
+            torch_rows = raw.tensor.clone()
+            got = raw.numpy()                               # reads the range word, recomputes
+            assert eng.overflow_reruns >= 1
+            assert np.array_equal(got, exact), mode
+            assert not np.array_equal(torch_rows.cpu().numpy(), exact)      # what the f16 path had produced was wrong
+            assert not eng.range_exceeded()                 # the word was reset
+        # a quiet input through the same engine afterwards: no flag, no recomputation
+        eng.set_pointwise_mode("f16x3")
+        before = eng.overflow_reruns
+        quiet = eng.predict(np.zeros(HOP * 2 + 15600, np.float32), 0.96).numpy()
+        assert np.isfinite(quiet).all()
+    finally:
+        eng.close()
+    # the reference weights stay far inside the range: the shared engine never trips the guard
+    assert before >= 2
+
+
+def test_plain_f16_mode_is_close_but_outside_the_gate(engine, weights_bundle):
+    """Mode 'f16' (BASELINE config 5): one MFMA per product.  Reported separately from the 1e-4 gate: the error is
+    ~1e-3 of the logit scale, far from garbage, and the default mode is unaffected afterwards."""
+    b = weights_bundle
+    x = O.synthetic_audio(HOP * 40 + 15600, seed=78)
+    ref = O.predict(x, b["blob"], b["mel"], b["head_kernel"], b["head_bias"], HOP, STEP, np.float64)
+    default = engine.predict(x, 0.96).numpy().copy()
+    engine.set_pointwise_mode("f16")
+    try:
+        plain = engine.predict(x, 0.96).numpy().copy()
+    finally:
+        engine.set_pointwise_mode("f16x3")
+    err_plain, err_default = np.abs(plain - ref).max(), np.abs(default - ref).max()
+    assert err_default < 1e-4
+    assert 1e-5 < err_plain < 5e-2, err_plain
+    assert np.array_equal(engine.predict(x, 0.96).numpy(), default)
+    assert engine.overflow_reruns == 0
