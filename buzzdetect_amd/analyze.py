@@ -50,7 +50,8 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
             framehop_prop: float = 1, chunklength: float = 200, dir_audio: str = "audio_in",
             dir_out: Optional[str] = None, embeddername: str = "yamnet_k2", engine=None,
             rank: Optional[int] = None, world_size: Optional[int] = None, analyzers_gpu: int = 2,
-            n_streamers: Optional[int] = None, engines: Optional[list] = None) -> AnalyzeReport:
+            n_streamers: Optional[int] = None, engines: Optional[list] = None,
+            gather_logits: bool = False) -> AnalyzeReport:
     """Analyse every ``.wav`` under ``dir_audio``; write ``<ident>_buzzdetect.csv`` under ``dir_out``.
 
     ``classes_out`` / ``precision`` choose activations vs detections exactly as in the reference;
@@ -58,7 +59,10 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
     ``analyzers_gpu`` analyzer threads (each with its own engine and HIP stream) are fed by ``n_streamers`` reader
     threads.  ``engine``: use this engine on ONE analyzer thread instead (tests, embedding in another loop);
     ``engines``: prebuilt engines, one per analyzer thread (a caller that analyses folder after folder keeps them: building
-    an engine folds and uploads the weights, ~0.1 s)."""
+    an engine folds and uploads the weights, ~0.1 s).
+    ``gather_logits`` (several ranks): BASELINE config 4 - every rank analyses its recordings, the per-window logits
+    are gathered to rank 0 over RCCL once per round of ``world_size`` recordings, and rank 0 alone writes the result
+    files (for output folders only rank 0 can reach; without it every rank writes its own files)."""
     from .engine import HipEngine, hop_samples, patch_step   # device code is only needed once there is work to do
 
     dist = None
@@ -104,9 +108,6 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
     conflicting = {i for i in idents if idents.count(i) > 1}
     todo = [(p, i) for p, i in zip(paths, idents) if i not in conflicting]
     mine = [todo[k] for k in sharding.shard_indices(len(todo), rank, world_size)]
-    jobs = [FileJob(path=p, ident=i, shortpath=i + os.path.splitext(p)[1], rf=results.ResultFile(os.path.join(dir_out, i)))
-            for p, i in mine]
-
     if engine is not None:
         analyzers, make_engine = 1, (lambda: engine)
     elif engines:
@@ -126,12 +127,92 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
             return HipEngine(embeddername=embeddername, modelname=modelname, device=device_index)
 
     readers = n_streamers if n_streamers else STREAMERS_PER_ANALYZER * analyzers
-    pipe = Pipeline(make_engine=make_engine, classes=classes, framehop_s=framehop_s, hop=hop_samples(framehop_s),
-                    step=patch_step(framehop_s), chunklength=chunklength, framelength_s=framelength_s,
-                    digits_time=digits_time, digits_results=digits_results, classes_out=classes_out, threshold=threshold,
-                    readers=readers, analyzers=analyzers)
-    report = pipe.run(jobs)
+    common = dict(make_engine=make_engine, classes=classes, framehop_s=framehop_s, hop=hop_samples(framehop_s),
+                  step=patch_step(framehop_s), chunklength=chunklength, framelength_s=framelength_s,
+                  digits_time=digits_time, digits_results=digits_results, classes_out=classes_out, threshold=threshold,
+                  readers=readers, analyzers=analyzers)
+
+    if gather_logits and dist is not None and world_size > 1:
+        report = _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, framehop_s, chunklength,
+                                   digits_time, digits_results, classes_out, threshold)
+    else:
+        jobs = [FileJob(path=p, ident=i, shortpath=i + os.path.splitext(p)[1], rf=results.ResultFile(os.path.join(dir_out, i)))
+                for p, i in mine]
+        report = Pipeline(**common).run(jobs)
     report.files_total = len(todo)
     for ident in sorted(conflicting):
         report.messages.append(f"conflicting names, skipped: {ident}")
+    return report
+
+
+def _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, framehop_s, chunklength, digits_time,
+                      digits_results, classes_out, threshold) -> Report:
+    """Config 4: round-robin recordings, one RCCL gather of the logit blocks per round, rank 0 writes every file.
+    All ranks derive the same plan (which recordings, how many rows each) from the files themselves."""
+    import numpy as np
+    from . import _lib
+    from .pipeline import log
+    from .wavio import WavFormatError
+    lib = _lib.load()
+    hop, step = common["hop"], common["step"]
+    plan = []                     # (path, ident, chunks, windows per chunk)
+    for path, ident in todo:
+        rf = results.ResultFile(os.path.join(dir_out, ident))
+        if rf.complete or os.path.getsize(path) < FILE_SIZE_MINIMUM:
+            continue
+        try:
+            track = WavTrack(path)
+        except (WavFormatError, OSError) as exc:
+            log.warning(f"planner: {exc}; skipping")
+            continue
+        chunks, counts = [], []
+        for chunk in framing.gaps_to_chunklist([(0, track.duration)], chunklength):
+            a, b = framing.chunk_sample_range(chunk, track.samplerate)
+            frames = min(b, track.frames) - a
+            if frames <= 0:
+                continue
+            n16 = _lib.check(lib.bd_resample_length(frames, track.samplerate, 16000))
+            chunks.append((float(chunk[0]), float(chunk[1])))
+            counts.append(_lib.check(lib.bd_num_windows(n16, hop, step)))
+        track.close()
+        if chunks:
+            plan.append((path, ident, chunks, counts))
+    rows_per_file = [sum(c) for _, _, _, c in plan]
+
+    def write_file(index: int, rows: "np.ndarray") -> None:          # rank 0, from its writer thread
+        path, ident, chunks, counts = plan[index]
+        rf = results.ResultFile(os.path.join(dir_out, ident))
+        os.makedirs(os.path.dirname(rf.path_complete) or ".", exist_ok=True)
+        at, parts, head = 0, [], b""
+        for chunk, n in zip(chunks, counts):
+            block = rows[at:at + n]
+            at += n
+            if threshold is None:
+                head, body = results.activation_csv(block, classes, framehop_s, digits_time, chunk[0], classes_out, digits_results)
+            else:
+                head, body = results.detection_csv(block, threshold, classes, framehop_s, digits_time, chunk[0])
+            parts.append(body)
+        with open(rf.path_complete + ".tmp", "wb") as f:
+            f.write(head)
+            f.writelines(parts)
+        os.replace(rf.path_complete + ".tmp", rf.path_complete)
+        if os.path.exists(rf.path_partial):
+            os.remove(rf.path_partial)
+
+    import torch.distributed as dist
+    # RCCL moves device tensors; a gloo group (rehearsals on one GPU, CPU tests) moves host tensors
+    gather_device = "cpu" if dist.get_backend() == "gloo" else probe.device
+    gatherer = sharding.RoundGatherer(rows_per_file, len(classes), write_file, device=gather_device)
+
+    def sink(job: FileJob, rows) -> None:
+        block = np.concatenate([r for _, r in rows]) if rows else np.zeros((0, len(classes)), np.float32)
+        gatherer.submit(job.index, block)
+
+    jobs = []
+    for k in sharding.shard_indices(len(plan), rank, world_size):
+        path, ident, _, _ = plan[k]
+        jobs.append(FileJob(path=path, ident=ident, shortpath=ident + os.path.splitext(path)[1],
+                            rf=results.ResultFile(os.path.join(dir_out, ident)), index=k))
+    report = Pipeline(**common, file_sink=sink, ignore_partial=True).run(jobs)
+    gatherer.finish()
     return report

@@ -65,6 +65,8 @@ class FileJob:
     track: Optional[WavTrack] = None
     header: bytes = b""
     bodies: List[Tuple[float, bytes]] = field(default_factory=list)      # (chunk start, rows) of a fresh recording
+    index: int = -1               # position in the run's recording list (gather mode)
+    rows: List[Tuple[float, "np.ndarray"]] = field(default_factory=list)  # (chunk start, logits) when a file sink takes the rows
 
 
 @dataclass
@@ -142,7 +144,9 @@ class PinnedRing:
 class Pipeline:
     def __init__(self, *, make_engine: Callable[[], object], classes: Sequence[str], framehop_s: float, hop: int, step: int,
                  chunklength: float, framelength_s: float, digits_time: int, digits_results: int, classes_out,
-                 threshold: Optional[float], readers: int = 4, analyzers: int = 2, device=None):
+                 threshold: Optional[float], readers: int = 4, analyzers: int = 2, device=None,
+                 file_sink: Optional[Callable[[FileJob, List[Tuple[float, "np.ndarray"]]], None]] = None,
+                 ignore_partial: bool = False):
         import torch
         self.torch = torch
         self.make_engine = make_engine
@@ -152,6 +156,9 @@ class Pipeline:
         self.digits_time, self.digits_results = digits_time, digits_results
         self.n_readers, self.n_analyzers = max(1, readers), max(1, analyzers)
         self.device = device
+        # file_sink: instead of writing result files, hand every finished recording's rows (sorted by chunk start) to this
+        # callable from the writer thread (the multi-GPU gather: rank 0 writes what the other ranks computed)
+        self.file_sink, self.ignore_partial = file_sink, ignore_partial
         self.q_files: "queue.Queue" = queue.Queue()
         self.q_units: "queue.Queue" = queue.Queue(maxsize=8 * self.n_readers)
         self.q_analyze: "queue.Queue" = queue.Queue(maxsize=2 * self.n_readers)      # coordination.py:129-138
@@ -208,7 +215,10 @@ class Pipeline:
             return self._skip("planner", job, f"{exc}; skipping", logging.WARNING,
                               f"unreadable, skipped: {job.shortpath} ({exc})")
         job.fresh = not os.path.exists(job.rf.path_partial)
-        chunks = job.rf.pending_chunks(track.duration, self.chunklength, self.framelength_s)
+        if self.ignore_partial:
+            chunks = framing.gaps_to_chunklist([(0, track.duration)], self.chunklength)
+        else:
+            chunks = job.rf.pending_chunks(track.duration, self.chunklength, self.framelength_s)
         if not chunks:
             track.close()
             return self._skip("planner", job, f"Skipping {job.shortpath}; nothing left to analyze")
@@ -400,6 +410,12 @@ class Pipeline:
         if job.track is not None:
             job.track.close()
             job.track = None
+        if self.file_sink is not None:
+            rows, job.rows = sorted(job.rows, key=lambda sr: sr[0]), []
+            self.file_sink(job, rows)
+            with self.lock:
+                self.report.files_done += 1
+            return
         if not os.path.exists(job.rf.path_partial):
             return
         if job.fresh and job.bodies:
@@ -438,14 +454,18 @@ class Pipeline:
                 for t, n in zip(item.tasks, item.counts):
                     rows = item.host[at:at + n]
                     at += n
-                    if self.threshold is None:
+                    if self.file_sink is not None:
+                        t.job.rows.append((t.chunk[0], rows.copy()))
+                        head = body = None
+                    elif self.threshold is None:
                         head, body = results.activation_csv(rows, self.classes, self.framehop_s, self.digits_time, t.chunk[0],
                                                             self.classes_out, self.digits_results)
                     else:
                         head, body = results.detection_csv(rows, self.threshold, self.classes, self.framehop_s,
                                                            self.digits_time, t.chunk[0])
-                    t.job.rf.append_text(head, body)
-                    if t.job.fresh:
+                    if head is not None:
+                        t.job.rf.append_text(head, body)
+                    if head is not None and t.job.fresh:
                         t.job.header = head
                         t.job.bodies.append((t.chunk[0], body))
                     log.log(PROGRESS, f"analyzer {item.analyzer}: analyzed {t.job.shortpath}, chunk "

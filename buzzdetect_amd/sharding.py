@@ -144,3 +144,68 @@ def assemble_files(rounds: Sequence[Round], gathered: Sequence[torch.Tensor], n_
             for u, at in zip(units, unit_offsets(units)):
                 parts[u.file].append((u.batch, g[r, at:at + u.windows]))
     return [torch.cat([t for _, t in sorted(p, key=lambda bt: bt[0])]) if p else torch.empty(0) for p in parts]
+
+
+class RoundGatherer:
+    """Config 4's collective inside a running analysis: recordings complete in any order on every rank, but the
+    gathers - one per ROUND of ``world`` recordings (recording i belongs to rank i mod world, round i // world) - are
+    collectives and must be issued in the same order everywhere.  ``submit`` hands in the rows of a finished recording;
+    rounds are gathered as soon as they and all earlier rounds are ready; on ``dst`` every gathered recording is passed
+    to ``on_file(file_index, rows)``.  Block sizes come from ``rows_per_file``, which every rank computes for itself
+    from the recordings' headers: no count exchange."""
+
+    def __init__(self, rows_per_file: Sequence[int], n_cols: int, on_file, device="cpu", dst: int = 0, group=None):
+        self.rows_per_file = [int(r) for r in rows_per_file]
+        self.n_files, self.n_cols = len(self.rows_per_file), int(n_cols)
+        self.on_file, self.device, self.dst, self.group = on_file, torch.device(device), dst, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_rounds = (self.n_files + self.world - 1) // self.world
+        self._ready = {}                      # round -> rows of this rank's recording in it
+        self._next = 0
+
+    def round_rows(self, g: int) -> int:
+        files = range(g * self.world, min((g + 1) * self.world, self.n_files))
+        m = max(self.rows_per_file[f] for f in files)
+        return (m + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+
+    def submit(self, file_index: int, rows) -> None:
+        if owner_of(file_index, self.world) != self.rank:
+            raise ValueError(f"recording {file_index} does not belong to rank {self.rank}")
+        rows = torch.as_tensor(rows, dtype=torch.float32)
+        if tuple(rows.shape) != (self.rows_per_file[file_index], self.n_cols):
+            raise ValueError(f"recording {file_index}: got {tuple(rows.shape)} rows, planned "
+                             f"({self.rows_per_file[file_index]}, {self.n_cols})")
+        self._ready[file_index // self.world] = rows
+        self._pump()
+
+    def _mine(self, g: int) -> Optional[int]:
+        f = g * self.world + self.rank
+        return f if f < self.n_files else None
+
+    def _pump(self) -> None:
+        while self._next < self.n_rounds:
+            g = self._next
+            mine = self._mine(g)
+            if mine is not None and g not in self._ready:
+                return                        # this rank's recording of the round is still being analysed
+            n = self.round_rows(g)
+            block = torch.zeros((n, self.n_cols), dtype=torch.float32, device=self.device)
+            if mine is not None:
+                rows = self._ready.pop(g)
+                block[: rows.shape[0]] = rows.to(self.device)
+            out, _ = gather_round(block, n, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                host = out.cpu()
+                for r in range(self.world):
+                    f = g * self.world + r
+                    if f < self.n_files:
+                        self.on_file(f, host[r, : self.rows_per_file[f]].numpy())
+            self._next += 1
+
+    def finish(self) -> None:
+        """Every local recording has been submitted: run the remaining rounds (a rank without a recording in the last
+        round contributes an empty block)."""
+        self._pump()
+        if self._next != self.n_rounds:
+            raise RuntimeError(f"rank {self.rank}: rounds {self._next}..{self.n_rounds - 1} never became ready")

@@ -235,3 +235,41 @@ def test_pipeline_failure_in_any_stage_stops_everything(engine, tmp_path, monkey
     jobs = [FileJob(path=str(audio / "two.wav"), ident="two", shortpath="two.wav", rf=R.ResultFile(str(tmp_path / "x" / "two")))]
     with pytest.raises(RuntimeError, match="no such device"):
         pipe.run(jobs)
+
+
+def _gather_rank(rank, world, port, audio, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                       # both ranks share the one GPU of the box; the collective runs over gloo
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from buzzdetect_amd.analyze import analyze
+        rep = analyze("model_general_v3", chunklength=5, dir_audio=audio, dir_out=out, gather_logits=True, analyzers_gpu=1)
+        assert rep.files_total == 3
+        assert rep.files_done == (2 if rank == 0 else 1)        # round-robin: recordings 0 and 2 / recording 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_analyze_gathers_logits_to_rank_0_world_size_2(engine, tmp_path):
+    """BASELINE config 4 in miniature: two ranks, recordings dealt round-robin, one gather per round, rank 0 writes every
+    result file - the same bytes a single process writes."""
+    import socket
+    import torch.multiprocessing as mp
+    from buzzdetect_amd.analyze import analyze
+    audio = tmp_path / "audio"
+    _three_recordings(audio)
+    analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "solo"), engine=engine)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gather_rank, args=(2, port, str(audio), str(tmp_path / "gathered")), nprocs=2, join=True)
+    for rel in ("a/one", "two", "three32k"):
+        a = (tmp_path / "solo" / f"{rel}_buzzdetect.csv").read_bytes()
+        b = (tmp_path / "gathered" / f"{rel}_buzzdetect.csv").read_bytes()
+        assert a == b
+        assert not (tmp_path / "gathered" / f"{rel}_buzzpart.csv").exists()

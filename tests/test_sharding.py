@@ -2,6 +2,7 @@
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -166,3 +167,36 @@ def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
     monkeypatch.delenv("BD_BENCH_REHEARSAL")
     calls.clear()
     assert bench.main() == 2 and not calls
+
+
+def _worker_round_gatherer(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows_per_file = [5, 9, 2, 7, 4]                       # five recordings over two ranks: rounds (0,1) (2,3) (4,-)
+        got = {}
+        g = sharding.RoundGatherer(rows_per_file, 13, lambda f, rows: got.__setitem__(f, rows.copy()))
+        assert (g.n_rounds, g.round_rows(0), g.round_rows(1), g.round_rows(2)) == (3, 12, 8, 4)
+        mine = sharding.shard_indices(5, rank, world)
+        for f in reversed(mine):                              # recordings finish out of order; gathers still go round by round
+            g.submit(f, np.full((rows_per_file[f], 13), 10.0 * f) + np.arange(rows_per_file[f])[:, None])
+        g.finish()
+        if rank == 0:
+            assert sorted(got) == [0, 1, 2, 3, 4]
+            for f, rows in got.items():
+                assert rows.shape == (rows_per_file[f], 13)
+                assert np.array_equal(rows[:, 5], 10.0 * f + np.arange(rows_per_file[f]))
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+        else:
+            assert not got
+        with pytest.raises(ValueError):
+            g.submit(rank ^ 1, np.zeros((rows_per_file[rank ^ 1], 13)))       # not this rank's recording
+    finally:
+        dist.destroy_process_group()
+
+
+def test_round_gatherer_world_size_2_gloo(tmp_path):
+    import numpy  # noqa: F401
+    mp.spawn(_worker_round_gatherer, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
