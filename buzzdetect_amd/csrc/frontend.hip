@@ -452,17 +452,13 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restric
         for (int n1 = 0; n1 < 13; ++n1) win[n1] = raw[n1] * t_hann[16 * n1];
 
         // ---------------- output: this wave's four rows of 256 bytes ----------------
-        // four LDS reads, then four stores through a buffer resource sized n_frames rows: rows of a last, partial group
-        // fall outside it and are dropped by the bounds check (no per-row branch)
+        // one 16-byte store per lane (lane -> row lane / 16, bands 4 (lane % 16) ..) through a buffer resource sized
+        // n_frames rows: rows of a last, partial group fall outside it and are dropped by the bounds check
         {
-            float o[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = xw[q * kOutRow + lane];
-            const int byte0 = ((group * kGroup + wave * 4) * BD_MEL_BANDS + lane) * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[q]), out_rsrc,
-                                                      byte0 + q * (BD_MEL_BANDS * 4), 0, 0);
+            const float* src = xw + fq * kOutRow + 4 * j16;
+            v4f o = {src[0], src[1], src[2], src[3]};
+            const int byte0 = ((group * kGroup + wave * 4 + fq) * BD_MEL_BANDS + 4 * j16) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), out_rsrc, byte0, 0, 0);
             lds_order();                                       // the row reads stay ahead of the next transform's tile writes
         }
         FE_STAMP(20)
