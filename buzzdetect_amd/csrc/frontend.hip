@@ -5,7 +5,7 @@
 // folded in as "samples past n_valid read as zero".  Nothing of [T,400] / [T,257] is ever
 // written to HBM.
 //
-// logmel_kernel: one 1024-thread workgroup per CU (four waves per SIMD) walks groups of 64 STFT frames.
+// logmel_kernel: one 768-thread workgroup per CU (three waves per SIMD) walks groups of 48 STFT frames.
 //   FFT phase   sixteen lanes own a frame, a wave four frames: the frame is read straight from global memory
 //               (buffer resource: samples past the end read as zero) as 200 packed complex points
 //               z[n] = x[2n] + i x[2n+1] (+56 zeros), Hann-windowed, and transformed as 256 = 16 x 16:
@@ -14,9 +14,9 @@
 //               The upper half of the packed spectrum goes through the tile once more in natural order so
 //               that every lane can pick up the mirrored bins Z[256 - k] of half of its own bins and split
 //               BOTH X[k] and X[256 - k] out of one (Z[k], Z[256 - k]) pair.  |X| lands in a
-//               [64 frames][244] f32 tile.  Wave-level ordering only, no workgroup barrier inside the phase;
+//               [48 frames][244] f32 tile.  Wave-level ordering only, no workgroup barrier inside the phase;
 //               the next group's samples are requested before the barrier that ends it.
-//   mel phase   lane = frame: each of the sixteen waves owns a run of mel bands (balanced by non-zeros);
+//   mel phase   lane = frame: each of the twelve waves owns a run of mel bands (balanced by non-zeros);
 //               a band is a short run of bins, so its weights are wave-uniform and come in through
 //               scalar loads - 461 v_fmac per 64 frames instead of 18 per frame and lane, and every LDS
 //               read is a conflict-free 16-byte row read.  log(), then the row is staged in the LDS region
@@ -36,23 +36,23 @@ namespace {
 
 namespace fe {
 
-constexpr int kThreads = 1024;         // one workgroup per CU, four waves per SIMD (128 VGPRs): a wave issues one vector
-constexpr int kWavesG = 16;            // instruction per ~5 cycles, so the packed-f32 pipe only fills with several waves
-constexpr int kGroup = 64;             // frames per workgroup pass: every wave transforms four of them
+constexpr int kWavesG = 12;            // one workgroup per CU, three waves per SIMD: 168 VGPRs keep the per-lane twiddles in
+constexpr int kThreads = 64 * kWavesG; // registers and the LDS affords every wave a full four-frame transpose tile
+constexpr int kGroup = 4 * kWavesG;    // 48 frames per workgroup pass: every wave transforms four of them
 constexpr int kXRow = 36;              // transpose tile: row (frame, k1) = 16 float2 + 16 B of bank padding, in dwords
-constexpr int kXFrame = 8 * kXRow;     // 288 dwords; the transpose runs eight of the sixteen rows at a time: 4 frames = 4608 B
+constexpr int kXFrame = 16 * kXRow;    // 576 dwords per frame, 2304 for the wave's four
 constexpr int kZFrame = 2 * 128 + 32;  // natural-order tile of the upper half spectrum: 128 float2 + 128 B bank shift
-constexpr int kTile = 1284;            // a wave's LDS region in dwords (5136 B); 1284 = 4 mod 32 spreads the staged
-                                       // output rows of the sixteen regions over the banks
+constexpr int kTile = 2308;            // a wave's LDS region in dwords (9232 B); 2308 = 4 mod 32 spreads the staged
+                                       // output rows of the regions over the banks
 constexpr int kMagRow = 244;           // |X| tile row: bins 0..243 (5..239 are used); 244 = 52 mod 64 -> 16-byte row reads of
                                        // sixteen consecutive lanes cover all 64 banks
 constexpr int kOutRow = 65;
-constexpr int kTabRows = 13 + 15 + 8;  // per-lane constants in LDS: Hann pairs, W256^(n2 k1), split twiddles; [row][16] float2
+constexpr int kTabRows = 13;           // per-lane Hann pairs in LDS, [row][16] float2 (read once per group, at a quiet moment)
 static_assert(4 * kXFrame <= kTile && 4 * kZFrame <= kTile && 4 * kOutRow <= kTile, "a wave's region holds each of its tiles");
 
-// mel bands of wave w in the mel phase: [kCut[w], kCut[w + 1]); balanced on (non-zeros + log) per band; each run holds at
-// most 48 weights counted from a 16-byte boundary (three s_load_dwordx16)
-constexpr int kCut[kWavesG + 1] = {0, 7, 13, 19, 24, 29, 33, 38, 42, 45, 49, 52, 55, 57, 60, 62, 64};
+// mel bands of wave w in the mel phase: [kCut[w], kCut[w + 1]); balanced on (non-zeros + log) per band under the
+// constraint that a run holds at most 48 weights counted from a 16-byte boundary (three s_load_dwordx16)
+constexpr int kCut[kWavesG + 1] = {0, 11, 20, 28, 35, 41, 46, 50, 54, 57, 60, 62, 64};
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -242,9 +242,9 @@ __device__ __forceinline__ void mel_wave(const float* __restrict__ mag_row, floa
 __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restrict__ pcm, int n_valid, int n_frames,
                                                           float* __restrict__ out,
                                                           const FeTables* __restrict__ tab FE_TRACE_ARG) {
-    __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        // 62 464 B
-    __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kTile];           // 82 176 B
-    __shared__ __attribute__((aligned(16))) v2f s_tab[kTabRows * 16];             //  4 608 B
+    __shared__ __attribute__((aligned(16))) float s_mag[kGroup * kMagRow];        //  46 848 B
+    __shared__ __attribute__((aligned(16))) float s_x[kWavesG * kTile];           // 110 784 B
+    __shared__ __attribute__((aligned(16))) v2f s_tab[kTabRows * 16];             //   1 664 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -252,32 +252,31 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restric
     const int fq = lane >> 4;              // frame of the wave's four
     const int j16 = lane & 15;             // n2 before the transpose, k1 after it
 
-    // Per-lane constants (a lane's n2 / k1 never changes) live in LDS, [row][16]: the register file has to hold four
-    // waves per SIMD.  rows 0..12: Hann taps of z[16 n1 + n2] (zero past sample 400); 13..27: W256^(n2 k1), k1 = 1..15;
-    // 28..35: 0.5 exp(-2 pi i k / 512), k = k1 + 16 k2, k2 = 0..7 (the 1/2 of the real-FFT split).
+    // Per-lane constants (a lane's n2 / k1 never changes).  Hann taps of z[16 n1 + n2] (zero past sample 400) sit in LDS,
+    // [n1][16], and are read once per group; the twiddles stay in registers.
     if (tid < kTabRows * 16) {
         const int r = tid >> 4, c = tid & 15;
-        v2f v;
-        if (r < 13) {
-            v = v2f{tab->hann[2 * (16 * r + c)], tab->hann[2 * (16 * r + c) + 1]};
-        } else if (r < 28) {
-            const float2 t = tab->tw256[(c * (r - 12)) & 255];
-            v = v2f{t.x, t.y};
-        } else {
-            const float2 t = tab->tw512[c + 16 * (r - 28)];
-            v = v2f{0.5f * t.x, 0.5f * t.y};
-        }
-        s_tab[tid] = v;
+        s_tab[tid] = v2f{tab->hann[2 * (16 * r + c)], tab->hann[2 * (16 * r + c) + 1]};
     }
     const v2f* const t_hann = s_tab + j16;
-    const v2f* const t_tw = s_tab + 13 * 16 + j16;
-    const v2f* const t_tws = s_tab + 28 * 16 + j16;
+    v2f tw[15];                            // W256^(n2 k1), k1 = 1..15
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const float2 t = tab->tw256[(j16 * k1) & 255];
+        tw[k1 - 1] = v2f{t.x, t.y};
+    }
+    v2f tws[8];                            // 0.5 * exp(-2 pi i k / 512), k = k1 + 16 k2, k2 = 0..7 (the 1/2 of the split)
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+        const float2 t = tab->tw512[j16 + 16 * k2];
+        tws[k2] = v2f{0.5f * t.x, 0.5f * t.y};
+    }
     const float* const melw = tab->melw;
     const v2f kHalf = {0.5f, 0.5f};
 
     float* const xw = s_x + wave * kTile;                       // this wave's region
-    v2f* const x_wr = reinterpret_cast<v2f*>(xw + fq * kXFrame) + j16;                        // + (k1 & 7) * (kXRow / 2)
-    const float4* const x_rd = reinterpret_cast<const float4*>(xw + fq * kXFrame + (j16 & 7) * kXRow);
+    v2f* const x_wr = reinterpret_cast<v2f*>(xw + fq * kXFrame) + j16;                        // + k1 * (kXRow / 2)
+    const float4* const x_rd = reinterpret_cast<const float4*>(xw + fq * kXFrame + j16 * kXRow);
     v2f* const z_wr = reinterpret_cast<v2f*>(xw + fq * kZFrame) + j16;                       // + 16 (k2 - 8)
     const v2f* const z_base = reinterpret_cast<const v2f*>(xw + fq * kZFrame);
     // mirrored bin of (k1, k2) minus 128: k2 = 0: 128 - k1 (k1 = 0: the pair of bin 0 feeds no mel band; read something
@@ -327,34 +326,25 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restric
             dft16(u);                                          // over n1 -> k1
 #pragma unroll
             for (int kb = 1; kb < 16; kb += 5) {               // five independent products at a time
-                v2f t[5], w[5];
-                lds_order();                                   // keeps the table reads where they are (register budget)
+                v2f t[5];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) w[i] = t_tw[16 * (kb + i - 1)];
+                for (int i = 0; i < 5; ++i) t[i] = cmul1_v(u[kb + i], tw[kb + i - 1]);
 #pragma unroll
-                for (int i = 0; i < 5; ++i) t[i] = cmul1_v(u[kb + i], w[i]);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) u[kb + i] = cmul2_v(u[kb + i], w[i], t[i]);
+                for (int i = 0; i < 5; ++i) u[kb + i] = cmul2_v(u[kb + i], tw[kb + i - 1], t[i]);
             }
             FE_STAMP(round * 8 + 2)
-            // transpose through the wave's tile, eight rows (k1) at a time: every lane writes its eight points of those
-            // rows (full-width stores), then the eight lanes of each frame that own one of the rows gather theirs
+            // transpose through the wave's tile
             v2f v[16];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int k1 = 0; k1 < 16; ++k1) x_wr[k1 * (kXRow / 2)] = u[k1];
+            lds_order();
 #pragma unroll
-                for (int k1 = 0; k1 < 8; ++k1) x_wr[k1 * (kXRow / 2)] = u[8 * h + k1];
-                lds_order();
-                if ((j16 >> 3) == h) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {              // lane k1 gathers its row over n2
-                        const float4 f = x_rd[q];
-                        v[2 * q] = v2f{f.x, f.y};
-                        v[2 * q + 1] = v2f{f.z, f.w};
-                    }
-                }
-                lds_order();                                   // the tile is rewritten by the second half / below
+            for (int q = 0; q < 8; ++q) {                      // lane k1 gathers its row over n2
+                const float4 f = x_rd[q];
+                v[2 * q] = v2f{f.x, f.y};
+                v[2 * q + 1] = v2f{f.z, f.w};
             }
+            lds_order();                                       // the tile is rewritten below
             FE_STAMP(round * 8 + 3)
             dft16(v);                                          // over n2 -> k2: v[k2] = Z[k1 + 16 k2]
             FE_STAMP(round * 8 + 4)
@@ -371,19 +361,16 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restric
             FE_STAMP(round * 8 + 5)
 #pragma unroll
             for (int kb = 0; kb < 8; kb += 4) {                // four pairs at a time
-                v2f e2[4], o2[4], t[4], w[4];
-                lds_order();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) w[i] = t_tws[16 * (kb + i)];
+                v2f e2[4], o2[4], t[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     e2[i] = add_conj(v[kb + i], zm[kb + i]);   // 2 E[k]
                     o2[i] = odd_part(v[kb + i], zm[kb + i]);   // 2 O[k]
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = cmul1_v(o2[i], w[i]);
+                for (int i = 0; i < 4; ++i) t[i] = cmul1_v(o2[i], tws[kb + i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o2[i] = cmul2_v(o2[i], w[i], t[i]);              // W^k O[k]
+                for (int i = 0; i < 4; ++i) o2[i] = cmul2_v(o2[i], tws[kb + i], t[i]);       // W^k O[k]
                 float mp[4], mq[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -421,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restric
         // ---------------- mel phase: lane = frame, wave = run of bands ----------------
         // The staged log-mel row of frame f lives in the region of the wave that transformed (and will store) it:
         // that wave may then go on into its next transform, which rewrites only its own region, without a third barrier.
-        {
+        if (lane < kGroup) {
             const float* mag_row = s_mag + lane * kMagRow;
             float* out_row = s_x + (lane >> 2) * kTile + (lane & 3) * kOutRow;
             switch (wave) {
@@ -436,11 +423,7 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(const float* __restric
                 case 8: mel_wave<8>(mag_row, out_row, melw); break;
                 case 9: mel_wave<9>(mag_row, out_row, melw); break;
                 case 10: mel_wave<10>(mag_row, out_row, melw); break;
-                case 11: mel_wave<11>(mag_row, out_row, melw); break;
-                case 12: mel_wave<12>(mag_row, out_row, melw); break;
-                case 13: mel_wave<13>(mag_row, out_row, melw); break;
-                case 14: mel_wave<14>(mag_row, out_row, melw); break;
-                default: mel_wave<15>(mag_row, out_row, melw); break;
+                default: mel_wave<11>(mag_row, out_row, melw); break;
             }
         }
         FE_STAMP(18)
@@ -597,7 +580,7 @@ void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* l
                    const FeTables* tables, hipStream_t stream) {
     if (n_frames <= 0) return;
     const int64_t groups = (n_frames + fe::kGroup - 1) / fe::kGroup;
-    const int grid = (int)(groups < 256 ? groups : 256);      // one 149 KB, 16-wave workgroup per CU
+    const int grid = (int)(groups < 256 ? groups : 256);      // one 156 KB, 12-wave workgroup per CU
 #ifdef BD_FE_TRACE
     hipLaunchKernelGGL(fe::logmel_kernel, dim3(grid), dim3(fe::kThreads), 0, stream, pcm, (int)n_valid, (int)n_frames,
                        logmel, tables, (unsigned long long*)nullptr);
