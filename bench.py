@@ -587,6 +587,47 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
                                             "call (file read, H2D, device conversion, hot path, D2H, CSV) with two prebuilt "
                                             "engines (2 analyzer threads, 6 reader threads)", **legs}
 
+    # config 5 on one GPU: 48 kHz stereo 16-bit PCM resident in HBM -> channel mean + 3:1 polyphase resample in one kernel
+    # -> hot path in plain-f16 mode; and that kernel alone against its own HBM roofline
+    n48 = WINDOWS_PER_BATCH * hop * 3
+    st = torch.stack([synthetic_audio(device, n48, 31), synthetic_audio(device, n48, 32)], 1)
+    st = (st * 32768.0).round().clamp_(-32768, 32767).to(torch.int16).contiguous()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        mono = engines[0].resample(st, 48000, SAMPLE_RATE)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(k):
+        mono = engines[0].resample(st, 48000, SAMPLE_RATE)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / k
+    rs_bytes = st.numel() * 2 + mono.numel() * 4
+    out["resample_roofline"] = {"kernel": "resample_kernel<short> (48 kHz stereo s16 -> 16 kHz mono f32, 61 taps)", "bound": "hbm",
+                                "achieved": round(rs_bytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(rs_bytes / us / 1e3 / PEAK_HBM_GBS, 4), "avg_launch_us": round(us, 2),
+                                "bytes_per_launch": rs_bytes}
+    log(f"resample 48k stereo s16 -> 16k mono: {us:.1f} us per batch = {rs_bytes / us / 1e3:.0f} GB/s")
+    for e in engines:
+        e.set_pointwise_mode("f16")
+    for i in range(4):
+        engines[i % len(engines)].predict(engines[i % len(engines)].resample(st, 48000, SAMPLE_RATE), framehop_s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(k):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            e = engines[i % len(engines)]
+            e.predict(e.resample(st, 48000, SAMPLE_RATE), framehop_s)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    for e in engines:
+        e.set_pointwise_mode("f16x3")
+    out["config5_1gpu"] = {"value": round(k * WINDOWS_PER_BATCH / sec, 1), "unit": "windows/s",
+                           "what": "BASELINE config 5 on ONE GPU: 48 kHz stereo 16-bit PCM resident in HBM, downmix + 3:1 resample "
+                                   "in-kernel, plain-f16 MFMA mode (value_mode2_f16 has its max|dlogit|); never `value`"}
+    log(f"config 5 on one GPU (48 kHz stereo in, plain f16): {out['config5_1gpu']['value']:.0f} windows/s")
+    del st, mono
+
     # the other arithmetic modes of the 1x1 convolutions, same K batches of 1024 windows, reported beside `value`
     x = synthetic_audio(device, WINDOWS_PER_BATCH * hop, 99)
     ref = engines[0].predict(x, framehop_s).numpy().copy()

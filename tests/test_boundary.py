@@ -120,6 +120,17 @@ def test_plugin_halfhop_and_free_hop_on_gpu(dropin_cwd, weights_bundle):
     emb = e.embed(x).numpy()
     ref3 = O.embed(x, b["blob"], b["mel_keras3"], O.hop_samples(0.3), O.patch_step(0.3), np.float64)
     assert emb.shape == ref3.shape and np.abs(emb - ref3).max() < 1e-4
+    # hops whose sample count tf.cast rounds UP through float32 (5376, not int(5375.999...) = 5375): one sample per hop
+    # of padding decides the frame count of some chunk lengths: five hops after the first patch end on a multiple of 160
+    for prop, hop in ((0.35, 5376), (0.7, 10752), (0.95, 14592)):
+        e = load_embedder("yamnet", framehop_prop=prop, initialize=True)
+        n = 15600 + 4 * hop + 1
+        xs = O.synthetic_audio(n, seed=int(prop * 100))
+        assert O.hop_samples(prop) == hop
+        got = e.embed(xs).numpy()
+        ref = O.embed(xs, b["blob"], b["mel_keras3"], hop, O.patch_step(prop), np.float64)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-4, prop
+        assert O.num_frames(O.padded_length(n, hop)) != O.num_frames(O.padded_length(n, hop - 1)), "the case must tell the hops apart"
 
 
 @pytest.mark.gpu
