@@ -91,7 +91,7 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
                             hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
-                                    hipStream_t stream);
+                                    bool band_tiles, hipStream_t stream);
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);

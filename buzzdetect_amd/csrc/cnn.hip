@@ -19,6 +19,7 @@
 // keeps no mutable state besides the once-per-device dynamic-LDS attribute flags.
 #include "bd_internal.h"
 #include <mutex>
+#include <type_traits>
 
 namespace bd {
 
@@ -1640,6 +1641,475 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
                        L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
 }
 
+// --------------------------------------------------------------------------- pointwise with the weights in registers
+// LDS operations the compiler must not reorder or wait for on its own: the kernel below counts them (lgkmcnt).
+__device__ __forceinline__ unsigned pw_lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+template <int OFFSET>
+__device__ __forceinline__ f16x8 pw_lds_frag(unsigned addr) {
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET) : "memory");
+    return v;
+}
+__device__ __forceinline__ void pw_lds_store64(unsigned addr, f16x4 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f16x8 pw_landed(f16x8 v) {       // after the wait that covers the read: later uses stay behind it
+    asm volatile("" : "+v"(v));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void pw_lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int I, int E, typename F>
+__device__ __forceinline__ void static_for_pw(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for_pw<I + 1, E>(f);
+    }
+}
+// Issue order of a tile's LDS operations in pw_res_kernel: fragments of steps 0 and 1 (R reads each: hi, lo), then per
+// step q the fragments of step q + 2 and, at V evenly spaced steps, the R stores of one split item; pending(q) is how
+// many of them may still be in flight when the fragments of step q are needed.
+template <int K16, int V, int R>
+struct PwResSchedule {
+    static constexpr int split_at(int q) {                      // item index whose stores follow the reads of step q, or -1
+        for (int j = 0; j < V; ++j)
+            if (q == j * K16 / V + 1) return j;
+        return -1;
+    }
+    static constexpr int issued_at_step(int u) { return (u + 2 < K16 ? R : 0) + (split_at(u) >= 0 ? R : 0); }
+    static constexpr int pending(int q) {
+        int upto_wait = 2 * R;
+        for (int u = 0; u <= q; ++u) upto_wait += issued_at_step(u);
+        int through_read = q < 2 ? R * (q + 1) : 2 * R;
+        if (q >= 2) {
+            for (int u = 0; u < q - 2; ++u) through_read += issued_at_step(u);
+            through_read += R;
+        }
+        return upto_wait - through_read;
+    }
+};
+
+// The 1x1 convolutions of layers 5 (128 -> 256) and 7 (256 -> 512) have so few input channels that a wave's share of the
+// split-f16 weights - 32 output columns x K, hi and lo - fits its register file: 64 VGPRs at K = 128, 128 at K = 256.
+// A workgroup is 8 equal waves, wave w owning columns 32 w .. 32 w + 31 of a 256-column block; it is PERSISTENT
+// (one per CU), loads its weight fragments once and then walks 32-row tiles of the input: all waves split the
+// next tile into f16 hi + lo in LDS (rows requested three tiles ahead, straight into registers), every wave runs the
+// 3 K / 16 MFMAs of its column tile on the current one and writes bias + ReLU from the accumulators (a store
+// instruction covers two 128-byte row segments).  No weight traffic after the prologue, no pipeline fill per tile, one
+// barrier per tile.  Same products in the same order as pointwise_f16x3_kernel: bit-identical.
+template <int K16, bool PLAIN>
+__global__ __launch_bounds__(512, 2) void pw_res_kernel(const float* __restrict__ X, const _Float16* __restrict__ Wfhi,
+                                                         const _Float16* __restrict__ Wflo, const float* __restrict__ bias,
+                                                         float* __restrict__ C, int M, int N, int tiles_n,
+                                                         unsigned* __restrict__ range_flag) {
+    constexpr int K = 16 * K16;
+    constexpr int V = K16 / 4;                // float4 items per thread and tile: 32 rows x K / 4 over 512 threads
+    constexpr int RP = 2048 / K;              // rows the 512 threads cover per item
+    constexpr int ROWB = 2 * K;               // bytes of a row of one f16 half
+    constexpr int HALF = 32 * ROWB;
+    constexpr int R = PLAIN ? 1 : 2;          // LDS operations per fragment / per split item
+    using S = PwResSchedule<K16, V, R>;
+    // [2 buffers][hi, lo][32 rows][K] f16; the 16-byte chunks of a row are XOR-swizzled by the row number
+    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+
+    // column block h and row stream r of this workgroup: IDs b and b + 8 (same XCD, dispatched together) are the
+    // column blocks of the same row tiles, so the second read of a tile is an L2 hit
+    const unsigned b = blockIdx.x, tn = (unsigned)tiles_n;
+    const unsigned h = (b >> 3) % tn;
+    const int r = (int)((b / (8 * tn)) * 8 + (b & 7));
+    const int streams = (int)(gridDim.x / tn);
+    const int n_tiles = (M + 31) >> 5;
+    if (r >= n_tiles) return;
+    const int ct = (int)h * 8 + wave;         // column tile of this wave
+
+    // split items: thread -> (row r0 + RP j, channels 4 c4 ..) of a tile
+    const int r0 = tid / (K / 4), c4 = tid % (K / 4);
+    const float* const xcol = X + c4 * 4;
+    const unsigned lds0 = pw_lds_addr(smem_raw);
+    const unsigned st0 = lds0 + r0 * ROWB + (((c4 >> 1) ^ (r0 & 15)) << 4) + (c4 & 1) * 8;
+    // fragment (row frow, k 16 q + 8 fh ..): chunk (2 q + fh) ^ (frow & 15), i.e. fr0 ^ (q << 5) as a byte address
+    const unsigned fr0 = lds0 + frow * ROWB + ((fh ^ (frow & 15)) << 4);
+    v4f rx[2][V];
+    float rmax = 0.0f;
+#define BD_R_LOAD(DST, TILE)                                                                              \
+    _Pragma("unroll") for (int j = 0; j < V; ++j) {                                                       \
+        int row_ = 32 * (TILE) + r0 + RP * j;                                                             \
+        row_ = row_ < M ? row_ : M - 1;                                                                   \
+        DST[j] = *reinterpret_cast<const v4f*>(xcol + (size_t)row_ * K);                                  \
+    }
+#define BD_R_SPLIT1(SRC, J, BUF)                                                                          \
+    {                                                                                                     \
+        const v4f a4 = SRC[J];                                                                            \
+        rmax = range_of(rmax, a4);                                                                        \
+        f16x4 hi, lo;                                                                                     \
+        hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;   \
+        lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);                 \
+        lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);                 \
+        const unsigned st_ = (st0 ^ (((RP * (J)) & 15) << 4)) + RP * (J) * ROWB + (BUF) * 2 * HALF;       \
+        pw_lds_store64(st_, hi);                                                                          \
+        if constexpr (!PLAIN) pw_lds_store64(st_ + HALF, lo);                                             \
+    }
+    int t = r;
+    BD_R_LOAD(rx[0], t)
+    BD_R_LOAD(rx[1], t + streams)
+
+    f16x8 bh[K16], bl[K16];
+#pragma unroll
+    for (int q = 0; q < K16; ++q) {
+        const size_t frag = ((size_t)(ct * K16 + q) * 64 + lane) * 8;
+        bh[q] = *reinterpret_cast<const f16x8*>(Wfhi + frag);
+        if constexpr (!PLAIN) bl[q] = *reinterpret_cast<const f16x8*>(Wflo + frag);
+    }
+    const int col = ct * 32 + frow;
+    const float bcol = bias[col];
+
+#pragma unroll
+    for (int j = 0; j < V; ++j) BD_R_SPLIT1(rx[0], j, 0)
+    BD_R_LOAD(rx[0], t + 2 * streams)
+    // the weights have to be in their registers HERE: left to the compiler, their waits land between the MFMAs of the
+    // loop, where in steady state they wait for the previous tile's stores instead
+#pragma unroll
+    for (int q = 0; q < K16; ++q) {
+        bh[q] = pw_landed(bh[q]);
+        if constexpr (!PLAIN) bl[q] = pw_landed(bl[q]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    int i = 0;
+    // during tile i register set i & 1 holds the rows of tile i + 2 and the other set those of tile i + 1, which are
+    // split now and replaced by the request for tile i + 3; the loop is unrolled by two so that the sets are named statically
+    auto tile = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;                 // = i & 1: LDS buffer of this tile
+        constexpr int buf = p;
+        // A fragments through a ring of three k-steps, requested two steps ahead: the wave's LDS operations complete in
+        // order, so "the fragments of step q have landed" is a count of what was issued after them (PwResSchedule).
+        // The rows of the next tile are split into the other buffer in V pieces placed between the MFMAs (past the last
+        // tile they are clamped copies nobody reads); once the last piece is taken its registers take the request for
+        // the rows two tiles ahead.
+        const unsigned ab = fr0 + buf * 2 * HALF;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        f16x8 fa[3][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            fa[q][0] = pw_lds_frag<0>(ab ^ (q << 5));
+            if constexpr (!PLAIN) fa[q][1] = pw_lds_frag<HALF>(ab ^ (q << 5));
+        }
+        static_for_pw<0, K16>([&](auto qi) {
+            constexpr int q = decltype(qi)::value;
+            if constexpr (q + 2 < K16) {
+                fa[(q + 2) % 3][0] = pw_lds_frag<0>(ab ^ ((q + 2) << 5));
+                if constexpr (!PLAIN) fa[(q + 2) % 3][1] = pw_lds_frag<HALF>(ab ^ ((q + 2) << 5));
+            }
+            if constexpr (S::split_at(q) >= 0) {
+                constexpr int j = S::split_at(q) >= 0 ? S::split_at(q) : 0;
+                BD_R_SPLIT1(rx[p ^ 1], j, buf ^ 1)
+            }
+            pw_lds_wait<S::pending(q)>();
+            const f16x8 ah = pw_landed(fa[q % 3][0]);
+            if constexpr (!PLAIN) {
+                const f16x8 al = pw_landed(fa[q % 3][1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[q], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[q], acc, 0, 0, 0);
+        });
+        BD_R_LOAD(rx[p ^ 1], t + 3 * streams)      // set p ^ 1 held tile i + 1 (split above): now tile i + 3
+        const int row0 = 32 * t + 4 * fh;
+        float* const crow = C + (size_t)row0 * N + col;
+        if (32 * t + 32 <= M) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) crow[(size_t)((e & 3) + 8 * (e >> 2)) * N] = fmaxf(acc[e] + bcol, 0.0f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (row0 + (e & 3) + 8 * (e >> 2) < M) crow[(size_t)((e & 3) + 8 * (e >> 2)) * N] = fmaxf(acc[e] + bcol, 0.0f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ++i;
+        t += streams;
+    };
+    for (;;) {
+        tile(std::integral_constant<int, 0>{});
+        if (t >= n_tiles) break;
+        tile(std::integral_constant<int, 1>{});
+        if (t >= n_tiles) break;
+    }
+#undef BD_R_LOAD
+#undef BD_R_SPLIT1
+    range_report(rmax, range_flag);
+}
+
+template <int K16, bool PLAIN = false>
+void launch_pw_res(const float* X, const SepLayer& L, float* out, int M, hipStream_t stream) {
+    if constexpr (!PLAIN) {
+        if (L.pw_mode == 2) return launch_pw_res<K16, true>(X, L, out, M, stream);
+    }
+    constexpr int lds = 2 * 2 * 32 * 32 * K16;
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&pw_res_kernel<K16, PLAIN>, lds, lds_once);
+    const int tiles_n = L.cout / 256;
+    const int n_tiles = (M + 31) / 32;
+    // one workgroup per CU (256 on MI355X), in whole groups of 8 row streams x tiles_n column blocks
+    int streams = 256 / tiles_n;
+    if (streams > n_tiles) streams = (n_tiles + 7) / 8 * 8;
+    hipLaunchKernelGGL((pw_res_kernel<K16, PLAIN>), dim3((unsigned)(streams * tiles_n)), dim3(512), lds, stream, X,
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
+                       L.cout, tiles_n, L.range_flag);
+}
+
+// --------------------------------------------------------------------------- layer 4 (+ depthwise 5), a window per workgroup
+// Layer 4 is the widest map (24 x 16) with the fewest channels (128 -> 128): as 96-row tiles of the generic kernel it is
+// four short stages per tile behind a full pipeline fill, and the band tiles that carry depthwise 5 in their epilogue
+// compute every other row pair twice.  Here a workgroup owns a WINDOW and walks it top to bottom in twelve steps of two
+// map rows (= one 32-row MFMA tile, all 128 input channels at once):
+//   waves 0-3 (matrix side)  the split-f16 weights of their 32 output channels live in registers for the whole window
+//                            (64 VGPRs); per step they move two input rows global -> registers -> LDS ring (requested
+//                            four steps ahead), run the 24 MFMAs of the row tile the vector side finished in the previous
+//                            step and write bias + ReLU as f32 into a two-row buffer in LDS
+//   waves 4-7 (vector side)  a thread owns four channels (its 9 + 9 taps and two shifts stay in registers) and two map
+//                            columns: the 3x3 depthwise of the step's 2 x 2 outputs from a register window of 4 x 4
+//                            inputs that slides down the map (8 LDS reads per step), split into the A tile of the next
+//                            MFMA step; and depthwise 5 (stride 2) on the two-row buffer: one output row per step,
+//                            whose third input row arrives a step later - the partial sum waits in a register, the
+//                            order of the nine FMAs is unchanged
+// so nothing is computed twice, layer 4's own output never exists, and the input is read once.  One barrier per step,
+// 14 steps per window (two to fill and drain).  Arithmetic order per element equals depthwise_kernel /
+// pointwise_f16x3_kernel: bit-identical to the unfused path.
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 2) void l4_window_kernel(
+    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
+    const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out,
+    unsigned* __restrict__ range_flag) {
+    constexpr int H = 24, W = 16, C = 128, K16 = 8, STEPS = H / 2;
+    constexpr int COL_B = C * 4;                       // bytes of one map position, f32
+    constexpr int ROW_B = (W + 1) * COL_B;             // ring slot of a map row: 16 columns + a zero column
+    constexpr int RING0 = COL_B;                       // a zero column in front of slot 0 (column -1 of slot 0)
+    constexpr int A0 = RING0 + 8 * ROW_B;              // A tile [2 buffers][hi, lo][32 rows][128 f16], chunks XOR-swizzled
+    constexpr int A_HALF = 32 * 2 * C, A_BUF = 2 * A_HALF;
+    constexpr int Y0 = A0 + 2 * A_BUF;                 // layer-4 rows [2 buffers][2 rows x 17 columns][132 f32]
+    constexpr int Y_POS = (C + 4) * 4, Y_BUF = 2 * (W + 1) * Y_POS;
+    static_assert(A0 % 512 == 0, "fragment addresses are formed by XOR");
+    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+    char* const smem = smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t win = blockIdx.x;
+    const float* const xw = X + win * (size_t)(H * W * C);
+
+    // the zero columns: in front of the ring, column 16 of every ring slot and of every row of the two-row buffers
+    for (int i = tid; i < 9 * 32 + 4 * 33; i += 512) {
+        if (i < 9 * 32) {
+            const int z = i >> 5;
+            *reinterpret_cast<v4f*>(smem + (z == 0 ? 0 : RING0 + (z - 1) * ROW_B + W * COL_B) + (i & 31) * 16) = v4f{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const int j = i - 9 * 32, z = j / 33;      // z: buffer * 2 + row
+            *reinterpret_cast<v4f*>(smem + Y0 + (z >> 1) * Y_BUF + ((z & 1) * (W + 1) + W) * Y_POS + (j % 33) * 16) = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    float rmax = 0.0f;
+
+    if (wave < 4) {
+        // ================================================================= matrix side
+        const int frow = lane & 31, fh = lane >> 5;
+        const int c4 = tid & 31, col_lo = tid >> 5;    // slab items: 16-byte chunk c4 of columns col_lo and col_lo + 8
+        v4f rs[2][4];                                  // two row pairs in flight
+#define BD_L4_LOAD(DST, J)                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                         \
+        DST[u] = *reinterpret_cast<const v4f*>(xw + ((size_t)(2 * (J) + (u >> 1)) * W + col_lo + 8 * (u & 1)) * C + c4 * 4);
+#define BD_L4_STORE(SRC, J)                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                         \
+        *reinterpret_cast<v4f*>(smem + RING0 + ((2 * (J) + (u >> 1)) & 7) * ROW_B + (col_lo + 8 * (u & 1)) * COL_B + c4 * 16) = SRC[u];
+        BD_L4_LOAD(rs[0], 0)
+        BD_L4_LOAD(rs[1], 1)
+        f16x8 bh[K16], bl[K16];
+#pragma unroll
+        for (int q = 0; q < K16; ++q) {
+            const size_t frag = ((size_t)(wave * K16 + q) * 64 + lane) * 8;
+            bh[q] = *reinterpret_cast<const f16x8*>(Wfhi + frag);
+            if constexpr (!PLAIN) bl[q] = *reinterpret_cast<const f16x8*>(Wflo + frag);
+        }
+        const int ncol = 32 * wave + frow;
+        const float bcol = pw_b[ncol];
+        BD_L4_STORE(rs[0], 0)
+        BD_L4_STORE(rs[1], 1)
+        BD_L4_LOAD(rs[0], 2)
+        BD_L4_LOAD(rs[1], 3)
+#pragma unroll
+        for (int q = 0; q < K16; ++q) {                // the weights are in their registers before the loop (see pw_res_kernel)
+            bh[q] = pw_landed(bh[q]);
+            if constexpr (!PLAIN) bl[q] = pw_landed(bl[q]);
+        }
+        // fragment (row frow, k 16 q + 8 fh ..) sits in chunk (2 q + fh) ^ (frow & 15) of its row: fr0 ^ (q << 5)
+        const int fr0 = A0 + frow * 2 * C + ((fh ^ (frow & 15)) << 4);
+        __syncthreads();
+        auto step = [&](auto pc, int k) {
+            constexpr int p = decltype(pc)::value;     // k & 1
+            if (k + 2 < STEPS) { BD_L4_STORE(rs[p], k + 2) }
+            if (k + 4 < STEPS) { BD_L4_LOAD(rs[p], k + 4) }
+            if (k >= 1 && k <= STEPS) {
+                // row tile k - 1: A tile buffer (k - 1) & 1 = p ^ 1
+                const int ab = fr0 + (p ^ 1) * A_BUF;
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < K16; ++q) {
+                    const char* const ap = smem + (ab ^ (q << 5));
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(ap);
+                    if constexpr (!PLAIN) {
+                        const f16x8 al = *reinterpret_cast<const f16x8*>(ap + A_HALF);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[q], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[q], acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[q], acc, 0, 0, 0);
+                }
+                float* const yb = reinterpret_cast<float*>(smem + Y0 + (p ^ 1) * Y_BUF) + ncol;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = (e & 3) + 8 * (e >> 2) + 4 * fh;       // tile row: map row m >> 4, column m & 15
+                    yb[((m >> 4) * (W + 1) + (m & 15)) * (C + 4)] = fmaxf(acc[e] + bcol, 0.0f);
+                }
+            }
+            __syncthreads();
+        };
+        for (int k = 0; k < STEPS + 2; k += 2) {
+            step(std::integral_constant<int, 0>{}, k);
+            step(std::integral_constant<int, 1>{}, k + 1);
+        }
+#undef BD_L4_LOAD
+#undef BD_L4_STORE
+    } else {
+        // ================================================================= vector side
+        const int pt = tid - 256, c4 = pt & 31, pg = pt >> 5;            // channels 4 c4 .., map columns 2 pg, 2 pg + 1
+        v4f w4[9], w5[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            w4[t] = *reinterpret_cast<const v4f*>(dw_w + t * C + c4 * 4);
+            w5[t] = *reinterpret_cast<const v4f*>(ndw_w + t * C + c4 * 4);
+        }
+        const v4f b4 = *reinterpret_cast<const v4f*>(dw_b + c4 * 4);
+        const v4f b5 = *reinterpret_cast<const v4f*>(ndw_b + c4 * 4);
+        // input row r, columns 2 pg - 1 .. 2 pg + 2 (column -1 is the zero column in front, column 16 the one behind)
+        const char* const xin = smem + RING0 + (2 * pg - 1) * COL_B + c4 * 16;
+        // A tile: row m = 16 rr + 2 pg + cc, channels 4 c4 ..: 8 bytes of chunk c4 >> 1
+        int a_st[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int m = 16 * (o >> 1) + 2 * pg + (o & 1);
+            a_st[o] = A0 + m * 2 * C + (((c4 >> 1) ^ (m & 15)) << 4) + (c4 & 1) * 8;
+        }
+        const char* const yin = smem + Y0 + (2 * pg) * Y_POS + c4 * 16;
+        float* const orow = out + win * (size_t)(STEPS * (W / 2) * C) + (size_t)pg * C + c4 * 4;
+        v4f xr[4][4];                                  // input rows 2 k - 1 .. 2 k + 2 at [(2 p + i) & 3], four columns
+        v4f acc5 = b5;
+        __syncthreads();
+        auto step = [&](auto pc, int k) {
+            constexpr int p = decltype(pc)::value;     // k & 1
+            if (k < STEPS) {
+                // ---- depthwise 4 of map rows 2 k, 2 k + 1 -> A tile buffer p
+                if (k == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        xr[0][c] = v4f{0.f, 0.f, 0.f, 0.f};
+                        xr[1][c] = *reinterpret_cast<const v4f*>(xin + c * COL_B);
+                    }
+                }
+                {
+                    const char* const r2 = xin + ((2 * k + 1) & 7) * ROW_B;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xr[(2 * p + 2) & 3][c] = *reinterpret_cast<const v4f*>(r2 + c * COL_B);
+                }
+                if (k + 1 < STEPS) {
+                    const char* const r3 = xin + ((2 * k + 2) & 7) * ROW_B;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xr[(2 * p + 3) & 3][c] = *reinterpret_cast<const v4f*>(r3 + c * COL_B);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xr[(2 * p + 3) & 3][c] = v4f{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int rr = o >> 1, cc = o & 1;
+                    v4f a4 = b4;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            a4 = __builtin_elementwise_fma(xr[(2 * p + rr + kh) & 3][cc + kw], w4[kh * 3 + kw], a4);
+                    a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f);
+                    rmax = range_of(rmax, a4);
+                    f16x4 hi, lo;
+                    hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;
+                    lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);
+                    lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);
+                    *reinterpret_cast<f16x4*>(smem + a_st[o] + p * A_BUF) = hi;
+                    if constexpr (!PLAIN) *reinterpret_cast<f16x4*>(smem + a_st[o] + p * A_BUF + A_HALF) = lo;
+                }
+            }
+            if (k >= 2) {
+                // ---- depthwise 5 on layer-4 rows 2 s, 2 s + 1 (s = k - 2, buffer s & 1 = p): finishes output row s - 1
+                // (its kh = 2 row is 2 s), starts output row s (kh = 0, 1); row 11's third row is the zero padding
+                const int s = k - 2;
+                const char* const yb = yin + p * Y_BUF;
+                v4f y[2][3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) y[r][kw] = *reinterpret_cast<const v4f*>(yb + (r * (W + 1) + kw) * Y_POS);
+                if (s > 0) {
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[0][kw], w5[6 + kw], acc5);
+                    acc5.x = fmaxf(acc5.x, 0.0f); acc5.y = fmaxf(acc5.y, 0.0f); acc5.z = fmaxf(acc5.z, 0.0f); acc5.w = fmaxf(acc5.w, 0.0f);
+                    *reinterpret_cast<v4f*>(orow + (size_t)(s - 1) * (W / 2) * C) = acc5;
+                }
+                acc5 = b5;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[r][kw], w5[3 * r + kw], acc5);
+                if (s == STEPS - 1) {
+                    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(zero, w5[6 + kw], acc5);
+                    acc5.x = fmaxf(acc5.x, 0.0f); acc5.y = fmaxf(acc5.y, 0.0f); acc5.z = fmaxf(acc5.z, 0.0f); acc5.w = fmaxf(acc5.w, 0.0f);
+                    *reinterpret_cast<v4f*>(orow + (size_t)s * (W / 2) * C) = acc5;
+                }
+            }
+            __syncthreads();
+        };
+        for (int k = 0; k < STEPS + 2; k += 2) {
+            step(std::integral_constant<int, 0>{}, k);
+            step(std::integral_constant<int, 1>{}, k + 1);
+        }
+    }
+    range_report(rmax, range_flag);
+}
+
+template <bool PLAIN = false>
+void launch_l4_window(const float* X, const SepLayer& L, const SepLayer& next, float* out, int windows, hipStream_t stream) {
+    if constexpr (!PLAIN) {
+        if (L.pw_mode == 2) return launch_l4_window<true>(X, L, next, out, windows, stream);
+    }
+    constexpr int lds = 512 + 8 * 17 * 512 + 2 * 2 * 32 * 256 + 2 * 2 * 17 * 132 * 4;
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&l4_window_kernel<PLAIN>, lds, lds_once);
+    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)windows), dim3(512), lds, stream, X, L.dw_w, L.dw_b,
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, next.dw_w,
+                       next.dw_b, out, L.range_flag);
+}
+
 // --------------------------------------------------------------------------- fused stem + layer-3 depthwise
 // Layers 1-2 (conv 3x3 s2 -> depthwise 3x3 -> pointwise 32 -> 64) and the stride-2 depthwise of layer 3 (yamnet.py:77-80)
 // in one kernel, in the arithmetic order of conv1_kernel, depthwise_kernel and the split-f16 pointwise kernel: the layer-2 output
@@ -2123,6 +2593,12 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 // previous layer's epilogue.  Same products in the same order as pointwise_f16x3_kernel: bit-identical.
 bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream) {
     if (rows <= 0 || rows >= (1LL << 31) || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0) return false;
+    // layers 5 and 7: few enough input channels for the weights to live in registers (variant 10 keeps the tile kernel)
+    if (L.pw_variant16 != 10 && (L.cin == 128 || L.cin == 256) && L.cout <= 2048) {
+        if (L.cin == 128) launch_pw_res<8>(in, L, out, (int)rows, stream);
+        else launch_pw_res<16>(in, L, out, (int)rows, stream);
+        return true;
+    }
     // (96 x 128 tiles with two workgroups per CU measured the same: 33.1 vs 32.6 us on layer 7)
     launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
     return true;
@@ -2141,11 +2617,12 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
 // Fused depthwise+pointwise of layer L followed by the stride-2 depthwise of the NEXT layer; `out` receives
 // that depthwise's output [windows][H/2][W/2][L.cout].  Only for whole-window tiles (12x8 and 6x4 maps).
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
-                                    hipStream_t stream) {
+                                    bool band_tiles, hipStream_t stream) {
     const int P = L.h_out * L.w_out;
     if (L.stride == 1 && next.stride == 2 && windows > 0 && P == 384 && L.w_out == 16 && L.cin >= 128 && L.cin % 64 == 0 &&
-        L.cout == 128 && next.cin == 128) {       // layer 4 + depthwise 5: overlapping 6-row band tiles
-        launch_sep_ws<128, 128, 0, 3, 96, 1, 1, 1, 1>(in, L, out, (long long)windows * P, stream, &next);
+        L.cout == 128 && next.cin == 128) {       // layer 4 + depthwise 5
+        if (L.cin == 128 && !band_tiles) launch_l4_window(in, L, next, out, windows, stream);   // a window per workgroup
+        else launch_sep_ws<128, 128, 0, 3, 96, 1, 1, 1, 1>(in, L, out, (long long)windows * P, stream, &next);   // overlapping 6-row band tiles
         return true;
     }
     if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;

@@ -57,6 +57,7 @@ struct bd_engine {
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     int sep_variant = 0;
+    bool l4_band_tiles = false;       // layer 4 + depthwise 5 as overlapping band tiles of the generic kernel (bd_set_fusion separable = 2)
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
     const float* conv1_w = nullptr;   // [9][32]
@@ -740,7 +741,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
             if (e->fuse_sep && e->fuse_next_dw && e->pointwise_mode != 0 && e->sep_variant <= 1 && l + 1 < 13 &&
                 (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
-                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, e->sep[l + 1], stream)) {
+                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, e->sep[l + 1], e->l4_band_tiles, stream)) {
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 skip_dw_layer = l + 1;
                 last = buf_b;
@@ -865,14 +866,15 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
-    if (separable != 0 && separable != 1 && separable != 9 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 9 or 12");
+    if (separable != 0 && separable != 1 && separable != 2 && separable != 9 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 9 or 12");
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_stem4 = stem >= 3;
     h->fuse_sep = separable != 0;
-    h->fuse_next_dw = separable == 1;
-    h->sep_variant = separable > 1 ? separable : 0;
+    h->fuse_next_dw = separable == 1 || separable == 2;
+    h->l4_band_tiles = separable == 2;
+    h->sep_variant = separable > 2 ? separable : 0;
     return BD_OK;
 }
 

@@ -335,7 +335,7 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 9, 12):
+        for variant in (1, 2, 9, 12):            # 2: layer 4 as band tiles instead of a window per workgroup
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
@@ -361,7 +361,7 @@ def test_pointwise_on_wave_specialised_kernel_bit_identical_to_gemm_kernel(engin
             engine.set_pointwise_variant(layer, 1)
         plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in stages}
         plain_logits = engine.predict(x, 0.96).numpy()
-        for variant in (0, 10):                  # auto and explicit wave-specialised kernel
+        for variant in (0, 10, 11):              # auto, the wave-specialised tile kernel, resident weights where they fit
             for layer in range(5, 15):
                 engine.set_pointwise_variant(layer, variant)
             for st, ref in plain.items():
