@@ -79,12 +79,16 @@ def slot_plan(launches, pool_fused=True):
                 # (engine rule, cnn.hip launch_pointwise_ws: K >= 128 and N % 256 == 0 run on the wave-specialised
                 #  kernel with pass-through producers; the others on the plain split-f16 GEMM kernel)
                 fam = "sep_ws_kernel" if (c >= 128 and c % 64 == 0 and cout % 256 == 0) else "pointwise_f16x3_kernel"
+                if fam == "sep_ws_kernel" and c in (128, 256):
+                    fam = "pw_res_kernel"            # layers 5 and 7: the weights live in registers
                 plan[pw_slot] = (f"pw{layer}", fam, pw[0], pw[1])
                 if launches[dw_slot] == 0 and layer >= 5 and (pw_slot - 2) in plan:
                     nm, fam, nb, fl = plan[pw_slot - 2]
                     # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own
                     # (epilogue fusion exists only in the 8-wave kernel)
-                    plan[pw_slot - 2] = (nm + f"+dw{layer}", "sep_ws_kernel", nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
+                    # (layer 4 + depthwise 5 have their own kernel: a window per workgroup, no overlapping bands)
+                    plan[pw_slot - 2] = (nm + f"+dw{layer}", "l4_window_kernel" if layer == 5 else "sep_ws_kernel",
+                                         nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
                 # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
                 fam = "sep_w12_kernel" if (pool_fused and c == 512 and cout == 512) else "sep_ws_kernel"
@@ -497,7 +501,8 @@ def main() -> int:
                 f["flops"] += fl * windows_per_file * ev_steps
                 f["slots"].append(nm)
             total_ms = float(ms.sum())
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "stem3_kernel")
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "stem3_kernel", "pw_res_kernel",
+                         "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
             sec = d["ms"] * 1e-3

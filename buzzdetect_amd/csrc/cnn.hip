@@ -5,17 +5,21 @@
 //
 // Default path (14 launches per pass):
 //   stem3_kernel<true>   layers 1-3: conv 3x3 s2 -> dw 3x3 -> pw 32->64 -> dw 3x3 s2 -> pw 64->128, one kernel
+//   l4_window_kernel     layer 4 (depthwise + pointwise 128 -> 128 on the 24 x 16 map) + depthwise 5: persistent
+//                        workgroups that walk whole windows two map rows at a time, weights in registers
+//   pw_res_kernel        the 1x1 convolutions of layers 5 and 7 (K = 128 / 256): persistent, weights in registers
 //   sep_ws_kernel        fused depthwise + pointwise of a stride-1 layer, wave-specialised (4 producer + 4 MFMA
-//                        waves, slab ring by LDS-DMA, split-f16 MFMA); with PWO the plain 1x1 convolution of the
-//                        stride-2 layers; NDW = 1 / 3: next layer's stride-2 depthwise in the epilogue (3: layer 4,
-//                        overlapping band tiles); NDW = 2: global average pool in the epilogue (layer 14)
+//                        waves, slab ring by LDS-DMA, split-f16 MFMA); with PWO the plain 1x1 convolution of layer 13;
+//                        NDW = 1: next layer's stride-2 depthwise in the epilogue (layers 6, 12; NDW = 3: layer 4 as
+//                        overlapping band tiles, the test hook bd_set_fusion(.., 2)); NDW = 2: global average pool in
+//                        the epilogue (layer 14)
 //   sep_w12_kernel       the same for the 512 -> 512 layers 8-11 with 8 MFMA waves (depthwise once per row tile)
 //   pool_head_kernel<1>  Dense(1024 -> n_classes) on the pooled embeddings
 // Reference kernels, one per op (the fused ones are tested bit for bit against them; they are also the exact-f32 mode):
 //   conv1_kernel, depthwise_kernel, pointwise_f16x3_kernel (split-f16), pointwise_kernel (exact-f32 MFMA),
 //   stem3_kernel<false> (layers 1-2 + depthwise 3, for the stage taps), pool_head_kernel<6>
 // Workgroup -> tile mapping is XCD-aware (tile_of).  Clock traces of single workgroups exist only in a developer build
-// (-DBD_KERNEL_TRACE, then selected by BD_WS_TRACE / BD_STEM_TRACE); the shipped launch path reads no environment and
+// (-DBD_KERNEL_TRACE, then selected by BD_WS_TRACE / BD_STEM_TRACE / BD_L4_TRACE); the shipped launch path reads no environment and
 // keeps no mutable state besides the once-per-device dynamic-LDS attribute flags.
 #include "bd_internal.h"
 #include <mutex>
@@ -1868,30 +1872,41 @@ void launch_pw_res(const float* X, const SepLayer& L, float* out, int M, hipStre
                        L.cout, tiles_n, L.range_flag);
 }
 
-// --------------------------------------------------------------------------- layer 4 (+ depthwise 5), a window per workgroup
+// --------------------------------------------------------------------------- layer 4 (+ depthwise 5), whole windows per workgroup
 // Layer 4 is the widest map (24 x 16) with the fewest channels (128 -> 128): as 96-row tiles of the generic kernel it is
 // four short stages per tile behind a full pipeline fill, and the band tiles that carry depthwise 5 in their epilogue
-// compute every other row pair twice.  Here a workgroup owns a WINDOW and walks it top to bottom in twelve steps of two
-// map rows (= one 32-row MFMA tile, all 128 input channels at once):
-//   waves 0-3 (matrix side)  the split-f16 weights of their 32 output channels live in registers for the whole window
+// compute every other row pair twice.  Here a workgroup is persistent (one per CU), owns WINDOWS b, b + G, .. and walks
+// each top to bottom in twelve steps of two map rows (= one 32-row MFMA tile, all 128 input channels at once):
+//   waves 0-3 (matrix side)  the split-f16 weights of their 32 output channels live in registers for the whole launch
 //                            (64 VGPRs); per step they move two input rows global -> registers -> LDS ring (requested
 //                            four steps ahead), run the 24 MFMAs of the row tile the vector side finished in the previous
 //                            step and write bias + ReLU as f32 into a two-row buffer in LDS
-//   waves 4-7 (vector side)  a thread owns four channels (its 9 + 9 taps and two shifts stay in registers) and two map
-//                            columns: the 3x3 depthwise of the step's 2 x 2 outputs from a register window of 4 x 4
-//                            inputs that slides down the map (8 LDS reads per step), split into the A tile of the next
-//                            MFMA step; and depthwise 5 (stride 2) on the two-row buffer: one output row per step,
-//                            whose third input row arrives a step later - the partial sum waits in a register, the
-//                            order of the nine FMAs is unchanged
-// so nothing is computed twice, layer 4's own output never exists, and the input is read once.  One barrier per step,
-// 14 steps per window (two to fill and drain).  Arithmetic order per element equals depthwise_kernel /
-// pointwise_f16x3_kernel: bit-identical to the unfused path.
+//   waves 4-11 (vector side) a thread owns four channels (its taps and shift stay in registers) and one map column: the
+//                            3x3 depthwise of the step's two outputs from a register window of 4 x 3 inputs that slides
+//                            down the map (6 LDS reads per step), split into the A tile of the next MFMA step; the waves
+//                            of the even columns also run depthwise 5 (stride 2) on the two-row buffer: one output row
+//                            per step, whose third input row arrives a step later - the partial sum waits in a register,
+//                            the order of the nine FMAs is unchanged.  Two vector waves and one matrix wave per SIMD.
+// so nothing is computed twice, layer 4's own output never exists, and the input is read once.  The row tiles of a
+// workgroup's windows form ONE stream (tile T = 12 i + s): step K runs the depthwise of tile K, the MFMAs of tile K - 1
+// and depthwise 5 of tile K - 2, so the pipeline fills once per launch, not once per window; the top and bottom rows of
+// a window take zeros instead of their neighbours' rows.  One barrier per step.  Arithmetic order per element equals
+// depthwise_kernel / pointwise_f16x3_kernel: bit-identical to the unfused path.
 template <bool PLAIN>
-__global__ __launch_bounds__(512, 2) void l4_window_kernel(
+__global__ __launch_bounds__(768) void l4_window_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
-    const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out,
-    unsigned* __restrict__ range_flag) {
+    const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out, int windows,
+    unsigned* __restrict__ range_flag
+#ifdef BD_KERNEL_TRACE
+    , unsigned* __restrict__ dbg          // developer build: clock of block 0's waves 0 and 4 at every barrier (arrive, leave)
+#define BD_L4_TS(SIDE, SLOT)                                                                              \
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && k < 32)                                \
+        dbg[((SIDE) * 32 + k) * 2 + (SLOT)] = (unsigned)__builtin_readcyclecounter();
+#else
+#define BD_L4_TS(SIDE, SLOT)
+#endif
+) {
     constexpr int H = 24, W = 16, C = 128, K16 = 8, STEPS = H / 2;
     constexpr int COL_B = C * 4;                       // bytes of one map position, f32
     constexpr int ROW_B = (W + 1) * COL_B;             // ring slot of a map row: 16 columns + a zero column
@@ -1900,16 +1915,19 @@ __global__ __launch_bounds__(512, 2) void l4_window_kernel(
     constexpr int A_HALF = 32 * 2 * C, A_BUF = 2 * A_HALF;
     constexpr int Y0 = A0 + 2 * A_BUF;                 // layer-4 rows [2 buffers][2 rows x 17 columns][132 f32]
     constexpr int Y_POS = (C + 4) * 4, Y_BUF = 2 * (W + 1) * Y_POS;
+    constexpr size_t WIN_IN = (size_t)H * W * C, WIN_OUT = (size_t)STEPS * (W / 2) * C;
     static_assert(A0 % 512 == 0, "fragment addresses are formed by XOR");
+    static_assert((2 * STEPS) % 8 == 0 && STEPS % 2 == 0, "ring slots and buffer parities carry over from window to window");
     extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
     char* const smem = smem_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t win = blockIdx.x;
-    const float* const xw = X + win * (size_t)(H * W * C);
+    const int b = blockIdx.x, G = gridDim.x;
+    if (b >= windows) return;
+    const int NT = STEPS * ((windows - b + G - 1) / G);          // row tiles of this workgroup
 
     // the zero columns: in front of the ring, column 16 of every ring slot and of every row of the two-row buffers
-    for (int i = tid; i < 9 * 32 + 4 * 33; i += 512) {
+    for (int i = tid; i < 9 * 32 + 4 * 33; i += 768) {
         if (i < 9 * 32) {
             const int z = i >> 5;
             *reinterpret_cast<v4f*>(smem + (z == 0 ? 0 : RING0 + (z - 1) * ROW_B + W * COL_B) + (i & 31) * 16) = v4f{0.f, 0.f, 0.f, 0.f};
@@ -1924,13 +1942,20 @@ __global__ __launch_bounds__(512, 2) void l4_window_kernel(
         // ================================================================= matrix side
         const int frow = lane & 31, fh = lane >> 5;
         const int c4 = tid & 31, col_lo = tid >> 5;    // slab items: 16-byte chunk c4 of columns col_lo and col_lo + 8
+        const float* const xt = X + (size_t)b * WIN_IN + (size_t)col_lo * C + c4 * 4;
+        char* const ring_t = smem + RING0 + col_lo * COL_B + c4 * 16;
         v4f rs[2][4];                                  // two row pairs in flight
+        // row pair J of the stream = rows 2 j, 2 j + 1 of the workgroup's window i (J = 12 i + j), ring slots (2 J + row) & 7
 #define BD_L4_LOAD(DST, J)                                                                                \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                         \
-        DST[u] = *reinterpret_cast<const v4f*>(xw + ((size_t)(2 * (J) + (u >> 1)) * W + col_lo + 8 * (u & 1)) * C + c4 * 4);
+    {                                                                                                     \
+        const int i_ = (J) / STEPS, j_ = (J) - i_ * STEPS;                                                \
+        const float* const src_ = xt + (size_t)i_ * G * WIN_IN + (size_t)j_ * (2 * W * C);                \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                     \
+            DST[u] = *reinterpret_cast<const v4f*>(src_ + ((u >> 1) * W + 8 * (u & 1)) * C);              \
+    }
 #define BD_L4_STORE(SRC, J)                                                                               \
     _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                         \
-        *reinterpret_cast<v4f*>(smem + RING0 + ((2 * (J) + (u >> 1)) & 7) * ROW_B + (col_lo + 8 * (u & 1)) * COL_B + c4 * 16) = SRC[u];
+        *reinterpret_cast<v4f*>(ring_t + ((2 * (J) + (u >> 1)) & 7) * ROW_B + 8 * (u & 1) * COL_B) = SRC[u];
         BD_L4_LOAD(rs[0], 0)
         BD_L4_LOAD(rs[1], 1)
         f16x8 bh[K16], bl[K16];
@@ -1952,39 +1977,58 @@ __global__ __launch_bounds__(512, 2) void l4_window_kernel(
             if constexpr (!PLAIN) bl[q] = pw_landed(bl[q]);
         }
         // fragment (row frow, k 16 q + 8 fh ..) sits in chunk (2 q + fh) ^ (frow & 15) of its row: fr0 ^ (q << 5)
-        const int fr0 = A0 + frow * 2 * C + ((fh ^ (frow & 15)) << 4);
+        const unsigned fr0 = pw_lds_addr(smem) + (unsigned)(A0 + frow * 2 * C + ((fh ^ (frow & 15)) << 4));
+        // accumulator element e is tile row (e & 3) + 8 (e >> 2) + 4 fh: map row m >> 4, column m & 15
+        float* const yt = reinterpret_cast<float*>(smem + Y0) + 4 * fh * (C + 4) + ncol;
         __syncthreads();
         auto step = [&](auto pc, int k) {
             constexpr int p = decltype(pc)::value;     // k & 1
-            if (k + 2 < STEPS) { BD_L4_STORE(rs[p], k + 2) }
-            if (k + 4 < STEPS) { BD_L4_LOAD(rs[p], k + 4) }
-            if (k >= 1 && k <= STEPS) {
-                // row tile k - 1: A tile buffer (k - 1) & 1 = p ^ 1
-                const int ab = fr0 + (p ^ 1) * A_BUF;
-                f32x16 acc;
+            f32x16 acc;
+            if (k >= 1 && k <= NT) {
+                // row tile k - 1: A tile buffer (k - 1) & 1 = p ^ 1.  A fragments through a ring of three k-steps, requested
+                // two steps ahead, with counted waits (pw_res_kernel)
+                const unsigned ab = fr0 + (unsigned)((p ^ 1) * A_BUF);
+                using S = PwResSchedule<K16, 0, PLAIN ? 1 : 2>;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                f16x8 fa[3][2];
 #pragma unroll
-                for (int q = 0; q < K16; ++q) {
-                    const char* const ap = smem + (ab ^ (q << 5));
-                    const f16x8 ah = *reinterpret_cast<const f16x8*>(ap);
+                for (int q = 0; q < 2; ++q) {
+                    fa[q][0] = pw_lds_frag<0>(ab ^ (q << 5));
+                    if constexpr (!PLAIN) fa[q][1] = pw_lds_frag<A_HALF>(ab ^ (q << 5));
+                }
+                static_for_pw<0, K16>([&](auto qi) {
+                    constexpr int q = decltype(qi)::value;
+                    if constexpr (q + 2 < K16) {
+                        fa[(q + 2) % 3][0] = pw_lds_frag<0>(ab ^ ((q + 2) << 5));
+                        if constexpr (!PLAIN) fa[(q + 2) % 3][1] = pw_lds_frag<A_HALF>(ab ^ ((q + 2) << 5));
+                    }
+                    pw_lds_wait<S::pending(q)>();
+                    const f16x8 ah = pw_landed(fa[q % 3][0]);
                     if constexpr (!PLAIN) {
-                        const f16x8 al = *reinterpret_cast<const f16x8*>(ap + A_HALF);
+                        const f16x8 al = pw_landed(fa[q % 3][1]);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[q], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[q], acc, 0, 0, 0);
                     }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[q], acc, 0, 0, 0);
-                }
-                float* const yb = reinterpret_cast<float*>(smem + Y0 + (p ^ 1) * Y_BUF) + ncol;
+                });
+            }
+            // the input rows two steps ahead into the ring, a request for those four steps ahead (under the last MFMAs)
+            if (k + 2 < NT) { BD_L4_STORE(rs[p], k + 2) }
+            if (k + 4 < NT) BD_L4_LOAD(rs[p], k + 4)
+            if (k >= 1 && k <= NT) {
+                float* const yb = yt + (p ^ 1) * (Y_BUF / 4);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int m = (e & 3) + 8 * (e >> 2) + 4 * fh;       // tile row: map row m >> 4, column m & 15
+                    const int m = (e & 3) + 8 * (e >> 2);                // + 4 fh, in yt: rows 16 .. 31 are map row 1
                     yb[((m >> 4) * (W + 1) + (m & 15)) * (C + 4)] = fmaxf(acc[e] + bcol, 0.0f);
                 }
             }
+            BD_L4_TS(0, 0)
             __syncthreads();
+            BD_L4_TS(0, 1)
         };
-        for (int k = 0; k < STEPS + 2; k += 2) {
+        for (int k = 0; k < NT + 2; k += 2) {
             step(std::integral_constant<int, 0>{}, k);
             step(std::integral_constant<int, 1>{}, k + 1);
         }
@@ -1992,36 +2036,49 @@ __global__ __launch_bounds__(512, 2) void l4_window_kernel(
 #undef BD_L4_STORE
     } else {
         // ================================================================= vector side
-        const int pt = tid - 256, c4 = pt & 31, pg = pt >> 5;            // channels 4 c4 .., map columns 2 pg, 2 pg + 1
-        v4f w4[9], w5[9];
+        // wave v = 0..7, half-wave hi: channels 4 c4 .. of ONE map column - the even columns in waves 0-3 (which also run
+        // depthwise 5: output column = column / 2), the odd ones in waves 4-7, so every SIMD carries one wave of each kind
+        const int v = wave - 4, c4 = lane & 31;
+        const int col = v < 4 ? 2 * (2 * v + (lane >> 5)) : 2 * (2 * (v - 4) + (lane >> 5)) + 1;
+        v4f w4[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            w4[t] = *reinterpret_cast<const v4f*>(dw_w + t * C + c4 * 4);
-            w5[t] = *reinterpret_cast<const v4f*>(ndw_w + t * C + c4 * 4);
-        }
+        for (int t = 0; t < 9; ++t) w4[t] = *reinterpret_cast<const v4f*>(dw_w + t * C + c4 * 4);
         const v4f b4 = *reinterpret_cast<const v4f*>(dw_b + c4 * 4);
-        const v4f b5 = *reinterpret_cast<const v4f*>(ndw_b + c4 * 4);
-        // input row r, columns 2 pg - 1 .. 2 pg + 2 (column -1 is the zero column in front, column 16 the one behind)
-        const char* const xin = smem + RING0 + (2 * pg - 1) * COL_B + c4 * 16;
-        // A tile: row m = 16 rr + 2 pg + cc, channels 4 c4 ..: 8 bytes of chunk c4 >> 1
-        int a_st[4];
+        v4f w5[9], b5 = {0.f, 0.f, 0.f, 0.f};
+        if (v < 4) {
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int m = 16 * (o >> 1) + 2 * pg + (o & 1);
-            a_st[o] = A0 + m * 2 * C + (((c4 >> 1) ^ (m & 15)) << 4) + (c4 & 1) * 8;
+            for (int t = 0; t < 9; ++t) w5[t] = *reinterpret_cast<const v4f*>(ndw_w + t * C + c4 * 4);
+            b5 = *reinterpret_cast<const v4f*>(ndw_b + c4 * 4);
         }
-        const char* const yin = smem + Y0 + (2 * pg) * Y_POS + c4 * 16;
-        float* const orow = out + win * (size_t)(STEPS * (W / 2) * C) + (size_t)pg * C + c4 * 4;
-        v4f xr[4][4];                                  // input rows 2 k - 1 .. 2 k + 2 at [(2 p + i) & 3], four columns
+        // input row r, columns col - 1 .. col + 1 (column -1 is the zero column in front, column 16 the one behind)
+        const char* const xin = smem + RING0 + (col - 1) * COL_B + c4 * 16;
+        // A tile: row m = 16 rr + col, channels 4 c4 ..: 8 bytes of chunk c4 >> 1
+        int a_st[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int m = 16 * rr + col;
+            a_st[rr] = A0 + m * 2 * C + (((c4 >> 1) ^ (m & 15)) << 4) + (c4 & 1) * 8;
+        }
+        const char* const yin = smem + Y0 + col * Y_POS + c4 * 16;
+        float* const ot = out + (size_t)b * WIN_OUT + (size_t)(col >> 1) * C + c4 * 4;
+        v4f xr[4][3];                                  // input rows 2 s - 1 .. 2 s + 2 at [(2 p + i) & 3], three columns
         v4f acc5 = b5;
+        int s4 = 0;                                    // row tile within its window: of the depthwise-4 stream ..
+        int s5 = 0, i5 = 0;                            // .. and of the depthwise-5 stream (two steps behind), with its window
         __syncthreads();
         auto step = [&](auto pc, int k) {
             constexpr int p = decltype(pc)::value;     // k & 1
-            if (k < STEPS) {
-                // ---- depthwise 4 of map rows 2 k, 2 k + 1 -> A tile buffer p
-                if (k == 0) {
+            const char* const yb = yin + p * Y_BUF;
+            v4f y[3];                                  // depthwise 5: the first of its two rows is requested before depthwise 4
+            if (v < 4 && k >= 2) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                for (int kw = 0; kw < 3; ++kw) y[kw] = *reinterpret_cast<const v4f*>(yb + kw * Y_POS);
+            }
+            if (k < NT) {
+                // ---- depthwise 4 of map rows 2 s4, 2 s4 + 1 -> A tile buffer p (ring slots continue across windows)
+                if (s4 == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
                         xr[0][c] = v4f{0.f, 0.f, 0.f, 0.f};
                         xr[1][c] = *reinterpret_cast<const v4f*>(xin + c * COL_B);
                     }
@@ -2029,72 +2086,76 @@ __global__ __launch_bounds__(512, 2) void l4_window_kernel(
                 {
                     const char* const r2 = xin + ((2 * k + 1) & 7) * ROW_B;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xr[(2 * p + 2) & 3][c] = *reinterpret_cast<const v4f*>(r2 + c * COL_B);
+                    for (int c = 0; c < 3; ++c) xr[(2 * p + 2) & 3][c] = *reinterpret_cast<const v4f*>(r2 + c * COL_B);
                 }
-                if (k + 1 < STEPS) {
+                if (s4 + 1 < STEPS) {
                     const char* const r3 = xin + ((2 * k + 2) & 7) * ROW_B;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xr[(2 * p + 3) & 3][c] = *reinterpret_cast<const v4f*>(r3 + c * COL_B);
+                    for (int c = 0; c < 3; ++c) xr[(2 * p + 3) & 3][c] = *reinterpret_cast<const v4f*>(r3 + c * COL_B);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xr[(2 * p + 3) & 3][c] = v4f{0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < 3; ++c) xr[(2 * p + 3) & 3][c] = v4f{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const int rr = o >> 1, cc = o & 1;
+                for (int rr = 0; rr < 2; ++rr) {
                     v4f a4 = b4;
 #pragma unroll
                     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw)
-                            a4 = __builtin_elementwise_fma(xr[(2 * p + rr + kh) & 3][cc + kw], w4[kh * 3 + kw], a4);
+                            a4 = __builtin_elementwise_fma(xr[(2 * p + rr + kh) & 3][kw], w4[kh * 3 + kw], a4);
                     a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f);
                     rmax = range_of(rmax, a4);
                     f16x4 hi, lo;
                     hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;
                     lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);
                     lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);
-                    *reinterpret_cast<f16x4*>(smem + a_st[o] + p * A_BUF) = hi;
-                    if constexpr (!PLAIN) *reinterpret_cast<f16x4*>(smem + a_st[o] + p * A_BUF + A_HALF) = lo;
+                    *reinterpret_cast<f16x4*>(smem + a_st[rr] + p * A_BUF) = hi;
+                    if constexpr (!PLAIN) *reinterpret_cast<f16x4*>(smem + a_st[rr] + p * A_BUF + A_HALF) = lo;
                 }
+                s4 = s4 + 1 == STEPS ? 0 : s4 + 1;
             }
-            if (k >= 2) {
-                // ---- depthwise 5 on layer-4 rows 2 s, 2 s + 1 (s = k - 2, buffer s & 1 = p): finishes output row s - 1
-                // (its kh = 2 row is 2 s), starts output row s (kh = 0, 1); row 11's third row is the zero padding
-                const int s = k - 2;
-                const char* const yb = yin + p * Y_BUF;
-                v4f y[2][3];
+            BD_L4_TS(2, 0)
+            if (v < 4 && k >= 2) {
+                // ---- depthwise 5 on layer-4 rows 2 s5, 2 s5 + 1 (tile k - 2, buffer p): finishes output row s5 - 1 (its
+                // kh = 2 row is 2 s5), starts output row s5 (kh = 0, 1); row 11's third row is the zero padding
+                float* const orow = ot + (size_t)i5 * G * WIN_OUT;
+                if (s5 > 0) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) y[r][kw] = *reinterpret_cast<const v4f*>(yb + (r * (W + 1) + kw) * Y_POS);
-                if (s > 0) {
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[0][kw], w5[6 + kw], acc5);
+                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[kw], w5[6 + kw], acc5);
                     acc5.x = fmaxf(acc5.x, 0.0f); acc5.y = fmaxf(acc5.y, 0.0f); acc5.z = fmaxf(acc5.z, 0.0f); acc5.w = fmaxf(acc5.w, 0.0f);
-                    *reinterpret_cast<v4f*>(orow + (size_t)(s - 1) * (W / 2) * C) = acc5;
+                    *reinterpret_cast<v4f*>(orow + (size_t)(s5 - 1) * (W / 2) * C) = acc5;
                 }
                 acc5 = b5;
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[kw], w5[kw], acc5);
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[r][kw], w5[3 * r + kw], acc5);
-                if (s == STEPS - 1) {
+                for (int kw = 0; kw < 3; ++kw) y[kw] = *reinterpret_cast<const v4f*>(yb + ((W + 1) + kw) * Y_POS);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[kw], w5[3 + kw], acc5);
+                if (s5 == STEPS - 1) {
                     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(zero, w5[6 + kw], acc5);
                     acc5.x = fmaxf(acc5.x, 0.0f); acc5.y = fmaxf(acc5.y, 0.0f); acc5.z = fmaxf(acc5.z, 0.0f); acc5.w = fmaxf(acc5.w, 0.0f);
-                    *reinterpret_cast<v4f*>(orow + (size_t)s * (W / 2) * C) = acc5;
+                    *reinterpret_cast<v4f*>(orow + (size_t)s5 * (W / 2) * C) = acc5;
+                    s5 = 0;
+                    ++i5;
+                } else {
+                    ++s5;
                 }
             }
+            BD_L4_TS(1, 0)
             __syncthreads();
+            BD_L4_TS(1, 1)
         };
-        for (int k = 0; k < STEPS + 2; k += 2) {
+        for (int k = 0; k < NT + 2; k += 2) {
             step(std::integral_constant<int, 0>{}, k);
             step(std::integral_constant<int, 1>{}, k + 1);
         }
     }
     range_report(rmax, range_flag);
+#undef BD_L4_TS
 }
 
 template <bool PLAIN = false>
@@ -2105,9 +2166,37 @@ void launch_l4_window(const float* X, const SepLayer& L, const SepLayer& next, f
     constexpr int lds = 512 + 8 * 17 * 512 + 2 * 2 * 32 * 256 + 2 * 2 * 17 * 132 * 4;
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&l4_window_kernel<PLAIN>, lds, lds_once);
-    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)windows), dim3(512), lds, stream, X, L.dw_w, L.dw_b,
+    const int grid = windows < 256 ? windows : 256;           // one persistent workgroup per CU
+#ifdef BD_KERNEL_TRACE      // developer build only: per-barrier clock trace of workgroup 0 (matrix wave 0, vector wave 4)
+    static unsigned* dbg = nullptr;
+    static int shots = 0;
+    if (!dbg) (void)hipMalloc(&dbg, 1024);
+    (void)hipMemsetAsync(dbg, 0, 1024, stream);
+    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
                        static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, next.dw_w,
-                       next.dw_b, out, L.range_flag);
+                       next.dw_b, out, windows, L.range_flag, dbg);
+    if (getenv("BD_L4_TRACE") && ++shots == 6) {
+        (void)hipStreamSynchronize(stream);
+        unsigned h[256];
+        (void)hipMemcpy(h, dbg, 1024, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[trace] layer-4 kernel, vector side: cycles of the depthwise-4 part of each step:");
+        for (int k = 1; k < 32 && h[(64 + k) * 2]; ++k) fprintf(stderr, " %u", h[(64 + k) * 2] - h[(32 + k - 1) * 2 + 1]);
+        fprintf(stderr, "\n");
+        for (int side = 0; side < 2; ++side) {
+            fprintf(stderr, "[trace] layer-4 kernel, %s side: work / wait cycles per step:", side ? "vector" : "matrix");
+            for (int k = 1; k < 32; ++k) {
+                const unsigned arr = h[(side * 32 + k) * 2], lv = h[(side * 32 + k) * 2 + 1], prev = h[(side * 32 + k - 1) * 2 + 1];
+                if (!arr && !lv) break;
+                fprintf(stderr, " %u/%u", arr - prev, lv - arr);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#else
+    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, next.dw_w,
+                       next.dw_b, out, windows, L.range_flag);
+#endif
 }
 
 // --------------------------------------------------------------------------- fused stem + layer-3 depthwise
