@@ -1681,7 +1681,7 @@ template <int K16, int V, int R>
 struct PwResSchedule {
     static constexpr int split_at(int q) {                      // item index whose stores follow the reads of step q, or -1
         for (int j = 0; j < V; ++j)
-            if (q == j * K16 / V + 1) return j;
+            if (q == j * K16 / (V > 0 ? V : 1) + 1) return j;
         return -1;
     }
     static constexpr int issued_at_step(int u) { return (u + 2 < K16 ? R : 0) + (split_at(u) >= 0 ? R : 0); }
