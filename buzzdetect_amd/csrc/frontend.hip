@@ -552,6 +552,117 @@ __global__ __launch_bounds__(kRsThreads) void resample_kernel(const T* __restric
     }
 }
 
+// decimate_kernel: integer decimation (up = 1: 48 kHz -> 16 kHz, 32 kHz -> 16 kHz), the ratios field recorders produce.
+// With up = 1 every output walks the same 20 * DOWN + 1 taps, so the filter is wave-uniform: it sits in scalar register
+// pairs and an FMA reads only its samples.  A thread owns kDecR = 7 CONSECUTIVE outputs as three pairs and a single: the
+// outputs r and r + 1 of a pair meet tap t at samples i and i + DOWN, which one ds_read2_b32 delivers as a register pair, so
+// a pair advances by one v_pk_fma_f32 (tap broadcast through op_sel) per tap and a sample pair serves all three pairs of
+// its step: 76 LDS reads, 183 packed and 61 plain FMAs for seven outputs (the general kernel: 2 LDS reads per FMA).  Every
+// output still accumulates its taps in increasing input index; samples outside the signal are staged as zeros.  Outputs
+// leave through LDS as whole rows.
+constexpr int kDecR = 7;                                      // outputs per thread; 7 * DOWN is odd for DOWN = 3: conflict-free reads
+
+template <int SEL>      // acc += x * tap[SEL] in both halves; tap = a pair of wave-uniform filter taps in scalar registers
+__device__ __forceinline__ fe::v2f dec_pk_fma(fe::v2f x, fe::v2f tap, fe::v2f acc) {
+    if constexpr (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(tap));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(tap));
+    return acc;
+}
+
+template <int O0, int O1>      // (x[O0], x[O1]) as one register pair; the caller waits (lgkmcnt) before using it
+__device__ __forceinline__ fe::v2f dec_read2(unsigned addr) {
+    fe::v2f v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+    return v;
+}
+__device__ __forceinline__ fe::v2f dec_landed(fe::v2f v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ fe::v2f dec_tap_landed(fe::v2f v) {     // the taps are in their scalar registers from here on
+    asm volatile("" : "+s"(v));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void dec_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int DOWN>
+__global__ __launch_bounds__(256) void decimate_kernel(const T* __restrict__ in, long long n_in, int channels,
+                                                       const float* __restrict__ h, float* __restrict__ out, long long n_out) {
+    using fe::v2f;
+    constexpr int HALF = 10 * DOWN, TAPS = 2 * HALF + 1;
+    constexpr int TILE = 256 * kDecR;                          // outputs per workgroup
+    constexpr int NX = (kDecR - 1) * DOWN + TAPS;              // samples under a thread's kDecR filters
+    constexpr int SPAN = (TILE - 1) * DOWN + TAPS;             // samples under the tile's filters
+    constexpr int NP = (TAPS + 1) / 2;                         // tap pairs
+    static_assert(kDecR == 7 && SPAN >= TILE, "three pairs and a single; the outputs are staged in the sample buffer");
+    __shared__ __attribute__((aligned(16))) float s_x[SPAN + 1];
+    const int tid = threadIdx.x;
+    const long long j0 = (long long)blockIdx.x * TILE;
+    const long long i0 = j0 * DOWN - HALF;                     // input index of s_x[0]
+    for (int k = tid; k < SPAN; k += 256) {
+        const long long i = i0 + k;
+        s_x[k] = i >= 0 && i < n_in ? mono_at(in, i, channels) : 0.0f;
+    }
+    v2f tap[NP];                                               // (h[2 m], h[2 m + 1]); the filter has an odd number of taps
+    fe::static_for<0, NP>([&](auto mi) {
+        constexpr int m = decltype(mi)::value;
+        if constexpr (2 * m + 1 < TAPS) tap[m] = *reinterpret_cast<const v2f*>(h + 2 * m);
+        else tap[m] = v2f{h[2 * m], 0.0f};
+    });
+    __syncthreads();
+    fe::static_for<0, NP>([&](auto mi) { tap[decltype(mi)::value] = dec_tap_landed(tap[decltype(mi)::value]); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned xs = fe::lds_addr(s_x + tid * (kDecR * DOWN));
+    v2f acc[3] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    float acc6 = 0.0f;
+    // sample pairs (x[i], x[i + DOWN]) through a ring, requested DEPTH steps ahead; LDS operations complete in order, so
+    // "pair i has landed" is "at most DEPTH (or what is left) requests are in flight"
+    constexpr int STEPS = NX - DOWN, DEPTH = 6, RING = 8;
+    v2f ring[RING];
+    fe::static_for<0, DEPTH>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        ring[i % RING] = dec_read2<i, i + DOWN>(xs);
+    });
+    fe::static_for<0, STEPS>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        if constexpr (i + DEPTH < STEPS) ring[(i + DEPTH) % RING] = dec_read2<i + DEPTH, i + DEPTH + DOWN>(xs);
+        dec_wait<(STEPS - 1 - i < DEPTH ? STEPS - 1 - i : DEPTH)>();
+        const v2f xp = dec_landed(ring[i % RING]);
+        fe::static_for<0, 3>([&](auto pi) {
+            constexpr int p = decltype(pi)::value;
+            constexpr int d = i - 2 * p * DOWN;                // position under the filter of the pair's first output
+            if constexpr (d >= 0 && d <= 2 * HALF) {
+                constexpr int t = 2 * HALF - d;
+                acc[p] = dec_pk_fma<t & 1>(xp, tap[t >> 1], acc[p]);
+            }
+        });
+        // output 6 meets sample i + DOWN at this step: the upper half of the pair
+        constexpr int d6 = i + DOWN - 6 * DOWN;
+        if constexpr (d6 >= 0 && d6 <= 2 * HALF) {
+            constexpr int t = 2 * HALF - d6;
+            acc6 = fmaf(xp.y, (t & 1) ? tap[t >> 1].y : tap[t >> 1].x, acc6);
+        }
+    });
+    __syncthreads();                                           // everyone is done reading the samples
+    s_x[tid * kDecR + 0] = acc[0].x;
+    s_x[tid * kDecR + 1] = acc[0].y;
+    s_x[tid * kDecR + 2] = acc[1].x;
+    s_x[tid * kDecR + 3] = acc[1].y;
+    s_x[tid * kDecR + 4] = acc[2].x;
+    s_x[tid * kDecR + 5] = acc[2].y;
+    s_x[tid * kDecR + 6] = acc6;
+    __syncthreads();
+    if (j0 + TILE <= n_out) {
+        for (int k = tid; k < TILE / 4; k += 256)
+            reinterpret_cast<float4*>(out + j0)[k] = reinterpret_cast<const float4*>(s_x)[k];
+    } else {
+        for (int k = tid; k < TILE && j0 + k < n_out; k += 256) out[j0 + k] = s_x[k];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void convert_kernel(const T* __restrict__ in, long long n, int channels,
                                                       float* __restrict__ out) {
@@ -581,6 +692,16 @@ void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const
         const int grid = (int)(blocks < 65536 ? blocks : 65536);
         if (s16) hipLaunchKernelGGL(convert_kernel<short>, dim3(grid), dim3(256), 0, stream, static_cast<const short*>(in), (long long)n_out, channels, out);
         else hipLaunchKernelGGL(convert_kernel<float>, dim3(grid), dim3(256), 0, stream, static_cast<const float*>(in), (long long)n_out, channels, out);
+        return;
+    }
+    if (up == 1 && (down == 2 || down == 3) && half == 10 * down) {      // integer decimation: filter in scalar registers
+        const int64_t grid = (n_out + 256 * kDecR - 1) / (256 * kDecR);
+#define BD_DEC_LAUNCH(T, D)                                                                                     \
+    hipLaunchKernelGGL((decimate_kernel<T, D>), dim3((unsigned)grid), dim3(256), 0, stream, static_cast<const T*>(in), \
+                       (long long)n_in, channels, taps, out, (long long)n_out)
+        if (s16) { if (down == 2) BD_DEC_LAUNCH(short, 2); else BD_DEC_LAUNCH(short, 3); }
+        else { if (down == 2) BD_DEC_LAUNCH(float, 2); else BD_DEC_LAUNCH(float, 3); }
+#undef BD_DEC_LAUNCH
         return;
     }
     // outputs per workgroup: as many as the staged input span allows (span = tile * down / up + 2 * half / up + 2)
