@@ -170,6 +170,9 @@ BD_API int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, in
    variant 0 = the library's choice for the shape; 1..8 = explicit tile shapes (see cnn.hip). */
 BD_API int bd_debug_pointwise(const float* a_dev, const float* wt_dev, const float* bias_dev, float* c_dev,
                               int64_t m, int32_t n, int32_t k, int32_t variant, void* stream);
+/* Per layer, in the f16 modes: 0 = the library's choice (layers 5 and 7: weights in registers, pw_res_kernel; 128+ input
+   channels otherwise: the wave-specialised tile kernel; else the plain split-f16 GEMM); 1..9 = tile shapes of the plain GEMM;
+   10 = always the wave-specialised tile kernel; 11 = as 0.  All variants give the same bits. */
 BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int32_t variant);
 
 /* Arithmetic of the 1x1 convolutions: 0 = v_mfma_f32_32x32x2_f32 (exact f32 products),
