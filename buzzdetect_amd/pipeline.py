@@ -302,6 +302,7 @@ class Pipeline:
             engine = self.make_engine()                    # per-thread engine, initialised in-thread
             device = engine.device
             stream = torch.cuda.Stream(device)
+            copy_stream = torch.cuda.Stream(device)         # host-to-device copies of batch n + 1 run under the kernels of batch n
             n_classes = engine.n_classes
             log.info(f"analyzer {aid}: processing on GPU")
             t_wait = time.perf_counter()
@@ -355,12 +356,20 @@ class Pipeline:
                     batch.append(nxt)
                     windows += engine.num_windows(self._out_samples(nxt), self.hop, self.step)
                 held = [t.slot for t in batch]
-                with torch.cuda.stream(stream):
-                    pcms = []
+                with torch.cuda.stream(copy_stream):
+                    devs = []
                     for t in batch:
                         pinned = self.ring.buffer(t.slot)[: t.nbytes]
                         dev = torch.empty(t.nbytes, dtype=torch.uint8, device=device)
                         dev.copy_(pinned, non_blocking=True)
+                        devs.append(dev)
+                    copied = torch.cuda.Event()
+                    copied.record(copy_stream)
+                with torch.cuda.stream(stream):
+                    stream.wait_event(copied)
+                    pcms = []
+                    for t, dev in zip(batch, devs):
+                        dev.record_stream(stream)          # allocated on the copy stream, read by this one
                         view = dev.view(torch.int16 if t.s16 else torch.float32).view(t.frames, t.channels)
                         if t.s16 or t.rate != 16000 or t.channels > 1:
                             pcms.append(engine.resample(view, t.rate, 16000))     # also s16 -> f32 and the channel mean
