@@ -337,6 +337,22 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
+// a = hi + lo with hi = f16(a) and lo = f16(a - hi), four values at a time.  The difference and its rounding are ONE
+// v_fma_mixlo/mixhi_f16 per value (fma(hi as f16, -1, a as f32), rounded to f16 into one half of the result): six
+// instructions per four values where the convert / subtract / convert form took eleven.  a - hi is exact in f32, so the
+// bits are those of (_Float16)(a - (float)hi).
+__device__ __forceinline__ void split_f16(float x, float y, float z, float w, f16x4& hi, f16x4& lo) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 h0 = {(_Float16)x, (_Float16)y}, h1 = {(_Float16)z, (_Float16)w};
+    f16x2 l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "v"(x));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(h0), "v"(y));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h1), "v"(z));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "v"(w));
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+}
+
 // Epilogue of a 32x32 tile accumulated TRANSPOSED (weights fed as the MFMA "A" operand, activations as
 // "B"): lane l then owns output row m = l & 31 and, per register quad g, the four consecutive channels
 // n = 8 g + 4 (l >> 5) + 0..3 - one 16-byte store per quad instead of four 4-byte ones.  Products and
@@ -432,9 +448,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
             const float4 v = ra[i];                                                                      \
             rmax = range_of(rmax, v);                                                                    \
             f16x4 hi, lo;                                                                                \
-            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;  \
-            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);              \
-            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);              \
+            split_f16(v.x, v.y, v.z, v.w, hi, lo);                                                      \
             *reinterpret_cast<f16x4*>(Ah + (BUF) * A_BYTES + a_st[i]) = hi;                              \
             *reinterpret_cast<f16x4*>(Al + (BUF) * A_BYTES + a_st[i]) = lo;                              \
         }                                                                                                \
@@ -782,9 +796,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
             rmax = range_of(rmax, a4);                                                                    \
             f16x4 hi, lo;                                                                                 \
-            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
-            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
-            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
+            split_f16(a4.x, a4.y, a4.z, a4.w, hi, lo);                                                  \
             *reinterpret_cast<f16x4*>(Ah + ((AB) * KS + u) * A_BYTES + a_st[i]) = hi;                     \
             *reinterpret_cast<f16x4*>(Al + ((AB) * KS + u) * A_BYTES + a_st[i]) = lo;                     \
         }                                                                                                 \
@@ -837,9 +849,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
         const v4f a4 = *reinterpret_cast<const v4f*>(Xs + (XB) * XS_FLOATS + (lrow + 32 * i) * 32 + lc4 * 4); \
         rmax = range_of(rmax, a4);                                                                        \
         f16x4 hi, lo;                                                                                     \
-        hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;   \
-        lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);                 \
-        lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);                 \
+        split_f16(a4.x, a4.y, a4.z, a4.w, hi, lo);                                                      \
         const int st_ = swz64(lrow + 32 * i, lc4 >> 1) + (lc4 & 1) * 8;                                   \
         *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + st_) = hi;                                        \
         *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + st_) = lo;                                        \
@@ -1444,9 +1454,7 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(
             a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
             rmax = range_of(rmax, a4);                                                                    \
             f16x4 hi, lo;                                                                                 \
-            hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w; \
-            lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);             \
-            lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);             \
+            split_f16(a4.x, a4.y, a4.z, a4.w, hi, lo);                                                  \
             *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
             *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
         }                                                                                                 \
@@ -1753,9 +1761,7 @@ __global__ __launch_bounds__(512, 2) void pw_res_kernel(const float* __restrict_
         const v4f a4 = SRC[J];                                                                            \
         rmax = range_of(rmax, a4);                                                                        \
         f16x4 hi, lo;                                                                                     \
-        hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;   \
-        lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);                 \
-        lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);                 \
+        split_f16(a4.x, a4.y, a4.z, a4.w, hi, lo);                                                      \
         const unsigned st_ = (st0 ^ (((RP * (J)) & 15) << 4)) + RP * (J) * ROWB + (BUF) * 2 * HALF;       \
         pw_lds_store64(st_, hi);                                                                          \
         if constexpr (!PLAIN) pw_lds_store64(st_ + HALF, lo);                                             \
@@ -2107,9 +2113,7 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
                     a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f);
                     rmax = range_of(rmax, a4);
                     f16x4 hi, lo;
-                    hi[0] = (_Float16)a4.x; hi[1] = (_Float16)a4.y; hi[2] = (_Float16)a4.z; hi[3] = (_Float16)a4.w;
-                    lo[0] = (_Float16)(a4.x - (float)hi[0]); lo[1] = (_Float16)(a4.y - (float)hi[1]);
-                    lo[2] = (_Float16)(a4.z - (float)hi[2]); lo[3] = (_Float16)(a4.w - (float)hi[3]);
+                    split_f16(a4.x, a4.y, a4.z, a4.w, hi, lo);
                     *reinterpret_cast<f16x4*>(smem + a_st[rr] + p * A_BUF) = hi;
                     if constexpr (!PLAIN) *reinterpret_cast<f16x4*>(smem + a_st[rr] + p * A_BUF + A_HALF) = lo;
                 }
@@ -2375,9 +2379,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             acc.w = fmaxf(acc.w, 0.0f);
             rmax = range_of(rmax, acc);
             f16x4 hi, lo;
-            hi[0] = (_Float16)acc.x; hi[1] = (_Float16)acc.y; hi[2] = (_Float16)acc.z; hi[3] = (_Float16)acc.w;
-            lo[0] = (_Float16)(acc.x - (float)hi[0]); lo[1] = (_Float16)(acc.y - (float)hi[1]);
-            lo[2] = (_Float16)(acc.z - (float)hi[2]); lo[3] = (_Float16)(acc.w - (float)hi[3]);
+            split_f16(acc.x, acc.y, acc.z, acc.w, hi, lo);
             const int off = swz64(r * 32 + col, c4 >> 1) + (c4 & 1) * 8;
             *reinterpret_cast<f16x4*>(s_ah + off) = hi;
             *reinterpret_cast<f16x4*>(s_al + off) = lo;
@@ -2476,9 +2478,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         if constexpr (PW3) {
             rmax = range_of(rmax, acc);
             f16x4 hi, lo;
-            hi[0] = (_Float16)acc.x; hi[1] = (_Float16)acc.y; hi[2] = (_Float16)acc.z; hi[3] = (_Float16)acc.w;
-            lo[0] = (_Float16)(acc.x - (float)hi[0]); lo[1] = (_Float16)(acc.y - (float)hi[1]);
-            lo[2] = (_Float16)(acc.z - (float)hi[2]); lo[3] = (_Float16)(acc.w - (float)hi[3]);
+            split_f16(acc.x, acc.y, acc.z, acc.w, hi, lo);
             const int c = c16 & 7;
             const int off = (c16 >> 3) * 32 * 64 + swz64(o * 16 + ow, c >> 1) + (c & 1) * 8;
             *reinterpret_cast<f16x4*>(smem + OFF_A3H + off) = hi;
