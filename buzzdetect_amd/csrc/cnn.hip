@@ -2275,15 +2275,6 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
 
-    f16x8 w3h[4], w3l[4];                       // PW3: this lane's layer-3 weight fragments, k16 steps 0..3
-    if constexpr (PW3) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t f = ((size_t)(wave * 4 + q) * 64 + lane) * 8;
-            w3h[q] = *reinterpret_cast<const f16x8*>(W3fhi + f);
-            w3l[q] = *reinterpret_cast<const f16x8*>(W3flo + f);
-        }
-    }
 
     // every phase's weights are requested one phase ahead (a phase used to begin with a global round trip)
     const int c4 = tid & 7;
@@ -2329,20 +2320,21 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             const int c1r = r0 - 1 + i;                                                                   \
             _Pragma("unroll") for (int kh = 1; kh < 3; ++kh)                                              \
                 _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[kh][kw] = s_lm[2 * i + kh][2 * col + kw]; \
-            v4f acc = bias;                                                                               \
-            _Pragma("unroll") for (int kh = 0; kh < 3; ++kh) {                                            \
-                if (CHECK && 2 * c1r + kh >= BD_PATCH_FRAMES) continue;                                   \
-                _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                        \
-                    const float v = lm[kh][kw];                                                           \
-                    acc = __builtin_elementwise_fma(v4f{v, v, v, v}, wt[kh * 3 + kw], acc);               \
+            v4f r4 = {0.f, 0.f, 0.f, 0.f};                                                                \
+            if (__builtin_amdgcn_readfirstlane((int)(c1r >= 0 && c1r < 48))) {   /* else: the depthwise's zero padding; */ \
+                v4f acc = bias;                                                  /* the row is the same for the whole workgroup */ \
+                _Pragma("unroll") for (int kh = 0; kh < 3; ++kh) {                                        \
+                    if (CHECK && 2 * c1r + kh >= BD_PATCH_FRAMES) continue;                               \
+                    _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                    \
+                        const float v = lm[kh][kw];                                                       \
+                        acc = __builtin_elementwise_fma(v4f{v, v, v, v}, wt[kh * 3 + kw], acc);           \
+                    }                                                                                     \
                 }                                                                                         \
+                r4.x = fmaxf(acc.x, 0.0f);                                                                \
+                r4.y = fmaxf(acc.y, 0.0f);                                                                \
+                r4.z = fmaxf(acc.z, 0.0f);                                                                \
+                r4.w = fmaxf(acc.w, 0.0f);                                                                \
             }                                                                                             \
-            const bool valid = c1r >= 0 && c1r < 48;                                                      \
-            v4f r4;                                                                                       \
-            r4.x = valid ? fmaxf(acc.x, 0.0f) : 0.0f;                                                     \
-            r4.y = valid ? fmaxf(acc.y, 0.0f) : 0.0f;                                                     \
-            r4.z = valid ? fmaxf(acc.z, 0.0f) : 0.0f;                                                     \
-            r4.w = valid ? fmaxf(acc.w, 0.0f) : 0.0f;                                                     \
             *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = r4;                                      \
             _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[0][kw] = lm[2][kw];                       \
         }                                                                                                 \
@@ -2438,16 +2430,21 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         for (int i = 0; i < 3; ++i) {
             const int rt = wr + 2 * i;
             if (rt < R2) {
-                const bool live = r0 + rt < 48;
+                const bool live = __builtin_amdgcn_readfirstlane((int)(r0 + rt < 48)) != 0;    // the same for the whole wave
                 float* prow = P + (rt * 32 + frow) * PW + wc * 32 + 4 * fh;
+                if (live) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    v4f v;
-                    v.x = live ? fmaxf(acc2[i][4 * g + 0] + b4[g].x, 0.0f) : 0.0f;
-                    v.y = live ? fmaxf(acc2[i][4 * g + 1] + b4[g].y, 0.0f) : 0.0f;
-                    v.z = live ? fmaxf(acc2[i][4 * g + 2] + b4[g].z, 0.0f) : 0.0f;
-                    v.w = live ? fmaxf(acc2[i][4 * g + 3] + b4[g].w, 0.0f) : 0.0f;
-                    *reinterpret_cast<v4f*>(prow + 8 * g) = v;
+                    for (int g = 0; g < 4; ++g) {
+                        v4f v;
+                        v.x = fmaxf(acc2[i][4 * g + 0] + b4[g].x, 0.0f);
+                        v.y = fmaxf(acc2[i][4 * g + 1] + b4[g].y, 0.0f);
+                        v.z = fmaxf(acc2[i][4 * g + 2] + b4[g].z, 0.0f);
+                        v.w = fmaxf(acc2[i][4 * g + 3] + b4[g].w, 0.0f);
+                        *reinterpret_cast<v4f*>(prow + 8 * g) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<v4f*>(prow + 8 * g) = v4f{0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
@@ -2455,6 +2452,15 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
     __syncthreads();
     ST_TS(6)
 
+    f16x8 w3h[4], w3l[4];                       // PW3: this lane's layer-3 weight fragments, k16 steps 0..3 (in flight during F)
+    if constexpr (PW3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t f = ((size_t)(wave * 4 + q) * 64 + lane) * 8;
+            w3h[q] = *reinterpret_cast<const f16x8*>(W3fhi + f);
+            w3l[q] = *reinterpret_cast<const f16x8*>(W3flo + f);
+        }
+    }
     // ---- F: depthwise 3, stride 2: out[o][ow][c] from P rows 2o + kh, columns 2ow + kw (column 32 = padding) ----
     float* dst = out + (((size_t)win * 24 + 2 * ob) * 16) * 64;
 #pragma unroll
