@@ -2315,14 +2315,14 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
 #define BD_STEM3_CONV1(CHECK)                                                                             \
     {                                                                                                     \
         float lm[3][3];                                                                                   \
+        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};                                                           \
         _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[0][kw] = s_lm[0][2 * col + kw];               \
         _Pragma("unroll") for (int i = 0; i < C1R; ++i) {                                                 \
             const int c1r = r0 - 1 + i;                                                                   \
             _Pragma("unroll") for (int kh = 1; kh < 3; ++kh)                                              \
                 _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[kh][kw] = s_lm[2 * i + kh][2 * col + kw]; \
-            v4f r4 = {0.f, 0.f, 0.f, 0.f};                                                                \
-            if (__builtin_amdgcn_readfirstlane((int)(c1r >= 0 && c1r < 48))) {   /* else: the depthwise's zero padding; */ \
-                v4f acc = bias;                                                  /* the row is the same for the whole workgroup */ \
+            if (c1r >= 0 && c1r < 48) {          /* the row is the same for the whole workgroup: a scalar branch */ \
+                v4f acc = bias;                                                                           \
                 _Pragma("unroll") for (int kh = 0; kh < 3; ++kh) {                                        \
                     if (CHECK && 2 * c1r + kh >= BD_PATCH_FRAMES) continue;                               \
                     _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                    \
@@ -2330,12 +2330,15 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                         acc = __builtin_elementwise_fma(v4f{v, v, v, v}, wt[kh * 3 + kw], acc);           \
                     }                                                                                     \
                 }                                                                                         \
+                v4f r4;                                                                                   \
                 r4.x = fmaxf(acc.x, 0.0f);                                                                \
                 r4.y = fmaxf(acc.y, 0.0f);                                                                \
                 r4.z = fmaxf(acc.z, 0.0f);                                                                \
                 r4.w = fmaxf(acc.w, 0.0f);                                                                \
+                *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = r4;                                  \
+            } else {                             /* a row above or below the map: the depthwise's zero padding */ \
+                *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = zero4;                               \
             }                                                                                             \
-            *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = r4;                                      \
             _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[0][kw] = lm[2][kw];                       \
         }                                                                                                 \
     }
@@ -2392,11 +2395,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
     // ---- D: GEMM.  Waves (wr, wc): column tile wc; row tiles wr, wr + 2 and, for wr == 0, 4 ----
     const int wr = wave >> 1, wc = wave & 1;
     const int frow = lane & 31, fh = lane >> 5;
-    f32x16 acc2[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
+    f32x16 acc2[3];                             // (the first MFMA of a tile takes a literal zero: no 48 moves to clear them)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -2406,13 +2405,18 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                 const int off = swz64(rt * 32 + frow, 2 * s2 + fh);
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(s_ah + off);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(s_al + off);
+                f32x16 c = acc2[i];
+                if (s2 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+                }
                 // operands swapped: the accumulators hold the TRANSPOSED tile (lane = position, four consecutive
                 // channels per register quad), so phase E writes 16 bytes at a time; same products, same k order
                 if constexpr (!PLAIN) {
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], al, acc2[i], 0, 0, 0);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbl[s2], ah, acc2[i], 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], al, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbl[s2], ah, c, 0, 0, 0);
                 }
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], ah, acc2[i], 0, 0, 0);
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh[s2], ah, c, 0, 0, 0);
             }
         }
     }
