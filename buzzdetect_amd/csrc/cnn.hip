@@ -1356,12 +1356,13 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
 // Twelve waves per CU leave 168 registers per wave, 96 of them accumulators: A fragments are read per 32-row tile
 // and weight fragments per 16-deep k step, double-buffered.  The output goes out in three 32-row chunks.
 // Plain instantiation only (no epilogue fusion); same products in the same order: bit-identical.
-template <int XPMAX, bool TRACE, bool PLAIN>
-__global__ __launch_bounds__(768, 3) void sep_w12_kernel(
+template <int XPMAX, bool TRACE, bool PLAIN, int KT = 0>   // KT: the number of input channels when known at compile time
+__global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8-11: tap and slab strides become immediates)
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
-    float* __restrict__ Cout, long long M, int K, int H, int W, unsigned* __restrict__ dbg,
+    float* __restrict__ Cout, long long M, int K_, int H, int W, unsigned* __restrict__ dbg,
     unsigned* __restrict__ range_flag) {
+    const int K = KT > 0 ? KT : K_;
     float rmax = 0.0f;
     constexpr int BM = 96, BN = 512, N = 512;
     constexpr int TM = 3, TN = 2, LA = 3;
@@ -1648,6 +1649,14 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
         return;
     }
 #endif
+    if (L.cin == 512) {
+        static std::once_flag lds_once512[kMaxDevices];
+        allow_dynamic_lds(&sep_w12_kernel<XPMAX, false, PLAIN, 512>, (int)lds_max, lds_once512);
+        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN, 512>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w,
+                           L.dw_b, static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out,
+                           M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
+        return;
+    }
     hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
                        static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
                        L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
