@@ -2476,18 +2476,27 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
     }
     // ---- F: depthwise 3, stride 2: out[o][ow][c] from P rows 2o + kh, columns 2ow + kw (column 32 = padding) ----
     float* dst = out + (((size_t)win * 24 + 2 * ob) * 16) * 64;
+    // 512 tasks: o (2) x ow (16) x c4 (16); a thread keeps its column and channels in both (o = it).  Every tap is an
+    // immediate offset from one pointer; the tap right of column 31 (ow = 15, kw = 2) is read like the others and replaced by
+    // the zero padding afterwards (what it reads - the next row, or for the last one the bytes after P - is never used)
+    const int c16 = tid & 15, ow = (tid >> 4) & 15;
+    const float* const pcol = P + (2 * ow) * PW + c16 * 4;
+    const bool right_edge = ow == 15;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int id = tid + 256 * it;              // 512 tasks: o (2) x ow (16) x c4 (16)
-        const int c16 = id & 15, ow = (id >> 4) & 15, o = id >> 8;
+        const int o = it;
         v4f acc = d3bias;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int pc = 2 * ow + kw;
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (pc < 32) v = *reinterpret_cast<const v4f*>(P + ((2 * o + kh) * 32 + pc) * PW + c16 * 4);
+                v4f v = *reinterpret_cast<const v4f*>(pcol + ((2 * o + kh) * 32 + kw) * PW);
+                if (kw == 2) {
+                    v.x = right_edge ? 0.0f : v.x;
+                    v.y = right_edge ? 0.0f : v.y;
+                    v.z = right_edge ? 0.0f : v.z;
+                    v.w = right_edge ? 0.0f : v.w;
+                }
                 acc = __builtin_elementwise_fma(v, d3wt[kh * 3 + kw], acc);
             }
         acc.x = fmaxf(acc.x, 0.0f);
