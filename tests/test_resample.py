@@ -80,3 +80,22 @@ def test_device_resample_from_s16(engine, rate_in, channels):
     assert np.array_equal(got, via_f32)
     want = RO.resample(q.astype(np.float32) / 32768.0, rate_in)
     assert np.abs(got - want).max() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate_in", [48000, 32000])
+@pytest.mark.parametrize("n", [1, 2, 7, 59, 61, 62, 200, 5373, 5374, 5377, 1792 * 3, 1792 * 3 * 2 + 1, 100003])
+def test_integer_decimation_edges(engine, rate_in, n):
+    """decimate_kernel (filter in scalar registers, seven outputs per thread): inputs shorter than the filter, lengths around
+    a workgroup's 1792 outputs, a long odd length; mono float and stereo 16-bit."""
+    rng = np.random.default_rng(n + rate_in)
+    x = (0.5 * rng.standard_normal(n)).astype(np.float32)
+    got = engine.resample(x, rate_in).cpu().numpy()
+    want = RO.resample(x, rate_in)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6
+    q = rng.integers(-32768, 32767, size=(n, 2), dtype=np.int16)
+    got16 = engine.resample(q, rate_in).cpu().numpy()
+    want16 = RO.resample(q.astype(np.float32) / 32768.0, rate_in)
+    assert got16.shape == want16.shape
+    assert np.abs(got16 - want16).max() < 2e-6
