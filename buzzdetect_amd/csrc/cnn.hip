@@ -1801,7 +1801,6 @@ __global__ __launch_bounds__(512, 2) void pw_res_kernel(const float* __restrict_
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    int i = 0;
     // during tile i register set i & 1 holds the rows of tile i + 2 and the other set those of tile i + 1, which are
     // split now and replaced by the request for tile i + 3; the loop is unrolled by two so that the sets are named statically
     auto tile = [&](auto pc) {
@@ -1855,7 +1854,6 @@ __global__ __launch_bounds__(512, 2) void pw_res_kernel(const float* __restrict_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        ++i;
         t += streams;
     };
     for (;;) {
