@@ -2328,7 +2328,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             const int c1r = r0 - 1 + i;                                                                   \
             _Pragma("unroll") for (int kh = 1; kh < 3; ++kh)                                              \
                 _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[kh][kw] = s_lm[2 * i + kh][2 * col + kw]; \
-            if (c1r >= 0 && c1r < 48) {          /* the row is the same for the whole workgroup: a scalar branch */ \
+            if (!(CHECK) || (c1r >= 0 && c1r < 48)) {   /* the same for the whole workgroup: a scalar branch */ \
                 v4f acc = bias;                                                                           \
                 _Pragma("unroll") for (int kh = 0; kh < 3; ++kh) {                                        \
                     if (CHECK && 2 * c1r + kh >= BD_PATCH_FRAMES) continue;                               \
@@ -2349,7 +2349,8 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) lm[0][kw] = lm[2][kw];                       \
         }                                                                                                 \
     }
-        if (2 * (r0 + C1R - 2) + 2 >= BD_PATCH_FRAMES) BD_STEM3_CONV1(true)
+        // (only the first and the last row block of a window have conv1 rows outside the map or tap rows outside the patch)
+        if (ob == 0 || 2 * (r0 + C1R - 2) + 2 >= BD_PATCH_FRAMES || r0 + C1R - 2 >= 48) BD_STEM3_CONV1(true)
         else BD_STEM3_CONV1(false)
 #undef BD_STEM3_CONV1
     }
@@ -2446,11 +2447,12 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                 if (live) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        v4f v;
-                        v.x = fmaxf(acc2[i][4 * g + 0] + b4[g].x, 0.0f);
-                        v.y = fmaxf(acc2[i][4 * g + 1] + b4[g].y, 0.0f);
-                        v.z = fmaxf(acc2[i][4 * g + 2] + b4[g].z, 0.0f);
-                        v.w = fmaxf(acc2[i][4 * g + 3] + b4[g].w, 0.0f);
+                        // (vector add: two v_pk_add_f32 instead of four v_add_f32; the same IEEE additions)
+                        v4f v = v4f{acc2[i][4 * g + 0], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]} + b4[g];
+                        v.x = fmaxf(v.x, 0.0f);
+                        v.y = fmaxf(v.y, 0.0f);
+                        v.z = fmaxf(v.z, 0.0f);
+                        v.w = fmaxf(v.w, 0.0f);
                         *reinterpret_cast<v4f*>(prow + 8 * g) = v;
                     }
                 } else {
@@ -2539,7 +2541,9 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 4 * fh + (r & 3) + 8 * (r >> 2);
-            dst3[(size_t)m * 128 + n] = fmaxf(acc3[r] + b, 0.0f);
+            typedef float v2f_ __attribute__((ext_vector_type(2)));
+            const v2f_ t2 = v2f_{acc3[r & ~1], acc3[r | 1]} + v2f_{b, b};        // one v_pk_add_f32 per two outputs
+            dst3[(size_t)m * 128 + n] = fmaxf((r & 1) ? t2.y : t2.x, 0.0f);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ST_TS(9)
