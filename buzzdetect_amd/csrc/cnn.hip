@@ -1212,13 +1212,20 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
         const int P = H * W;
         const int OW2 = W / 2, P2 = (H / 2) * OW2;
         const int tasks = (BM / P) * P2 * C4;
+        // 512 is a multiple of the C4 channel quads of a row: a thread keeps its quad in all its tasks, so the nine taps and
+        // the shift are read once; the four channels of a tap are two packed FMAs (the same IEEE fmas as four plain ones)
+        static_assert(512 % C4 == 0, "a thread's tasks share their channels");
+        const int c4 = tid % C4;
+        v4f wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ndw_w + (size_t)t * N + n0 + c4 * 4);
+        const v4f shift = *reinterpret_cast<const v4f*>(ndw_b + n0 + c4 * 4);
         for (int id = tid; id < tasks; id += 512) {
-            const int c4 = id % C4;
             const int q = id / C4;
             const int pos2 = q % P2, wl = q / P2;
             if (m0 + (long long)wl * P >= M) continue;
             const int oh = pos2 / OW2, ow = pos2 % OW2;
-            v4f acc = *reinterpret_cast<const v4f*>(ndw_b + n0 + c4 * 4);
+            v4f acc = shift;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -1226,11 +1233,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
                     const int ih = 2 * oh + kh, iw = 2 * ow + kw;
                     v4f v = {0.f, 0.f, 0.f, 0.f};
                     if (ih < H && iw < W) v = *reinterpret_cast<const v4f*>(Ct + (wl * P + ih * W + iw) * (BN + 4) + c4 * 4);
-                    const v4f w = *reinterpret_cast<const v4f*>(ndw_w + (size_t)(kh * 3 + kw) * N + n0 + c4 * 4);
-                    acc.x = fmaf(v.x, w.x, acc.x);
-                    acc.y = fmaf(v.y, w.y, acc.y);
-                    acc.z = fmaf(v.z, w.z, acc.z);
-                    acc.w = fmaf(v.w, w.w, acc.w);
+                    acc = __builtin_elementwise_fma(v, wt[kh * 3 + kw], acc);
                 }
             acc.x = fmaxf(acc.x, 0.0f);
             acc.y = fmaxf(acc.y, 0.0f);
