@@ -479,8 +479,9 @@ __device__ __forceinline__ float pcm_to_float(float v) { return v; }
 __device__ __forceinline__ float pcm_to_float(short v) { return (float)v * (1.0f / 32768.0f); }   // as libsndfile's float read
 
 __device__ __forceinline__ float stereo_mean(const short* __restrict__ in, long long i) {      // one 4-byte load per frame
-    const short2 v = reinterpret_cast<const short2*>(in)[i];
-    return (pcm_to_float(v.x) + pcm_to_float(v.y)) * 0.5f;
+    // (l / 32768 + r / 32768) / 2 with every step exact in float32 = (l + r) / 65536: one conversion instead of two
+    const int v = reinterpret_cast<const int*>(in)[i];
+    return (float)(((v << 16) >> 16) + (v >> 16)) * (1.0f / 65536.0f);
 }
 __device__ __forceinline__ float stereo_mean(const float* __restrict__ in, long long i) {      // one 8-byte load per frame
     const float2 v = reinterpret_cast<const float2*>(in)[i];
