@@ -520,3 +520,22 @@ def test_plain_f16_mode_is_close_but_outside_the_gate(engine, weights_bundle):
     assert 1e-5 < err_plain < 5e-2, err_plain
     assert np.array_equal(engine.predict(x, 0.96).numpy(), default)
     assert engine.overflow_reruns == 0
+
+
+@pytest.mark.parametrize("windows", [2, 255, 256, 257, 513, 1025])
+def test_persistent_kernels_at_grid_boundaries(engine, windows):
+    """The layer-4 window kernel and the resident-weights pointwise kernel are persistent (256 workgroups): fewer windows than
+    workgroups, exactly as many, one more, two and a bit per workgroup, and a second CNN pass (1025 = 1024 + 1) must all give
+    the bits of the one-kernel-per-op path."""
+    x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=4000 + windows)
+    engine.set_pointwise_mode("f16x3")
+    try:
+        engine.set_fusion(False, False)
+        ref = engine.predict(x, 0.96).numpy()
+        ref_emb = engine.embed(x, 0.96).numpy()
+        engine.set_fusion(True, True)
+        assert ref.shape == (windows, 13)
+        assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)
+        assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb)
+    finally:
+        engine.set_fusion(True, True)
