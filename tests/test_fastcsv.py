@@ -65,3 +65,17 @@ def test_sorted_partial_file_survives_the_finalize_round_trip(tmp_path):
     b.finalize_sorted()
     assert open(a.path_complete, "rb").read() == open(b.path_complete, "rb").read()
     assert not (tmp_path / "a_buzzpart.csv").exists() and not (tmp_path / "b_buzzpart.csv").exists()
+
+
+def test_lookup_tables_entry_by_entry():
+    """The tables are built with array arithmetic; every entry against Python's own formatting."""
+    ints, frac = fastcsv._tables()
+    for i in list(range(0, 1200)) + list(range(9990, 10011)) + list(range(99900, 100000)) + [12345, 54321, 70007]:
+        assert bytes(ints[i]).rstrip(b"\0") == str(i).encode(), i
+    for f in range(100):
+        assert bytes(frac[f]).rstrip(b"\0") == (f"{f:02d}".rstrip("0") or "0").encode(), f
+    words = fastcsv._word_table().view(np.uint8).reshape(-1, 8)
+    for k in range(-9999, 10000):
+        text = f",{'-' if k < 0 else ''}{abs(k) // 100}.{(f'{abs(k) % 100:02d}'.rstrip('0') or '0')}".encode()
+        assert bytes(words[k + 10000]).rstrip(b"\0") == text, k
+    assert bytes(words[0]).rstrip(b"\0") == b",-0.0"
