@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 EMBEDDER_BLOB_FLOATS = 3_217_344
 EMBEDDING_SIZE = 1024
 MEL_BANDS = 64
@@ -66,6 +66,11 @@ PROTOTYPES = {
     "bd_batch_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32]),
     "bd_predict_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bd_predict_chunks": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bd_calibrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bd_get_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "bd_set_activation_exponents": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "bd_stage_shape": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bd_stage_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -76,7 +81,7 @@ PROTOTYPES = {
     "bd_range_flag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),
     "bd_range_flag_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "bd_set_fusion": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
-    "bd_debug_pointwise_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+    "bd_debug_pointwise_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "bd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "bd_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),

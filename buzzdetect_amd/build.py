@@ -7,11 +7,13 @@ with the repository snapshot to the GPU box; it is git-ignored.
 """
 from __future__ import annotations
 
+import fcntl
 import hashlib
 import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libbuzzdetect_hip.so"
@@ -49,18 +51,40 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile the library unless it is current.  Several processes may find it stale at once (every rank of a
+    ``torchrun`` launch imports the package): the rebuild is serialised by a lock file next to the sources, each
+    builder compiles into its own temporary name, and whoever gets the lock second finds the work done.  The command
+    line goes to stderr - stdout belongs to the caller (bench.py prints one JSON line there)."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print("[buzzdetect_amd.build]", " ".join(cmd), flush=True)
-    stamp = source_hash()
-    subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    with open(STAMP_PATH, "w") as f:
-        f.write(stamp + "\n")
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():          # another process built it while this one waited
+                return LIB_PATH
+            fd, tmp = tempfile.mkstemp(prefix=LIB_NAME + ".", suffix=".tmp", dir=CSRC)
+            os.close(fd)
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+                   "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print("[buzzdetect_amd.build]", " ".join(cmd), file=sys.stderr, flush=True)
+            stamp = source_hash()
+            try:
+                subprocess.run(cmd, check=True, stdout=sys.stderr)
+                os.chmod(tmp, 0o755)
+                with open(STAMP_PATH + ".tmp", "w") as f:
+                    f.write(stamp + "\n")
+                # the stamp goes first: a reader that sees the new library always sees its stamp
+                if os.path.exists(STAMP_PATH):
+                    os.remove(STAMP_PATH)
+                os.replace(tmp, LIB_PATH)
+                os.replace(STAMP_PATH + ".tmp", STAMP_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -70,7 +70,23 @@ struct SepLayer {
     int pw_variant16;    // tile choice for the split-f16 kernel (0 = by shape)
     int pw_mode;         // 0 = exact f32 MFMA, 1 = split-f16 MFMA (3 products), 2 = plain f16 MFMA (1 product)
     unsigned* range_flag;  // the engine's sticky "an activation left the f16 range" word (modes 1 and 2)
+    // Operand scaling of the f16 modes.  Both scales are exact powers of two, so nothing is rounded by them:
+    //   activations  the depthwise that produces this layer's GEMM input runs with taps and shift multiplied by 2^act_exp
+    //                (dw_w16 / dw_b16): its output is 2^act_exp times the true activation, bit for bit, and lands where f16
+    //                hi + lo carry 22 bits (act_exp comes from a calibration pass in exact f32, bd_create / bd_calibrate);
+    //   weights      output channel n of pw_whi / pw_wlo / pw_fhi / pw_flo is the split of pw_wt[n][:] * 2^row_exp[n], the
+    //                row's largest magnitude in [2^12, 2^13);
+    //   epilogue     out = relu(fma(acc, pw_u[n], pw_b[n])),  pw_u[n] = 2^-(act_exp + row_exp[n]).
+    const float* dw_w16; // [9][cin]  dw_w * 2^act_exp
+    const float* dw_b16; // [cin]     dw_b * 2^act_exp
+    const float* pw_u;   // [cout]
+    int act_exp;
+    unsigned* amax;      // calibration pass only: device word that takes max |depthwise output| (as float bits); else null
 };
+
+// taps / shift of the depthwise that feeds L's pointwise convolution, for the arithmetic mode L runs in
+inline const float* dw_w_of(const SepLayer& L) { return L.pw_mode != 0 ? L.dw_w16 : L.dw_w; }
+inline const float* dw_b_of(const SepLayer& L) { return L.pw_mode != 0 ? L.dw_b16 : L.dw_b; }
 
 // ---- launchers (each enqueues exactly one kernel on `stream`) ----
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
@@ -85,9 +101,10 @@ void launch_depthwise(const float* in, float* out, int windows, const SepLayer& 
 void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer& L, hipStream_t stream);
 int launch_pointwise_variant(const float* A, const float* Wt, const float* bias, float* C, long long M, int N,
                              int K, int variant, hipStream_t stream);
-int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* bias, float* C,
-                                   long long M, int N, int K, int variant, hipStream_t stream, bool plain = false,
+int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* unscale, const float* bias,
+                                   float* C, long long M, int N, int K, int variant, hipStream_t stream, bool plain = false,
                                    unsigned* range_flag = nullptr);
+void launch_scale_copy(const float* src, float* dst, int64_t n, float factor, hipStream_t stream);
 bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
                             hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,

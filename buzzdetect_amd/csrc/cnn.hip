@@ -117,8 +117,10 @@ template <int STRIDE, int OWB>
 __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ w9xc,
                                                         const float* __restrict__ bias, int windows, int H,
-                                                        int W, int C, int OH, int OW) {
+                                                        int W, int C, int OH, int OW,
+                                                        unsigned* __restrict__ amax) {
     constexpr int PAD = STRIDE == 1 ? 1 : 0;
+    float cmax = 0.0f;                       // calibration pass (amax != null): largest output of this thread
     constexpr int NCOL = (OWB - 1) * STRIDE + 3;
     const int c4n = C >> 2;
     const int owg = OW / OWB;
@@ -175,8 +177,20 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
             r.z = fmaxf(r.z, 0.0f);
             r.w = fmaxf(r.w, 0.0f);
             dst[(size_t)o * c4n] = r;
+            cmax = fmaxf(fmaxf(cmax, r.x), fmaxf(fmaxf(r.y, r.z), r.w));
         }
     }
+    if (amax) {                              // outputs are >= 0 (or NaN, which fmaxf drops): float bits order like unsigned
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+        if ((threadIdx.x & 63) == 0 && cmax > 0.0f) atomicMax(amax, __float_as_uint(cmax));
+    }
+}
+
+// dst = src * factor (the stage tap of a depthwise output in the f16 modes: factor = 2^-act_exp, exact)
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n,
+                                                         float factor) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) dst[i] = src[i] * factor;
 }
 
 // --------------------------------------------------------------------------- pointwise GEMM
@@ -357,16 +371,17 @@ __device__ __forceinline__ void split_f16(float x, float y, float z, float w, f1
 // "B"): lane l then owns output row m = l & 31 and, per register quad g, the four consecutive channels
 // n = 8 g + 4 (l >> 5) + 0..3 - one 16-byte store per quad instead of four 4-byte ones.  Products and
 // their k order are those of the untransposed form.
-__device__ __forceinline__ void store_tile_t(const f32x16& acc, const float* __restrict__ bias_n, float* crow,
-                                             bool live, int half) {
+__device__ __forceinline__ void store_tile_t(const f32x16& acc, const float* __restrict__ unscale_n,
+                                             const float* __restrict__ bias_n, float* crow, bool live, int half) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 b = *reinterpret_cast<const float4*>(bias_n + 8 * g + 4 * half);
+        const float4 u = *reinterpret_cast<const float4*>(unscale_n + 8 * g + 4 * half);
         float4 v;
-        v.x = fmaxf(acc[4 * g + 0] + b.x, 0.0f);
-        v.y = fmaxf(acc[4 * g + 1] + b.y, 0.0f);
-        v.z = fmaxf(acc[4 * g + 2] + b.z, 0.0f);
-        v.w = fmaxf(acc[4 * g + 3] + b.w, 0.0f);
+        v.x = fmaxf(fmaf(acc[4 * g + 0], u.x, b.x), 0.0f);
+        v.y = fmaxf(fmaf(acc[4 * g + 1], u.y, b.y), 0.0f);
+        v.z = fmaxf(fmaf(acc[4 * g + 2], u.z, b.z), 0.0f);
+        v.w = fmaxf(fmaf(acc[4 * g + 3], u.w, b.w), 0.0f);
         if (live) *reinterpret_cast<float4*>(crow + 8 * g + 4 * half) = v;
     }
 }
@@ -374,8 +389,8 @@ __device__ __forceinline__ void store_tile_t(const f32x16& acc, const float* __r
 template <int BM, int BN, int WGM, int WGN, bool PLAIN>
 __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
     const float* __restrict__ A, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
-    const float* __restrict__ bias, float* __restrict__ C, long long M, int N, int K, int tiles_n,
-    unsigned* __restrict__ range_flag) {
+    const float* __restrict__ unscale, const float* __restrict__ bias, float* __restrict__ C, long long M, int N, int K,
+    int tiles_n, unsigned* __restrict__ range_flag) {
     float rmax = 0.0f;
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -509,14 +524,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_f16x3_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nb = n0 + wc * WN + j * 32;
-            store_tile_t(acc[i][j], bias + nb, crow + nb, m < M, half);
+            store_tile_t(acc[i][j], unscale + nb, bias + nb, crow + nb, m < M, half);
         }
     }
     range_report(rmax, range_flag);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool PLAIN>
-void launch_pw16_(const float* A, const _Float16* Whi, const _Float16* Wlo, const float* bias, float* C,
+void launch_pw16_(const float* A, const _Float16* Whi, const _Float16* Wlo, const float* unscale, const float* bias, float* C,
                   long long M, int N, int K, unsigned* range_flag, hipStream_t stream) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = 2u * 2u * (BM + BN) * 64;
@@ -525,14 +540,14 @@ void launch_pw16_(const float* A, const _Float16* Whi, const _Float16* Wlo, cons
     const int tiles_n = N / BN;
     const long long tiles = ((M + BM - 1) / BM) * tiles_n;
     hipLaunchKernelGGL((pointwise_f16x3_kernel<BM, BN, WGM, WGN, PLAIN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A,
-                       Whi, Wlo, bias, C, M, N, K, tiles_n, range_flag);
+                       Whi, Wlo, unscale, bias, C, M, N, K, tiles_n, range_flag);
 }
 
 template <int BM, int BN, int WGM, int WGN>
-void launch_pw16(const float* A, const _Float16* Whi, const _Float16* Wlo, const float* bias, float* C,
+void launch_pw16(const float* A, const _Float16* Whi, const _Float16* Wlo, const float* unscale, const float* bias, float* C,
                  long long M, int N, int K, bool plain, unsigned* range_flag, hipStream_t stream) {
-    if (plain) launch_pw16_<BM, BN, WGM, WGN, true>(A, Whi, Wlo, bias, C, M, N, K, range_flag, stream);
-    else launch_pw16_<BM, BN, WGM, WGN, false>(A, Whi, Wlo, bias, C, M, N, K, range_flag, stream);
+    if (plain) launch_pw16_<BM, BN, WGM, WGN, true>(A, Whi, Wlo, unscale, bias, C, M, N, K, range_flag, stream);
+    else launch_pw16_<BM, BN, WGM, WGN, false>(A, Whi, Wlo, unscale, bias, C, M, N, K, range_flag, stream);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -602,7 +617,8 @@ __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned t
 template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD, int PWO, bool PLAIN>
 __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_b,
+    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_u,
+    const float* __restrict__ pw_b,
     float* __restrict__ Cout, long long M, int N, int K, int H, int W, int tiles_n,
     const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out2,
     unsigned* __restrict__ range_flag) {
@@ -1144,14 +1160,14 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nl = wc * WN + j * 32 + frow;
-        const float b = pw_b[n0 + nl];
+        const float b = pw_b[n0 + nl], u = pw_u[n0 + nl];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = i * 32 + 4 * fh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = mb + (r & 3) + 8 * (r >> 2);
-                Ct[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + b, 0.0f);
+                Ct[ml * (BN + 4) + nl] = fmaxf(fmaf(acc[i][j][r], u, b), 0.0f);
             }
         }
     }
@@ -1301,9 +1317,9 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
         static int shots = 0;
         if (!dbg) (void)hipMalloc(&dbg, 1024 + 8192);
         (void)hipMemsetAsync(dbg, 0, 1024 + 8192, stream);
-        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, L.dw_w,
-                       L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
-                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
+        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, dw_w_of(L),
+                       dw_b_of(L), static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
+                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_u, L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, nullptr, nullptr, reinterpret_cast<float*>(dbg), L.range_flag);
         (void)hipStreamSynchronize(stream);
         static unsigned h[256 + 2048];
@@ -1344,11 +1360,11 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
         return;
     }
 #endif
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds, stream, X, L.dw_w,
-                       L.dw_b, static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
-                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_b,
-                       out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? next->dw_w : nullptr,
-                       next ? next->dw_b : nullptr, out, L.range_flag);
+    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds, stream, X, dw_w_of(L),
+                       dw_b_of(L), static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
+                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_u, L.pw_b,
+                       out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? dw_w_of(*next) : nullptr,
+                       next ? dw_b_of(*next) : nullptr, out, L.range_flag);
 }
 
 // --------------------------------------------------------------------------- 12-wave form for N = 512
@@ -1362,7 +1378,8 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
 template <int XPMAX, bool TRACE, bool PLAIN, int KT = 0>   // KT: the number of input channels when known at compile time
 __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8-11: tap and slab strides become immediates)
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
+    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_u,
+    const float* __restrict__ pw_b,
     float* __restrict__ Cout, long long M, int K_, int H, int W, unsigned* __restrict__ dbg,
     unsigned* __restrict__ range_flag) {
     const int K = KT > 0 ? KT : K_;
@@ -1572,9 +1589,12 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
 #undef W12_STEP
 #undef W12_BLOAD
         // ---- epilogue, consumer part: bias + ReLU, 32 rows at a time through the chunk ----
-        float bias_[TN];
+        float bias_[TN], unsc_[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bias_[j] = pw_b[64 * wc + j * 32 + frow];
+        for (int j = 0; j < TN; ++j) {
+            bias_[j] = pw_b[64 * wc + j * 32 + frow];
+            unsc_[j] = pw_u[64 * wc + j * 32 + frow];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1583,7 +1603,7 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = 4 * fh + (r & 3) + 8 * (r >> 2);
-                    Cc[ml * (BN + 4) + nl] = fmaxf(acc[i][j][r] + bias_[j], 0.0f);
+                    Cc[ml * (BN + 4) + nl] = fmaxf(fmaf(acc[i][j][r], unsc_[j], bias_[j]), 0.0f);
                 }
             }
             __syncthreads();
@@ -1632,8 +1652,8 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         }
         (void)hipMemsetAsync(dbg, 0, 512, stream);
-        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
-                           static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
+        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
+                           static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, out, M,
                            L.cin, L.h_out, L.w_out, dbg, L.range_flag);
         (void)hipStreamSynchronize(stream);
         unsigned h[128];
@@ -1655,13 +1675,13 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
     if (L.cin == 512) {
         static std::once_flag lds_once512[kMaxDevices];
         allow_dynamic_lds(&sep_w12_kernel<XPMAX, false, PLAIN, 512>, (int)lds_max, lds_once512);
-        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN, 512>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w,
-                           L.dw_b, static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out,
-                           M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
+        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN, 512>), dim3((unsigned)tiles), dim3(768), lds, stream, X, dw_w_of(L),
+                           dw_b_of(L), static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u,
+                           L.pw_b, out, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
         return;
     }
-    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
-                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
+    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, out, M,
                        L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
 }
 
@@ -1727,7 +1747,8 @@ struct PwResSchedule {
 // barrier per tile.  Same products in the same order as pointwise_f16x3_kernel: bit-identical.
 template <int K16, bool PLAIN>
 __global__ __launch_bounds__(512, 2) void pw_res_kernel(const float* __restrict__ X, const _Float16* __restrict__ Wfhi,
-                                                         const _Float16* __restrict__ Wflo, const float* __restrict__ bias,
+                                                         const _Float16* __restrict__ Wflo, const float* __restrict__ unscale,
+                                                         const float* __restrict__ bias,
                                                          float* __restrict__ C, int M, int N, int tiles_n,
                                                          unsigned* __restrict__ range_flag) {
     constexpr int K = 16 * K16;
@@ -1790,7 +1811,7 @@ __global__ __launch_bounds__(512, 2) void pw_res_kernel(const float* __restrict_
         if constexpr (!PLAIN) bl[q] = *reinterpret_cast<const f16x8*>(Wflo + frag);
     }
     const int col = ct * 32 + frow;
-    const float bcol = bias[col];
+    const float bcol = bias[col], ucol = unscale[col];
 
 #pragma unroll
     for (int j = 0; j < V; ++j) BD_R_SPLIT1(rx[0], j, 0)
@@ -1848,11 +1869,11 @@ __global__ __launch_bounds__(512, 2) void pw_res_kernel(const float* __restrict_
         float* const crow = C + (size_t)row0 * N + col;
         if (32 * t + 32 <= M) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) crow[(size_t)((e & 3) + 8 * (e >> 2)) * N] = fmaxf(acc[e] + bcol, 0.0f);
+            for (int e = 0; e < 16; ++e) crow[(size_t)((e & 3) + 8 * (e >> 2)) * N] = fmaxf(fmaf(acc[e], ucol, bcol), 0.0f);
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (row0 + (e & 3) + 8 * (e >> 2) < M) crow[(size_t)((e & 3) + 8 * (e >> 2)) * N] = fmaxf(acc[e] + bcol, 0.0f);
+                if (row0 + (e & 3) + 8 * (e >> 2) < M) crow[(size_t)((e & 3) + 8 * (e >> 2)) * N] = fmaxf(fmaf(acc[e], ucol, bcol), 0.0f);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1884,7 +1905,7 @@ void launch_pw_res(const float* X, const SepLayer& L, float* out, int M, hipStre
     int streams = 256 / tiles_n;
     if (streams > n_tiles) streams = (n_tiles + 7) / 8 * 8;
     hipLaunchKernelGGL((pw_res_kernel<K16, PLAIN>), dim3((unsigned)(streams * tiles_n)), dim3(512), lds, stream, X,
-                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, out, M,
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, out, M,
                        L.cout, tiles_n, L.range_flag);
 }
 
@@ -1911,7 +1932,8 @@ void launch_pw_res(const float* X, const SepLayer& L, float* out, int M, hipStre
 template <bool PLAIN>
 __global__ __launch_bounds__(768) void l4_window_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_b,
+    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_u,
+    const float* __restrict__ pw_b,
     const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out, int windows,
     unsigned* __restrict__ range_flag
 #ifdef BD_KERNEL_TRACE
@@ -1982,7 +2004,7 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
             if constexpr (!PLAIN) bl[q] = *reinterpret_cast<const f16x8*>(Wflo + frag);
         }
         const int ncol = 32 * wave + frow;
-        const float bcol = pw_b[ncol];
+        const float bcol = pw_b[ncol], ucol = pw_u[ncol];
         BD_L4_STORE(rs[0], 0)
         BD_L4_STORE(rs[1], 1)
         BD_L4_LOAD(rs[0], 2)
@@ -2037,7 +2059,7 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = (e & 3) + 8 * (e >> 2);                // + 4 fh, in yt: rows 16 .. 31 are map row 1
-                    yb[((m >> 4) * (W + 1) + (m & 15)) * (C + 4)] = fmaxf(acc[e] + bcol, 0.0f);
+                    yb[((m >> 4) * (W + 1) + (m & 15)) * (C + 4)] = fmaxf(fmaf(acc[e], ucol, bcol), 0.0f);
                 }
             }
             BD_L4_TS(0, 0)
@@ -2186,9 +2208,9 @@ void launch_l4_window(const float* X, const SepLayer& L, const SepLayer& next, f
     static int shots = 0;
     if (!dbg) (void)hipMalloc(&dbg, 1024);
     (void)hipMemsetAsync(dbg, 0, 1024, stream);
-    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
-                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, next.dw_w,
-                       next.dw_b, out, windows, L.range_flag, dbg);
+    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, dw_w_of(next),
+                       dw_b_of(next), out, windows, L.range_flag, dbg);
     if (getenv("BD_L4_TRACE") && ++shots == 6) {
         (void)hipStreamSynchronize(stream);
         unsigned h[256];
@@ -2207,9 +2229,9 @@ void launch_l4_window(const float* X, const SepLayer& L, const SepLayer& next, f
         }
     }
 #else
-    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, L.dw_w, L.dw_b,
-                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_b, next.dw_w,
-                       next.dw_b, out, windows, L.range_flag);
+    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
+                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, dw_w_of(next),
+                       dw_b_of(next), out, windows, L.range_flag);
 #endif
 }
 
@@ -2234,10 +2256,12 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                                                     const float* __restrict__ c1_w, const float* __restrict__ c1_b,
                                                     const float* __restrict__ dw2_w, const float* __restrict__ dw2_b,
                                                     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
-                                                    const float* __restrict__ pw_b, const float* __restrict__ dw3_w,
+                                                    const float* __restrict__ pw_u, const float* __restrict__ pw_b,
+                                                    const float* __restrict__ dw3_w,
                                                     const float* __restrict__ dw3_b, float* __restrict__ out,
                                                     const _Float16* __restrict__ W3fhi, const _Float16* __restrict__ W3flo,
-                                                    const float* __restrict__ pw3_b, unsigned* __restrict__ dbg,
+                                                    const float* __restrict__ pw3_u, const float* __restrict__ pw3_b,
+                                                    unsigned* __restrict__ dbg,
                                                     unsigned* __restrict__ range_flag) {
     float rmax = 0.0f;
 #define ST_TS(I) if (dbg && blockIdx.x == 5 && blockIdx.y == 7 && threadIdx.x == 0) dbg[I] = (unsigned)__builtin_readcyclecounter();
@@ -2438,9 +2462,12 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
     {
         // transposed accumulators: lane -> position rt * 32 + frow; registers 4 g .. 4 g + 3 -> channels
         // wc * 32 + 8 g + 4 fh + (0..3)
-        v4f b4[4];
+        v4f b4[4], u4[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const v4f*>(pw_b + wc * 32 + 8 * g + 4 * fh);
+        for (int g = 0; g < 4; ++g) {
+            b4[g] = *reinterpret_cast<const v4f*>(pw_b + wc * 32 + 8 * g + 4 * fh);
+            u4[g] = *reinterpret_cast<const v4f*>(pw_u + wc * 32 + 8 * g + 4 * fh);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int rt = wr + 2 * i;
@@ -2450,8 +2477,9 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                 if (live) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        // (vector add: two v_pk_add_f32 instead of four v_add_f32; the same IEEE additions)
-                        v4f v = v4f{acc2[i][4 * g + 0], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]} + b4[g];
+                        // (vector fma: two v_pk_fma_f32 instead of four v_fma_f32; the same IEEE operations)
+                        v4f v = __builtin_elementwise_fma(v4f{acc2[i][4 * g + 0], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]},
+                                                          u4[g], b4[g]);
                         v.x = fmaxf(v.x, 0.0f);
                         v.y = fmaxf(v.y, 0.0f);
                         v.z = fmaxf(v.z, 0.0f);
@@ -2540,12 +2568,12 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         // ---- H: bias + ReLU, [32][128] block of the layer-3 output (rows are consecutive NHWC positions) ----
         float* dst3 = out + (((size_t)win * 24 + 2 * ob) * 16) * 128;
         const int n = 32 * wave + frow;
-        const float b = pw3_b[n];
+        const float b = pw3_b[n], u = pw3_u[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 4 * fh + (r & 3) + 8 * (r >> 2);
             typedef float v2f_ __attribute__((ext_vector_type(2)));
-            const v2f_ t2 = v2f_{acc3[r & ~1], acc3[r | 1]} + v2f_{b, b};        // one v_pk_add_f32 per two outputs
+            const v2f_ t2 = __builtin_elementwise_fma(v2f_{acc3[r & ~1], acc3[r | 1]}, v2f_{u, u}, v2f_{b, b});   // one v_pk_fma_f32 per two outputs
             dst3[(size_t)m * 128 + n] = fmaxf((r & 1) ? t2.y : t2.x, 0.0f);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2626,8 +2654,15 @@ static void launch_dw(const float* in, float* out, int windows, const SepLayer& 
     const long long total = (long long)windows * L.h_out * (L.w_out / OWB) * (L.cin / 4);
     const long long blocks = (total + 255) / 256;
     const int grid = (int)(blocks < (1 << 20) ? blocks : (1 << 20));
-    hipLaunchKernelGGL((depthwise_kernel<STRIDE, OWB>), dim3(grid), dim3(256), 0, stream, in, out, L.dw_w, L.dw_b,
-                       windows, L.h_in, L.w_in, L.cin, L.h_out, L.w_out);
+    hipLaunchKernelGGL((depthwise_kernel<STRIDE, OWB>), dim3(grid), dim3(256), 0, stream, in, out, dw_w_of(L), dw_b_of(L),
+                       windows, L.h_in, L.w_in, L.cin, L.h_out, L.w_out, L.amax);
+}
+
+void launch_scale_copy(const float* src, float* dst, int64_t n, float factor, hipStream_t stream) {
+    if (n <= 0) return;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, src, dst,
+                       (long long)n, factor);
 }
 
 void launch_depthwise(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream) {
@@ -2687,8 +2722,8 @@ static int pick_f16x3_variant(long long M, int N, int K) {
     return 8;
 }
 
-int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* bias, float* C,
-                                   long long M, int N, int K, int variant, hipStream_t stream, bool plain,
+int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* Wlo, const float* unscale, const float* bias,
+                                   float* C, long long M, int N, int K, int variant, hipStream_t stream, bool plain,
                                    unsigned* range_flag) {
     if (M <= 0) return 0;
     if (K % 32 != 0 || N % 64 != 0) return -1;
@@ -2696,15 +2731,15 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
     const _Float16* wl = static_cast<const _Float16*>(Wlo);
     if (variant == 0) variant = pick_f16x3_variant(M, N, K);
     switch (variant) {
-        case 1: if (N % 128) return -1; launch_pw16<128, 128, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 2: launch_pw16<128, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 3: if (N % 128) return -1; launch_pw16<256, 128, 4, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 4: if (N % 256) return -1; launch_pw16<128, 256, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 5: launch_pw16<256, 64, 4, 1>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 6: if (N % 128) return -1; launch_pw16<64, 128, 1, 4>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 7: if (N % 256) return -1; launch_pw16<128, 256, 2, 4>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 8: launch_pw16<64, 64, 2, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
-        case 9: if (N % 256) return -1; launch_pw16<256, 256, 4, 2>(A, wh, wl, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 1: if (N % 128) return -1; launch_pw16<128, 128, 2, 2>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 2: launch_pw16<128, 64, 2, 2>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 3: if (N % 128) return -1; launch_pw16<256, 128, 4, 2>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 4: if (N % 256) return -1; launch_pw16<128, 256, 2, 2>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 5: launch_pw16<256, 64, 4, 1>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 6: if (N % 128) return -1; launch_pw16<64, 128, 1, 4>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 7: if (N % 256) return -1; launch_pw16<128, 256, 2, 4>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 8: launch_pw16<64, 64, 2, 2>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
+        case 9: if (N % 256) return -1; launch_pw16<256, 256, 4, 2>(A, wh, wl, unscale, bias, C, M, N, K, plain, range_flag, stream); break;
         default: return -1;
     }
     return 0;
@@ -2730,7 +2765,7 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
     const bool f16 = L.pw_mode == 1 || L.pw_mode == 2;
     if (f16 && (L.pw_variant16 == 0 || L.pw_variant16 >= 10) && launch_pointwise_ws(in, out, rows, L, stream)) return;
     if (f16)
-        launch_pointwise_f16x3_variant(in, L.pw_whi, L.pw_wlo, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant16,
+        launch_pointwise_f16x3_variant(in, L.pw_whi, L.pw_wlo, L.pw_u, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant16,
                                        stream, L.pw_mode == 2, L.range_flag);
     else
         launch_pointwise_variant(in, L.pw_wt, L.pw_b, out, rows, L.cout, L.cin, L.pw_variant, stream);
@@ -2787,9 +2822,9 @@ void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int
     if (windows <= 0) return;
 #define BD_STEM3(PLAIN)                                                                                              \
     hipLaunchKernelGGL((stem3_kernel<false, PLAIN>), dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,  \
-                       c1_w, c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),                            \
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out, nullptr, nullptr, nullptr,  \
-                       nullptr, L2.range_flag)
+                       c1_w, c1_b, dw_w_of(L2), dw_b_of(L2), static_cast<const _Float16*>(L2.pw_whi),                     \
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_u, L2.pw_b, dw_w_of(L3), dw_b_of(L3), out, nullptr,   \
+                       nullptr, nullptr, nullptr, nullptr, L2.range_flag)
     if (L2.pw_mode == 2) BD_STEM3(true);
     else BD_STEM3(false);
 #undef BD_STEM3
@@ -2808,10 +2843,10 @@ void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int
 #endif
 #define BD_STEM4(PLAIN)                                                                                              \
     hipLaunchKernelGGL((stem3_kernel<true, PLAIN>), dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,   \
-                       c1_w, c1_b, L2.dw_w, L2.dw_b, static_cast<const _Float16*>(L2.pw_whi),                            \
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_b, L3.dw_w, L3.dw_b, out,                          \
-                       static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_b, dbg,    \
-                       L2.range_flag)
+                       c1_w, c1_b, dw_w_of(L2), dw_b_of(L2), static_cast<const _Float16*>(L2.pw_whi),                     \
+                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_u, L2.pw_b, dw_w_of(L3), dw_b_of(L3), out,            \
+                       static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_u, L3.pw_b,  \
+                       dbg, L2.range_flag)
     if (L2.pw_mode == 2) BD_STEM4(true);
     else BD_STEM4(false);
 #undef BD_STEM4

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -60,6 +61,13 @@ struct bd_engine {
     bool l4_band_tiles = false;       // layer 4 + depthwise 5 as overlapping band tiles of the generic kernel (bd_set_fusion separable = 2)
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
+    // operand scaling of the f16 modes (bd_internal.h, SepLayer): host copies of what the scaled tensors are made from
+    std::vector<float> h_dw[13];      // [10][cin]: folded depthwise taps, then the shift (unscaled)
+    std::vector<int> row_exp[13];     // [cout]: power-of-two exponent the pointwise row was scaled by before its f16 split
+    size_t off_dw16[13] = {0}, off_pw_u[13] = {0};   // float offsets of dw_w16 (dw_b16 follows at + 9 cin) / pw_u in d_pool
+    float act_max[13] = {0};          // largest depthwise output seen by the calibration passes (exact-f32 arithmetic)
+    int act_exp[13] = {0};
+    unsigned* d_amax = nullptr;       // [16] calibration words
     const float* conv1_w = nullptr;   // [9][32]
     const float* conv1_b = nullptr;   // [32]
     bd::SepLayer sep[13];
@@ -71,6 +79,8 @@ struct bd_engine {
         int up, down, half;
         float* dev;
         std::vector<float> host;      // source of the asynchronous upload; must outlive it
+        hipStream_t upload_stream;    // a launch on any OTHER stream first waits for `uploaded`
+        hipEvent_t uploaded;
     };
     std::vector<Taps> taps;
     // profiling
@@ -236,6 +246,9 @@ int build_tables(const float* mel, bd::FeTables* t) {
     return BD_OK;
 }
 
+int apply_scales(bd_engine* e);
+int calibrate_builtin(bd_engine* e);
+
 }  // namespace
 
 extern "C" {
@@ -318,6 +331,8 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
     const float* p = w->embedder_blob;
     size_t off_conv1_w, off_conv1_b;
     size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13], off_pw_hi[13], off_pw_lo[13], off_pw_fhi[13], off_pw_flo[13];
+    size_t off_dw16[13], off_pw_u[13];
+    std::vector<int> row_exps[13];
     {
         const int c = kLayerDefs[0][1];
         const float* kern = p;   // [3][3][1][32]
@@ -351,22 +366,43 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
             for (int k = 0; k < cin; ++k)
                 host[off_pw_w[l] + (size_t)n * cin + k] = (float)((double)pw[(size_t)k * cout + n] * fp.scale[n]);
         for (int n = 0; n < cout; ++n) host[off_pw_b[l] + n] = (float)fp.shift[n];
-        // split-f16 copy of the folded pointwise kernel: w = hi + lo, hi = f16(w), lo = f16(w - hi)
+        // split-f16 copy of the folded pointwise kernel.  Every output channel (row of W^T) is first multiplied by the
+        // power of two that puts its largest magnitude into [2^12, 2^13): then hi = f16(w) and lo = f16(w - hi) are both
+        // NORMAL f16 numbers for every weight within 2^-15 of the row's largest, i.e. w = hi + lo to 22 bits whatever the
+        // scale BatchNorm folding left the row at (unscaled, lo is subnormal - absolute quantum 2^-24 - below |w| = 0.125).
+        // The epilogue multiplies the accumulator by the inverse power of two (SepLayer::pw_u): nothing is rounded.
         const size_t nw = (size_t)cin * cout;
         off_pw_hi[l] = reserve((nw + 1) / 2);
         off_pw_lo[l] = reserve((nw + 1) / 2);
+        row_exps[l].assign(cout, 0);
         {
             _Float16* hi = reinterpret_cast<_Float16*>(host.data() + off_pw_hi[l]);
             _Float16* lo = reinterpret_cast<_Float16*>(host.data() + off_pw_lo[l]);
             const float* wf = host.data() + off_pw_w[l];
-            for (size_t i = 0; i < nw; ++i) {
-                if (std::fabs(wf[i]) > 60000.0f)
-                    return fail(BD_EWEIGHTS, "bd_create: folded pointwise weight exceeds the f16 range");
-                const _Float16 h = (_Float16)wf[i];
-                hi[i] = h;
-                lo[i] = (_Float16)(wf[i] - (float)h);
+            for (int n = 0; n < cout; ++n) {
+                float wmax = 0.0f;
+                for (int k = 0; k < cin; ++k) {
+                    const float a = std::fabs(wf[(size_t)n * cin + k]);
+                    if (!(a <= 3.0e38f)) return fail(BD_EWEIGHTS, "bd_create: non-finite value after BatchNorm folding");
+                    wmax = a > wmax ? a : wmax;
+                }
+                int ex = 0;
+                if (wmax > 0.0f) {
+                    (void)std::frexp(wmax, &ex);                  // wmax = m 2^ex, 0.5 <= m < 1
+                    ex = 13 - ex;
+                    ex = ex > 60 ? 60 : (ex < -60 ? -60 : ex);
+                }
+                row_exps[l][n] = ex;
+                for (int k = 0; k < cin; ++k) {
+                    const float w = std::ldexp(wf[(size_t)n * cin + k], ex);
+                    const _Float16 h = (_Float16)w;
+                    hi[(size_t)n * cin + k] = h;
+                    lo[(size_t)n * cin + k] = (_Float16)(w - (float)h);
+                }
             }
         }
+        off_dw16[l] = reserve(10 * (size_t)cin);
+        off_pw_u[l] = reserve(cout);
         // the same halves in MFMA fragment order (v_mfma_f32_32x32x16_f16 B operand): for a 32-channel tile t
         // and a 16-deep k step q, lane l holds W[32 t + l % 32][16 q + 8 (l / 32) .. + 8], so a wave's fragment
         // load is 1 KiB contiguous:  frag[((t * K/16 + q) * 64 + l) * 8 + e]
@@ -424,12 +460,15 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
     if (err == hipSuccess) err = hipMalloc(&e->d_tables, sizeof(bd::FeTables));
     if (err == hipSuccess) err = hipMalloc(&e->d_range_flag, 256);
     if (err == hipSuccess) err = hipMemset(e->d_range_flag, 0, 256);
+    if (err == hipSuccess) err = hipMalloc(&e->d_amax, 64);
+    if (err == hipSuccess) err = hipMemset(e->d_amax, 0, 64);
     if (err == hipSuccess) err = hipMemcpy(e->d_pool, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(e->d_tables, &tables, sizeof(tables), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
         if (e->d_pool) (void)hipFree(e->d_pool);
         if (e->d_tables) (void)hipFree(e->d_tables);
         if (e->d_range_flag) (void)hipFree(e->d_range_flag);
+        if (e->d_amax) (void)hipFree(e->d_amax);
         delete e;
         return fail(BD_EHIP, std::string("bd_create: ") + hipGetErrorString(err));
     }
@@ -458,6 +497,16 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         L.pw_variant16 = 0;
         L.pw_mode = e->pointwise_mode;
         L.range_flag = e->d_range_flag;
+        L.dw_w16 = e->d_pool + off_dw16[l];
+        L.dw_b16 = L.dw_w16 + 9 * (size_t)cin;
+        L.pw_u = e->d_pool + off_pw_u[l];
+        L.act_exp = 0;
+        L.amax = nullptr;
+        e->off_dw16[l] = off_dw16[l];
+        e->off_pw_u[l] = off_pw_u[l];
+        e->row_exp[l] = row_exps[l];
+        e->h_dw[l].assign(host.begin() + off_dw_w[l], host.begin() + off_dw_w[l] + 9 * (size_t)cin);
+        e->h_dw[l].insert(e->h_dw[l].end(), host.begin() + off_dw_b[l], host.begin() + off_dw_b[l] + cin);
         h = L.h_out;
         wd = L.w_out;
         cin = L.cout;
@@ -465,6 +514,14 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
     if (w->n_classes > 0) {
         e->head_wt = e->d_pool + off_head_w;
         e->head_b = e->d_pool + off_head_b;
+    }
+    // activation scales of the f16 modes from a pass over the built-in calibration signal in exact-f32 arithmetic
+    rc = apply_scales(e);
+    if (rc == BD_OK) rc = calibrate_builtin(e);
+    if (rc < 0) {
+        const std::string msg = g_error;
+        (void)bd_destroy(e);
+        return fail(rc, msg);
     }
     *out = e;
     return BD_OK;
@@ -478,7 +535,11 @@ int bd_destroy(bd_handle h) {
     if (h->d_pool) (void)hipFree(h->d_pool);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_range_flag) (void)hipFree(h->d_range_flag);
-    for (auto& t : h->taps) (void)hipFree(t.dev);
+    for (auto& t : h->taps) {
+        (void)hipFree(t.dev);
+        if (t.uploaded) (void)hipEventDestroy(t.uploaded);
+    }
+    if (h->d_amax) (void)hipFree(h->d_amax);
     delete h;
     return BD_OK;
 }
@@ -561,11 +622,21 @@ static int resample_any(bd_handle h, const void* in_dev, bool s16, int64_t n_in,
             t.down = down;
             t.host = design_taps(up, down, &t.half);
             t.dev = nullptr;
+            t.upload_stream = (hipStream_t)stream;
+            t.uploaded = nullptr;
             BD_HIP(hipMalloc(&t.dev, t.host.size() * sizeof(float)));
+            if (hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming) != hipSuccess) {
+                (void)hipFree(t.dev);
+                return fail(BD_EHIP, "bd_resample: hipEventCreate failed");
+            }
             h->taps.push_back(std::move(t));
             filt = &h->taps.back();
             BD_HIP(hipMemcpyAsync(filt->dev, filt->host.data(), filt->host.size() * sizeof(float), hipMemcpyHostToDevice,
                                   (hipStream_t)stream));
+            BD_HIP(hipEventRecord(filt->uploaded, (hipStream_t)stream));
+        } else if (filt->upload_stream != (hipStream_t)stream) {
+            // the taps were uploaded in the order of another stream: nothing else orders this launch behind that copy
+            BD_HIP(hipStreamWaitEvent((hipStream_t)stream, filt->uploaded, 0));
         }
     }
     const int64_t n_out = (n_in * up + down - 1) / down;
@@ -642,19 +713,45 @@ int64_t batch_workspace(const bd_engine* e, const BatchPlan& p) {
 
 // The launch plan of one batch of chunks.  stop_stage < 0: run everything; otherwise stop after that CNN
 // stage of the first group and copy it to tap_out.
-int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int32_t n_chunks, int32_t hop,
+// chunk_pcm[c]: device pointer of chunk c (4-byte aligned; the packed entry points pass pcm + the samples before it).
+// mode: arithmetic of the 1x1 convolutions for THIS call (-1: the handle's).  range_word: the word this call's kernels
+// raise instead of the engine's sticky one (device memory, or pinned host memory - the kernels then write across PCIe,
+// which only ever happens when a chunk does leave the range), or null.  calibrating: the depthwise kernels report their
+// largest output into e->d_amax (exact-f32, one kernel per op).
+int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk_samples, int32_t n_chunks, int32_t hop,
                int32_t step, void* ws, int64_t ws_bytes, float* emb, float* logits, int stop_stage, int tap_windows,
-               float* tap_out, hipStream_t stream) {
+               float* tap_out, int mode_arg, int32_t* range_word, bool calibrating, hipStream_t stream) {
     if (!e) return fail(BD_EINVAL, "null handle");
-    if (misaligned(pcm) || misaligned(ws) || misaligned(emb) || misaligned(logits) || misaligned(tap_out))
+    if (misaligned(ws) || misaligned(emb) || misaligned(logits) || misaligned(tap_out))
         return fail(BD_EINVAL, "device pointers need 16-byte alignment");
+    if (mode_arg < -1 || mode_arg > 2) return fail(BD_EINVAL, "mode must be -1 (the handle's), 0, 1 or 2");
     if (logits && e->n_classes == 0) return fail(BD_EINVAL, "engine was created without a head");
+    if (!chunk_pcm) return fail(BD_EINVAL, "null chunk pointer table");
     BatchPlan plan;
     int rc = plan_batch(chunk_samples, n_chunks, hop, step, &plan);
     if (rc < 0) return rc;
-    int64_t total_samples = 0;
-    for (int c = 0; c < n_chunks; ++c) total_samples += chunk_samples[c];
-    if (!pcm && total_samples > 0) return fail(BD_EINVAL, "null pcm pointer");
+    for (int c = 0; c < n_chunks; ++c) {
+        if (!chunk_pcm[c] && chunk_samples[c] > 0) return fail(BD_EINVAL, "null pcm pointer");
+        if (reinterpret_cast<uintptr_t>(chunk_pcm[c]) & 3u) return fail(BD_EINVAL, "pcm pointers need 4-byte alignment");
+    }
+    const int mode = calibrating ? 0 : (mode_arg < 0 ? e->pointwise_mode : mode_arg);
+    BD_HIP(hipSetDevice(e->device));
+    unsigned* flag = e->d_range_flag;
+    if (range_word) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, range_word) != hipSuccess || !attr.devicePointer) {
+            (void)hipGetLastError();
+            return fail(BD_EINVAL, "range_word must be device memory or pinned (device-mapped) host memory");
+        }
+        flag = static_cast<unsigned*>(attr.devicePointer);
+    }
+    bd::SepLayer sep[13];                     // this call's view of the layers: its own mode, range word, calibration words
+    for (int l = 0; l < 13; ++l) {
+        sep[l] = e->sep[l];
+        sep[l].pw_mode = mode;
+        sep[l].range_flag = flag;
+        sep[l].amax = calibrating ? e->d_amax + l : nullptr;
+    }
     const int64_t need = batch_workspace(e, plan);
     if (!ws || ws_bytes < need) return fail(BD_EWORKSPACE, "workspace smaller than bd_workspace_bytes()");
     struct { int64_t n_frames, n_windows; } g = {plan.total_frames, plan.total_windows};
@@ -671,7 +768,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
     if (e->profiling) Scope::mark(e, stream, -1);
     for (int c = 0; c < n_chunks; ++c) {       // one front-end launch per chunk: its padding is its own
         Scope sc(e, stream, 0);
-        bd::launch_logmel(pcm + plan.sample_base[c], chunk_samples[c], plan.frames[c],
+        bd::launch_logmel(chunk_pcm[c], chunk_samples[c], plan.frames[c],
                           logmel + (int64_t)plan.map.frame_base[c] * BD_MEL_BANDS, e->d_tables, stream);
     }
     const float* const lm = logmel;
@@ -683,7 +780,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
         float* buf_a = buf_a0;
         float* buf_b = buf_b0;
         // layers 1-3 run as one fused kernel (split-f16 mode) unless a test taps inside them
-        const bool fuse_stem = e->fuse_stem && e->pointwise_mode != 0 && (stop_stage < 0 || stop_stage >= 2);
+        const bool fuse_stem = e->fuse_stem && mode != 0 && (stop_stage < 0 || stop_stage >= 2);
         const float* last = buf_a;
         int64_t last_floats = 0;
         bool stopped = false;
@@ -695,7 +792,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
         if (fuse_stem3 && e->fuse_stem4) {
             {
                 Scope sc(e, stream, 5);      // timed in the slot of pointwise 3 (slots 1-4 stay empty)
-                bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, e->sep[0], e->sep[1], buf_a, stream);
+                bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
             }
             last = buf_a;
             last_floats = (int64_t)gw * 24 * 16 * 128;
@@ -704,7 +801,7 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
         } else if (fuse_stem3) {
             {
                 Scope sc(e, stream, 4);      // timed in the slot of depthwise 3 (slots 1-3 stay empty)
-                bd::launch_stem3(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, e->sep[0], e->sep[1], buf_b, stream);
+                bd::launch_stem3(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_b, stream);
             }
             last = buf_b;
             last_floats = (int64_t)gw * 24 * 16 * 64;
@@ -720,10 +817,10 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
         }
         bool pooled_done = false;    // the last layer's kernel already produced the pooled embeddings
         for (int l = first_layer; l < 13 && !stopped; ++l) {
-            const bd::SepLayer& L = e->sep[l];
+            const bd::SepLayer& L = sep[l];
             // last layer: the global average pool rides in the fused kernel's epilogue; only [windows][1024] is
             // written (into the caller's embedding buffer if there is one, else into buf_b)
-            if (l == 12 && e->fuse_sep && e->fuse_next_dw && e->pointwise_mode != 0 && e->sep_variant <= 1 &&
+            if (l == 12 && e->fuse_sep && e->fuse_next_dw && mode != 0 && e->sep_variant <= 1 &&
                 stop_stage < 0 && skip_dw_layer != l) {
                 float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
                 if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream)) {
@@ -739,16 +836,16 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
             // ... and when the NEXT layer is a stride-2 one, its depthwise is applied in that kernel's epilogue
             // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
-            if (e->fuse_sep && e->fuse_next_dw && e->pointwise_mode != 0 && e->sep_variant <= 1 && l + 1 < 13 &&
+            if (e->fuse_sep && e->fuse_next_dw && mode != 0 && e->sep_variant <= 1 && l + 1 < 13 &&
                 (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
-                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, e->sep[l + 1], e->l4_band_tiles, stream)) {
+                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream)) {
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 skip_dw_layer = l + 1;
                 last = buf_b;
-                last_floats = (int64_t)gw * e->sep[l + 1].h_out * e->sep[l + 1].w_out * L.cout;
+                last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * L.cout;
                 continue;
             }
-            if (e->fuse_sep && e->pointwise_mode != 0 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
+            if (e->fuse_sep && mode != 0 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
                 bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
@@ -779,7 +876,12 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
             if (stop_stage == 2 * l + 2) stopped = true;
         }
         if (stop_stage >= 0) {
-            BD_HIP(hipMemcpyAsync(tap_out, last, last_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            if (mode != 0 && (stop_stage & 1)) {
+                // a depthwise output of the f16 modes carries its layer's power-of-two activation scale: hand out the true values
+                bd::launch_scale_copy(last, tap_out, last_floats, std::ldexp(1.0f, -sep[(stop_stage - 1) / 2].act_exp), stream);
+            } else {
+                BD_HIP(hipMemcpyAsync(tap_out, last, last_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            }
             break;
         }
         if (!pooled_done) {
@@ -793,6 +895,143 @@ int run_chunks(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int
     return BD_OK;
 }
 
+// chunk pointers of the packed entry points: chunk c starts where chunk c - 1 ended
+int run_packed(bd_engine* e, const float* pcm, const int64_t* chunk_samples, int32_t n_chunks, int32_t hop, int32_t step,
+               void* ws, int64_t ws_bytes, float* emb, float* logits, int stop_stage, int tap_windows, float* tap_out,
+               hipStream_t stream) {
+    if (!chunk_samples || n_chunks <= 0 || n_chunks > bd::kMaxBatchChunks) return fail(BD_EINVAL, "batch must hold 1..64 chunks");
+    if (misaligned(pcm)) return fail(BD_EINVAL, "device pointers need 16-byte alignment");
+    const float* ptrs[bd::kMaxBatchChunks];
+    int64_t at = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        if (chunk_samples[c] < 0) return fail(BD_EINVAL, "n_samples must be >= 0");
+        if (!pcm && chunk_samples[c] > 0) return fail(BD_EINVAL, "null pcm pointer");
+        ptrs[c] = pcm ? pcm + at : nullptr;
+        at += chunk_samples[c];
+    }
+    return run_chunks(e, ptrs, chunk_samples, n_chunks, hop, step, ws, ws_bytes, emb, logits, stop_stage, tap_windows, tap_out,
+                      -1, nullptr, false, stream);
+}
+
+// ---- operand scaling of the f16 modes (SepLayer in bd_internal.h) ----
+
+// Exponent s with amax * 2^s in [2^8, 2^9): a factor 128 below the f16 overflow for inputs beyond the calibration set,
+// and hi + lo both normal f16 numbers (22-bit operands) for every activation down to 2^-11 of the layer's largest.
+int exponent_for(float amax) {
+    if (!(amax > 0.0f) || !(amax <= 3.0e38f)) return 0;
+    int ex = 0;
+    (void)std::frexp(amax, &ex);
+    const int s = 9 - ex;
+    return s > 60 ? 60 : (s < -60 ? -60 : s);
+}
+
+// Rebuilds the scaled depthwise copies and the epilogue factors from e->act_exp.  Blocking copies into the pool: only
+// call it while no work that uses the handle is in flight (bd_create, bd_calibrate, bd_set_activation_exponents).
+int apply_scales(bd_engine* e) {
+    BD_HIP(hipSetDevice(e->device));
+    std::vector<float> buf;
+    for (int l = 0; l < 13; ++l) {
+        bd::SepLayer& L = e->sep[l];
+        const int s = e->act_exp[l];
+        buf.resize(e->h_dw[l].size());
+        for (size_t i = 0; i < buf.size(); ++i) {
+            buf[i] = std::ldexp(e->h_dw[l][i], s);
+            if (!std::isfinite(buf[i])) return fail(BD_EWEIGHTS, "activation scale overflows a depthwise weight");
+        }
+        BD_HIP(hipMemcpy(e->d_pool + e->off_dw16[l], buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+        buf.resize(L.cout);
+        for (int n = 0; n < L.cout; ++n) buf[n] = std::ldexp(1.0f, -(s + e->row_exp[l][n]));
+        BD_HIP(hipMemcpy(e->d_pool + e->off_pw_u[l], buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.act_exp = s;
+    }
+    return BD_OK;
+}
+
+// One exact-f32 pass (one kernel per op) over the given chunks with the depthwise kernels reporting their largest
+// output; the per-layer maxima only ever grow, the exponents follow them.  Waits for the stream.
+int calibrate_on(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk_samples, int32_t n_chunks, int32_t hop,
+                 int32_t step, void* ws, int64_t ws_bytes, hipStream_t stream) {
+    BD_HIP(hipSetDevice(e->device));
+    BD_HIP(hipMemsetAsync(e->d_amax, 0, 64, stream));
+    const int rc = run_chunks(e, chunk_pcm, chunk_samples, n_chunks, hop, step, ws, ws_bytes, nullptr, nullptr, -1, 0, nullptr,
+                              0, nullptr, true, stream);
+    if (rc < 0) return rc;
+    unsigned words[16] = {0};
+    BD_HIP(hipMemcpyAsync(words, e->d_amax, 64, hipMemcpyDeviceToHost, stream));
+    BD_HIP(hipStreamSynchronize(stream));
+    for (int l = 0; l < 13; ++l) {
+        float m;
+        std::memcpy(&m, &words[l], sizeof(m));
+        if (m > e->act_max[l] && m <= 3.0e38f) e->act_max[l] = m;
+        e->act_exp[l] = exponent_for(e->act_max[l]);
+    }
+    return apply_scales(e);
+}
+
+// The signal bd_create calibrates on: sixteen 0.96 s windows that span what 16 kHz PCM in [-1, 1] can do to the log-mel
+// input (silence = the log(0.001) floor everywhere, full-scale noise = the ceiling everywhere, tones, clicks, a chirp,
+// a buzz-like square wave).  The CNN's input is a LOG spectrum, so a recording can leave this envelope only by a small
+// factor; the exponents keep a factor 128 in hand and the range word catches whatever goes beyond.
+std::vector<float> calibration_signal() {
+    const int seg = 15360, nseg = 16;
+    std::vector<float> x((size_t)seg * nseg + 240, 0.0f);
+    uint32_t lcg = 20260723u;
+    auto uni = [&]() {                                     // uniform in [-1, 1)
+        lcg = lcg * 1664525u + 1013904223u;
+        return (float)((int32_t)lcg) * (1.0f / 2147483648.0f);
+    };
+    const double w = 2.0 * M_PI / 16000.0;
+    for (int g = 0; g < nseg; ++g)
+        for (int i = 0; i < seg; ++i) {
+            const double t = i;
+            double v = 0.0;
+            switch (g) {
+                case 0: v = 0.0; break;
+                case 1: v = uni(); break;
+                case 2: v = 0.1 * uni(); break;
+                case 3: v = 0.01 * uni(); break;
+                case 4: v = 0.001 * uni(); break;
+                case 5: v = 0.9 * std::sin(w * 220.0 * t); break;
+                case 6: v = 0.5 * std::sin(w * 1000.0 * t) + 0.05 * uni(); break;
+                case 7: v = 0.9 * std::sin(w * 4000.0 * t); break;
+                case 8: v = 0.7 * std::sin(w * (100.0 + 6900.0 * t / (2.0 * seg)) * t); break;
+                case 9: v = i % 1000 == 0 ? 1.0 : 0.0; break;
+                case 10: v = std::sin(w * 300.0 * t) >= 0.0 ? 1.0 : -1.0; break;
+                case 11: v = 0.3 * uni() * (0.5 + 0.5 * std::sin(w * 200.0 * t)); break;
+                case 12: v = 0.5 + 0.0001 * uni(); break;
+                case 13: v = 0.8 * std::sin(w * 50.0 * t) + 0.2 * std::sin(w * 150.0 * t); break;
+                case 14: v = uni() >= 0.0f ? 1.0 : -1.0; break;
+                default: v = uni() * t / seg; break;
+            }
+            v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);
+            x[(size_t)g * seg + i] = (float)v;
+        }
+    return x;
+}
+
+int calibrate_builtin(bd_engine* e) {
+    const std::vector<float> sig = calibration_signal();
+    const int64_t n = (int64_t)sig.size();
+    const int32_t hop = 15360, step = 96;
+    const int64_t ws_bytes = bd_workspace_bytes(e, n, hop, step);
+    if (ws_bytes < 0) return (int)ws_bytes;
+    float* d_pcm = nullptr;
+    void* d_ws = nullptr;
+    hipError_t err = hipMalloc(&d_pcm, sig.size() * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&d_ws, (size_t)ws_bytes);
+    if (err == hipSuccess) err = hipMemcpy(d_pcm, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice);
+    int rc = BD_OK;
+    if (err != hipSuccess) {
+        rc = fail(BD_EHIP, std::string("bd_create (calibration): ") + hipGetErrorString(err));
+    } else {
+        const float* ptr = d_pcm;
+        rc = calibrate_on(e, &ptr, &n, 1, hop, step, d_ws, ws_bytes, nullptr);
+    }
+    if (d_pcm) (void)hipFree(d_pcm);
+    if (d_ws) (void)hipFree(d_ws);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -800,14 +1039,14 @@ extern "C" {
 int bd_embed(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
              void* workspace_dev, int64_t workspace_bytes, float* emb_dev, void* stream) {
     if (!emb_dev) return fail(BD_EINVAL, "bd_embed: null output");
-    return run_chunks(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
+    return run_packed(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
                       nullptr, -1, 0, nullptr, (hipStream_t)stream);
 }
 
 int bd_predict(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
                void* workspace_dev, int64_t workspace_bytes, float* emb_dev, float* logits_dev, void* stream) {
     if (!logits_dev) return fail(BD_EINVAL, "bd_predict: null output");
-    return run_chunks(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
+    return run_packed(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, emb_dev,
                       logits_dev, -1, 0, nullptr, (hipStream_t)stream);
 }
 
@@ -834,8 +1073,44 @@ int bd_predict_batch(bd_handle h, const float* pcm_dev, const int64_t* chunk_sam
                      int32_t hop_samples, int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
                      float* emb_dev, float* logits_dev, void* stream) {
     if (!logits_dev && !emb_dev) return fail(BD_EINVAL, "bd_predict_batch: no output requested");
-    return run_chunks(h, pcm_dev, chunk_samples, n_chunks, hop_samples, patch_step, workspace_dev, workspace_bytes,
+    return run_packed(h, pcm_dev, chunk_samples, n_chunks, hop_samples, patch_step, workspace_dev, workspace_bytes,
                       emb_dev, logits_dev, -1, 0, nullptr, (hipStream_t)stream);
+}
+
+int bd_predict_chunks(bd_handle h, const float* const* chunk_pcm_dev, const int64_t* chunk_samples, int32_t n_chunks,
+                      int32_t hop_samples, int32_t patch_step, void* workspace_dev, int64_t workspace_bytes, float* emb_dev,
+                      float* logits_dev, int32_t mode, int32_t* range_word, void* stream) {
+    if (!logits_dev && !emb_dev) return fail(BD_EINVAL, "bd_predict_chunks: no output requested");
+    if (!chunk_pcm_dev || !chunk_samples || n_chunks <= 0 || n_chunks > bd::kMaxBatchChunks)
+        return fail(BD_EINVAL, "batch must hold 1..64 chunks");
+    return run_chunks(h, chunk_pcm_dev, chunk_samples, n_chunks, hop_samples, patch_step, workspace_dev, workspace_bytes,
+                      emb_dev, logits_dev, -1, 0, nullptr, mode, range_word, false, (hipStream_t)stream);
+}
+
+int bd_calibrate(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
+                 void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    if (!h) return fail(BD_EINVAL, "bd_calibrate: null handle");
+    if (!pcm_dev && n_samples > 0) return fail(BD_EINVAL, "bd_calibrate: null pcm pointer");
+    if (misaligned(pcm_dev)) return fail(BD_EINVAL, "device pointers need 16-byte alignment");
+    return calibrate_on(h, &pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes,
+                        (hipStream_t)stream);
+}
+
+int bd_get_scales(bd_handle h, int32_t* act_exp, float* act_max) {
+    if (!h) return fail(BD_EINVAL, "bd_get_scales: null handle");
+    for (int l = 0; l < 13; ++l) {
+        if (act_exp) act_exp[l] = h->act_exp[l];
+        if (act_max) act_max[l] = h->act_max[l];
+    }
+    return 13;
+}
+
+int bd_set_activation_exponents(bd_handle h, const int32_t* act_exp) {
+    if (!h || !act_exp) return fail(BD_EINVAL, "bd_set_activation_exponents: null argument");
+    for (int l = 0; l < 13; ++l)
+        if (act_exp[l] < -60 || act_exp[l] > 60) return fail(BD_EINVAL, "bd_set_activation_exponents: exponent outside -60..60");
+    for (int l = 0; l < 13; ++l) h->act_exp[l] = act_exp[l];
+    return apply_scales(h);
 }
 
 int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
@@ -843,7 +1118,7 @@ int bd_stage_tap(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t h
                  void* stream) {
     if (!out_dev) return fail(BD_EINVAL, "bd_stage_tap: null output");
     if (stage < 0 || stage >= BD_NUM_STAGES) return fail(BD_EINVAL, "bd_stage_tap: stage out of range");
-    return run_chunks(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, nullptr,
+    return run_packed(h, pcm_dev, &n_samples, 1, hop_samples, patch_step, workspace_dev, workspace_bytes, nullptr,
                       nullptr, stage, windows, out_dev, (hipStream_t)stream);
 }
 
@@ -905,11 +1180,12 @@ int bd_set_pointwise_mode(bd_handle h, int32_t mode) {
     return BD_OK;
 }
 
-int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, const void* wlo_dev, const float* bias_dev,
-                             float* c_dev, int64_t m, int32_t n, int32_t k, int32_t variant, void* stream) {
-    if (!a_dev || !whi_dev || !wlo_dev || !bias_dev || !c_dev || m < 0)
+int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, const void* wlo_dev, const float* unscale_dev,
+                             const float* bias_dev, float* c_dev, int64_t m, int32_t n, int32_t k, int32_t variant,
+                             void* stream) {
+    if (!a_dev || !whi_dev || !wlo_dev || !unscale_dev || !bias_dev || !c_dev || m < 0)
         return fail(BD_EINVAL, "bd_debug_pointwise_f16x3: bad argument");
-    if (bd::launch_pointwise_f16x3_variant(a_dev, whi_dev, wlo_dev, bias_dev, c_dev, m, n, k, variant,
+    if (bd::launch_pointwise_f16x3_variant(a_dev, whi_dev, wlo_dev, unscale_dev, bias_dev, c_dev, m, n, k, variant,
                                            (hipStream_t)stream) != 0)
         return fail(BD_EINVAL, "bd_debug_pointwise_f16x3: shape/variant not supported");
     BD_HIP(hipGetLastError());

@@ -9,7 +9,8 @@ Replaces, behind the reference's plugin surface (see ``buzzdetect_amd/dropin``):
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+import threading
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -32,37 +33,107 @@ def patch_step(framehop_s: float) -> int:
     return int(round(spectrogram_sample_rate * framehop_s))
 
 
+class _VerdictPool:
+    """(pinned int32 word, HIP event) pairs for the range verdicts, recycled.
+
+    The kernels of a launch set write their word straight across PCIe (only when a chunk does leave the range), which
+    PyTorch knows nothing about, so the caching host allocator must not get the memory back while those kernels may still
+    run: a pair is reused only once the event recorded behind its launch set has completed.  Events are recycled with
+    their words - a fresh event per launch makes the HIP runtime grow its signal pool while the host runs ahead of the
+    GPU, a one-off stall of tens of milliseconds in the middle of a run."""
+
+    BLOCK = 256
+
+    def __init__(self):
+        from collections import deque
+        self._lock = threading.Lock()
+        self._idle: "deque" = deque()         # (word, event) given back, oldest first; the event may still be pending
+        self._blocks: list = []
+        self._next = 0
+
+    def take(self):
+        with self._lock:
+            if self._idle and self._idle[0][1].query():
+                word, event = self._idle.popleft()
+            else:
+                if not self._blocks or self._next == self.BLOCK:
+                    self._blocks.append(torch.zeros(self.BLOCK, dtype=torch.int32, pin_memory=True))
+                    self._next = 0
+                word = self._blocks[-1][self._next:self._next + 1]
+                self._next += 1
+                event = torch.cuda.Event()
+        word[0] = 0
+        return word, event
+
+    def give_back(self, word: torch.Tensor, event: "torch.cuda.Event") -> None:
+        with self._lock:
+            self._idle.append((word, event))
+
+
+_verdicts = _VerdictPool()
+
+
+class LaunchVerdict:
+    """The range word of ONE launch set (``bd_predict_chunks``): a pinned int32 that only this set's kernels can raise,
+    and the event that says they have all finished.  Every DeviceResult of the set shares it, nobody
+    resets anything: whichever thread reads a result later - the reference's writer does, src/write/worker.py:69, while the
+    analyzer has long enqueued the next chunk, src/inference/worker.py:71-74 - learns about exactly its own launches."""
+
+    def __init__(self, stream: torch.cuda.Stream):
+        self.word, self.event = _verdicts.take()
+        self.stream = stream
+
+    def wait(self) -> bool:
+        """Blocks until the launch set has finished; True when one of its activations left the f16 range."""
+        self.event.synchronize()
+        return int(self.word[0]) != 0
+
+    def __del__(self):
+        try:
+            _verdicts.give_back(self.word, self.event)
+        except Exception:                      # interpreter shutdown
+            pass
+
+
 class DeviceResult:
     """What ``predict``/``embed`` hand back: a device tensor that also answers ``.numpy()``,
     the one method the reference's writer calls on results (src/write/worker.py:69).
 
-    ``redo``: how to recompute the rows in exact-f32 arithmetic; ``.numpy()`` uses it when the engine reports that an
-    activation left the f16 range while these rows were computed (``HipEngine.range_exceeded``)."""
+    ``verdict``: the range word of the launch set that computed the rows.  ``redo``: how to recompute them with exact-f32
+    products (on the stream they were computed on, with a per-call mode: the engine's own state is not touched, so it is
+    safe from a thread other than the one that keeps predicting); ``.numpy()`` uses it when the verdict says so."""
 
     def __init__(self, tensor: torch.Tensor, stream: torch.cuda.Stream, engine: "Optional[HipEngine]" = None,
-                 redo=None):
+                 redo=None, verdict: Optional[LaunchVerdict] = None):
         self.tensor = tensor
         self._stream = stream
         self._host: Optional[np.ndarray] = None
         self._engine = engine
         self._redo = redo
+        self._verdict = verdict
+        self._lock = threading.Lock()
+        if verdict is None:                   # results that never pass through the f16 path (mode f32, resample ...)
+            self._done = torch.cuda.Event()
+            self._done.record(stream)
 
     @property
     def shape(self) -> Tuple[int, ...]:
         return tuple(self.tensor.shape)
 
     def numpy(self) -> np.ndarray:
-        if self._host is None:
-            self._stream.synchronize()
-            if self._engine is not None and self._redo is not None and self._engine.range_exceeded(self._stream):
-                # an activation beyond 65 504 went through the f16 matrix path: these rows may be garbage (and a ReLU
-                # can hide it).  Compute them again with exact f32 products.
-                self._engine.overflow_reruns += 1
-                self.tensor = self._redo()
-                torch.cuda.current_stream(self.tensor.device).synchronize()
-            self._redo = None
-            self._host = self.tensor.cpu().numpy()
-        return self._host
+        with self._lock:
+            if self._host is None:
+                if self._verdict is not None and self._verdict.wait() and self._redo is not None:
+                    # an activation beyond the f16 range went through the matrix path: these rows may be garbage (and a
+                    # ReLU can hide it).  Compute them again with exact f32 products.
+                    self.tensor = self._redo()
+                    if self._engine is not None:
+                        self._engine.overflow_reruns += 1
+                elif self._verdict is None:
+                    self._done.synchronize()
+                self._redo = None
+                self._host = self.tensor.cpu().numpy()
+            return self._host
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
@@ -103,7 +174,11 @@ class HipEngine:
             w.n_classes = hb.size
             self.classes = head.classes
             self.n_classes = int(hb.size)
-        _lib.check(self._lib.bd_create(C.byref(self._handle), self.device_index, C.byref(w)))
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.bd_create(C.byref(self._handle), self.device_index, C.byref(w)))
+        # the handle is not thread-safe (include/buzzdetect_hip.h): every call that takes it goes through this lock, so a
+        # writer thread that repeats a flagged chunk cannot interleave with the analyzer thread's next predict
+        self._lock = threading.RLock()
         self._workspace: Optional[torch.Tensor] = None
         self._mode = "f16x3"
         self.overflow_reruns = 0          # results recomputed in exact f32 because an activation left the f16 range
@@ -127,49 +202,75 @@ class HipEngine:
 
     # ------------------------------------------------------------------ helpers
     def set_group_windows(self, windows: int) -> None:
-        _lib.check(self._lib.bd_set_group_windows(self._handle, int(windows)))
+        with self._lock:
+            _lib.check(self._lib.bd_set_group_windows(self._handle, int(windows)))
 
     POINTWISE_MODES = ("f32", "f16x3", "f16")
+
+    MODE_CODES = {"f32": 0, "f16x3": 1, "f16": 2}
 
     def set_pointwise_mode(self, mode: str) -> None:
         """'f32' = exact f32 MFMA products; 'f16x3' = split-f16 MFMA (default, same accuracy class); 'f16' = plain f16
         operands, one MFMA per product (config 5; ~1e-3 on the logits)."""
-        _lib.check(self._lib.bd_set_pointwise_mode(self._handle, {"f32": 0, "f16x3": 1, "f16": 2}[mode]))
-        self._mode = mode
+        with self._lock:
+            _lib.check(self._lib.bd_set_pointwise_mode(self._handle, self.MODE_CODES[mode]))
+            self._mode = mode
+
+    # ------------------------------------------------------------------ operand scales of the f16 modes
+    def scales(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(act_exp[13], act_max[13]) for layers 2..14: the power-of-two exponent each layer's GEMM input is scaled by and
+        the largest activation the calibration passes saw there (``bd_get_scales``)."""
+        ex = (C.c_int32 * 13)()
+        mx = (C.c_float * 13)()
+        with self._lock:
+            _lib.check(self._lib.bd_get_scales(self._handle, ex, mx))
+        return np.array(ex[:], dtype=np.int32), np.array(mx[:], dtype=np.float32)
+
+    def set_activation_exponents(self, exps: Sequence[int]) -> None:
+        """Test hook (``bd_set_activation_exponents``): override the calibrated exponents; synchronises the device."""
+        arr = (C.c_int32 * 13)(*[int(v) for v in exps])
+        with self._lock, torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            _lib.check(self._lib.bd_set_activation_exponents(self._handle, arr))
+
+    def calibrate(self, samples, framehop_s: float = 0.96) -> None:
+        """Widen the activation scales with a pass over ``samples`` in exact-f32 arithmetic (``bd_calibrate``).  Call it
+        while nothing else is in flight on this engine."""
+        hop, step = hop_samples(framehop_s), patch_step(framehop_s)
+        x = self.to_device(samples)
+        with self._lock, torch.cuda.device(self.device):
+            ws_bytes = _lib.check(self._lib.bd_workspace_bytes(self._handle, x.numel(), hop, step))
+            ws = self._ws(ws_bytes)
+            torch.cuda.synchronize(self.device)
+            _lib.check(self._lib.bd_calibrate(self._handle, x.data_ptr(), x.numel(), hop, step, ws.data_ptr(), ws.numel(),
+                                              self._stream().cuda_stream))
 
     def range_exceeded(self, stream: Optional[torch.cuda.Stream] = None, reset: bool = True) -> bool:
         """Did any launch since the last reset convert an activation beyond the f16 range (modes 'f16x3' / 'f16')?
         Waits for ``stream``."""
         flag = C.c_int32(0)
         s = stream or self._stream()
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):
             _lib.check(self._lib.bd_range_flag(self._handle, C.byref(flag), 1 if reset else 0, s.cuda_stream))
         return bool(flag.value)
 
     def range_flag_to(self, dst: torch.Tensor, reset: bool = False) -> None:
         """Enqueue (no wait) a copy of the range word into ``dst`` (int32, device or pinned host) on the current stream."""
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):
             _lib.check(self._lib.bd_range_flag_copy(self._handle, dst.data_ptr(), 1 if reset else 0,
                                                     self._stream().cuda_stream))
-
-    def _exact(self, fn):
-        """Run ``fn`` with exact-f32 products, whatever mode the engine is in."""
-        mode = getattr(self, "_mode", "f16x3")
-        self.set_pointwise_mode("f32")
-        try:
-            return fn()
-        finally:
-            self.set_pointwise_mode(mode)
 
     def set_fusion(self, stem=True, separable=True) -> None:
         """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, False = off) and fused
         depthwise+pointwise kernels (True = default path, 2 = the same with layer 4 as band tiles of the generic kernel,
         9 / 12 = plain fused layers on the 8-wave / 12-wave kernel, False = one kernel per op)."""
         stem_code = 3 if stem is True else int(stem)
-        _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))
+        with self._lock:
+            _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))
 
     def set_pointwise_variant(self, layer: int, variant: int) -> None:
-        _lib.check(self._lib.bd_set_pointwise_variant(self._handle, int(layer), int(variant)))
+        with self._lock:
+            _lib.check(self._lib.bd_set_pointwise_variant(self._handle, int(layer), int(variant)))
 
     def num_windows(self, n_samples: int, hop: int, step: int) -> int:
         return _lib.check(self._lib.bd_num_windows(int(n_samples), int(hop), int(step)))
@@ -244,7 +345,7 @@ class HipEngine:
         n_out = _lib.check(self._lib.bd_resample_length(n_in, int(rate_in), int(rate_out)))
         out = torch.empty(max(n_out, 1), dtype=torch.float32, device=self.device)[:n_out]
         fn = self._lib.bd_resample_s16 if is_s16 else self._lib.bd_resample
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):      # (the first use of a rate ratio adds its filter to the handle)
             _lib.check(fn(self._handle, t.data_ptr(), n_in, channels, int(rate_in), int(rate_out),
                           out.data_ptr(), self._stream().cuda_stream))
         t.record_stream(self._stream())
@@ -256,7 +357,7 @@ class HipEngine:
         x = self.to_device(samples)
         t = self.num_frames(x.numel(), hop)
         out = torch.empty((t, _lib.MEL_BANDS), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):
             _lib.check(self._lib.bd_frontend(self._handle, x.data_ptr(), x.numel(), hop, out.data_ptr(),
                                              self._stream().cuda_stream))
         return out
@@ -271,91 +372,105 @@ class HipEngine:
                                             self._stream().cuda_stream))
         return out
 
-    def run(self, samples, hop: int, step: int, want_embeddings: bool, want_logits: bool,
-            out: Optional[torch.Tensor] = None):
-        x = self.to_device(samples)
-        n = x.numel()
-        w = self.num_windows(n, hop, step)
-        ws_bytes = _lib.check(self._lib.bd_workspace_bytes(self._handle, n, hop, step))
-        ws = self._ws(ws_bytes)
-        emb = torch.empty((w, _lib.EMBEDDING_SIZE), dtype=torch.float32, device=self.device) if want_embeddings else None
-        logits = None
+    def launch(self, parts: List[torch.Tensor], hop: int, step: int, want_embeddings: bool, want_logits: bool,
+               out: Optional[torch.Tensor] = None, mode: Optional[str] = None, verdict: Optional[LaunchVerdict] = None):
+        """One launch set over ``parts`` (device tensors, one per chunk; nothing is concatenated) on the current stream
+        (``bd_predict_chunks``).  ``mode``: arithmetic for this call only.  ``verdict``: takes this call's range word.
+        Returns (embeddings or None, logits or None, windows per chunk)."""
+        if not 1 <= len(parts) <= 64:
+            raise ValueError("a launch set takes 1..64 chunks")
+        if want_logits and self.n_classes == 0:
+            raise RuntimeError("engine was created without a classifier head")
+        nc = len(parts)
+        lengths = (C.c_int64 * nc)(*[int(p.numel()) for p in parts])
+        ptrs = (C.c_void_p * nc)(*[p.data_ptr() if p.numel() else None for p in parts])
+        per = (C.c_int64 * nc)()
+        total = _lib.check(self._lib.bd_batch_num_windows(lengths, nc, hop, step, per))
         stream = self._stream()
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):
+            ws_bytes = _lib.check(self._lib.bd_batch_workspace_bytes(self._handle, lengths, nc, hop, step))
+            ws = self._ws(ws_bytes)
+            emb = torch.empty((total, _lib.EMBEDDING_SIZE), dtype=torch.float32, device=self.device) if want_embeddings else None
+            logits = None
             if want_logits:
-                if self.n_classes == 0:
-                    raise RuntimeError("engine was created without a classifier head")
                 if out is None:
-                    logits = torch.empty((w, self.n_classes), dtype=torch.float32, device=self.device)
+                    logits = torch.empty((total, self.n_classes), dtype=torch.float32, device=self.device)
                 else:       # caller-owned rows (e.g. a slice of a per-recording buffer that is gathered later)
-                    if (tuple(out.shape) != (w, self.n_classes) or out.dtype != torch.float32 or
+                    if (tuple(out.shape) != (total, self.n_classes) or out.dtype != torch.float32 or
                             out.device != self.device or not out.is_contiguous() or out.data_ptr() % 16):
-                        raise ValueError(f"out must be a contiguous, 16-byte aligned float32 [{w}, {self.n_classes}] "
+                        raise ValueError(f"out must be a contiguous, 16-byte aligned float32 [{total}, {self.n_classes}] "
                                          f"tensor on {self.device}")
                     logits = out
-                _lib.check(self._lib.bd_predict(self._handle, x.data_ptr(), n, hop, step, ws.data_ptr(), ws.numel(),
-                                                emb.data_ptr() if emb is not None else None, logits.data_ptr(),
-                                                stream.cuda_stream))
-            else:
-                _lib.check(self._lib.bd_embed(self._handle, x.data_ptr(), n, hop, step, ws.data_ptr(), ws.numel(),
-                                              emb.data_ptr(), stream.cuda_stream))
-        x.record_stream(stream)
+            _lib.check(self._lib.bd_predict_chunks(
+                self._handle, ptrs, lengths, nc, hop, step, ws.data_ptr(), ws.numel(),
+                emb.data_ptr() if emb is not None else None, logits.data_ptr() if logits is not None else None,
+                -1 if mode is None else self.MODE_CODES[mode],
+                verdict.word.data_ptr() if verdict is not None else None, stream.cuda_stream))
+            if verdict is not None:
+                verdict.event.record(stream)
+        for p in parts:
+            p.record_stream(stream)
+        return emb, logits, [int(v) for v in per]
+
+    def run(self, samples, hop: int, step: int, want_embeddings: bool, want_logits: bool,
+            out: Optional[torch.Tensor] = None, mode: Optional[str] = None, verdict: Optional[LaunchVerdict] = None):
+        emb, logits, _ = self.launch([self.to_device(samples)], hop, step, want_embeddings, want_logits, out, mode, verdict)
         return emb, logits
 
-    def predict_batch(self, chunks, framehop_s: float, want_embeddings: bool = False):
-        """Several chunks through one launch set (``bd_predict_batch``): each chunk keeps its own end-of-chunk
+    def _redo_on(self, stream: torch.cuda.Stream, part: torch.Tensor, hop: int, step: int, embeddings: bool,
+                 out: Optional[torch.Tensor] = None):
+        """The exact-f32 repeat of one chunk: enqueued on the stream the chunk was computed on (behind whatever the
+        owning thread has queued there since - same workspace, stream order keeps it safe), waited for, returned."""
+        def run():
+            with torch.cuda.stream(stream):
+                e, l = self.run(part, hop, step, embeddings, not embeddings, out=out, mode="f32")
+                done = torch.cuda.Event()
+                done.record(stream)
+            done.synchronize()
+            return e if embeddings else l
+        return run
+
+    def predict_batch(self, chunks, framehop_s: float, want_embeddings: bool = False, mode: Optional[str] = None):
+        """Several chunks through one launch set (``bd_predict_chunks``): each chunk keeps its own end-of-chunk
         zero padding, so the rows are exactly those of one ``predict`` per chunk.  Returns one DeviceResult per
-        chunk (views of one device tensor); with ``want_embeddings`` a second list with the embeddings."""
+        chunk (views of one device tensor); with ``want_embeddings`` a second list with the embeddings.  The results
+        share the launch set's range word; a flagged set repeats chunk by chunk, each when it is read."""
         if not 1 <= len(chunks) <= 64:
             raise ValueError("predict_batch takes 1..64 chunks")
         hop, step = hop_samples(framehop_s), patch_step(framehop_s)
         parts = [self.to_device(c) for c in chunks]
-        lengths = (C.c_int64 * len(parts))(*[int(p.numel()) for p in parts])
-        x = parts[0] if len(parts) == 1 else torch.cat(parts)
-        if x.data_ptr() % 16:
-            x = x.clone()
-        per = (C.c_int64 * len(parts))()
-        total = _lib.check(self._lib.bd_batch_num_windows(lengths, len(parts), hop, step, per))
-        ws_bytes = _lib.check(self._lib.bd_batch_workspace_bytes(self._handle, lengths, len(parts), hop, step))
-        ws = self._ws(ws_bytes)
-        if self.n_classes == 0:
-            raise RuntimeError("engine was created without a classifier head")
-        logits = torch.empty((total, self.n_classes), dtype=torch.float32, device=self.device)
-        emb = torch.empty((total, _lib.EMBEDDING_SIZE), dtype=torch.float32, device=self.device) if want_embeddings else None
         stream = self._stream()
-        with torch.cuda.device(self.device):
-            _lib.check(self._lib.bd_predict_batch(self._handle, x.data_ptr(), lengths, len(parts), hop, step,
-                                                  ws.data_ptr(), ws.numel(), emb.data_ptr() if emb is not None else None,
-                                                  logits.data_ptr(), stream.cuda_stream))
-        x.record_stream(stream)
-        counts = [int(v) for v in per]
-        f16 = self._mode != "f32"
+        f16 = (mode or self._mode) != "f32"
+        verdict = LaunchVerdict(stream) if f16 else None
+        emb, logits, counts = self.launch(parts, hop, step, want_embeddings, True, mode=mode, verdict=verdict)
 
         def redo_chunk(i: int, embeddings: bool):
-            def run():
-                e, l = self._exact(lambda: self.run(parts[i], hop, step, embeddings, not embeddings))
-                return e if embeddings else l
-            return run if f16 else None
+            return self._redo_on(stream, parts[i], hop, step, embeddings) if f16 else None
 
-        out = [DeviceResult(t, stream, self, redo_chunk(i, False)) for i, t in enumerate(torch.split(logits, counts))]
+        out = [DeviceResult(t, stream, self, redo_chunk(i, False), verdict) for i, t in enumerate(torch.split(logits, counts))]
         if want_embeddings:
-            return out, [DeviceResult(t, stream, self, redo_chunk(i, True)) for i, t in enumerate(torch.split(emb, counts))]
+            return out, [DeviceResult(t, stream, self, redo_chunk(i, True), verdict)
+                         for i, t in enumerate(torch.split(emb, counts))]
         return out
 
     def embed(self, samples, framehop_s: float) -> DeviceResult:
         hop, step = hop_samples(framehop_s), patch_step(framehop_s)
         x = self.to_device(samples)
-        emb, _ = self.run(x, hop, step, True, False)
-        redo = (lambda: self._exact(lambda: self.run(x, hop, step, True, False))[0]) if self._mode != "f32" else None
-        return DeviceResult(emb, self._stream(), self, redo)
+        stream = self._stream()
+        f16 = self._mode != "f32"
+        verdict = LaunchVerdict(stream) if f16 else None
+        emb, _ = self.run(x, hop, step, True, False, verdict=verdict)
+        return DeviceResult(emb, stream, self, self._redo_on(stream, x, hop, step, True) if f16 else None, verdict)
 
     def predict(self, samples, framehop_s: float, out: Optional[torch.Tensor] = None) -> DeviceResult:
         """``out``: optional caller-owned ``[W, n_classes]`` device rows to write the logits into."""
         hop, step = hop_samples(framehop_s), patch_step(framehop_s)
         x = self.to_device(samples)
-        _, logits = self.run(x, hop, step, False, True, out=out)
-        redo = (lambda: self._exact(lambda: self.run(x, hop, step, False, True, out=out))[1]) if self._mode != "f32" else None
-        return DeviceResult(logits, self._stream(), self, redo)
+        stream = self._stream()
+        f16 = self._mode != "f32"
+        verdict = LaunchVerdict(stream) if f16 else None
+        _, logits = self.run(x, hop, step, False, True, out=out, verdict=verdict)
+        return DeviceResult(logits, stream, self, self._redo_on(stream, x, hop, step, False, out=out) if f16 else None, verdict)
 
     def stage_tap(self, samples, hop: int, step: int, stage: int, windows: int) -> torch.Tensor:
         """Test hook: NHWC activation after CNN stage ``stage`` for the first ``windows`` windows."""
@@ -363,9 +478,9 @@ class HipEngine:
         h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self._lib.bd_stage_shape(stage, C.byref(h), C.byref(w), C.byref(c)))
         out = torch.empty((windows, h.value, w.value, c.value), dtype=torch.float32, device=self.device)
-        ws_bytes = _lib.check(self._lib.bd_workspace_bytes(self._handle, x.numel(), hop, step))
-        ws = self._ws(ws_bytes)
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):
+            ws_bytes = _lib.check(self._lib.bd_workspace_bytes(self._handle, x.numel(), hop, step))
+            ws = self._ws(ws_bytes)
             _lib.check(self._lib.bd_stage_tap(self._handle, x.data_ptr(), x.numel(), hop, step, ws.data_ptr(),
                                               ws.numel(), stage, windows, out.data_ptr(),
                                               self._stream().cuda_stream))
@@ -373,10 +488,12 @@ class HipEngine:
 
     # ------------------------------------------------------------------ timing
     def profile_enable(self, on: bool) -> None:
-        _lib.check(self._lib.bd_profile_enable(self._handle, 1 if on else 0))
+        with self._lock:
+            _lib.check(self._lib.bd_profile_enable(self._handle, 1 if on else 0))
 
     def profile_read(self):
         ms = (C.c_double * _lib.PROFILE_SLOTS)()
         cnt = (C.c_int64 * _lib.PROFILE_SLOTS)()
-        _lib.check(self._lib.bd_profile_read(self._handle, ms, cnt, _lib.PROFILE_SLOTS))
+        with self._lock:
+            _lib.check(self._lib.bd_profile_read(self._handle, ms, cnt, _lib.PROFILE_SLOTS))
         return np.array(ms[:], dtype=np.float64), np.array(cnt[:], dtype=np.int64)

@@ -299,6 +299,7 @@ class Pipeline:
         held: List[int] = []
         try:
             log.info(f"analyzer {aid}: launching")
+            from .engine import LaunchVerdict
             engine = self.make_engine()                    # per-thread engine, initialised in-thread
             device = engine.device
             stream = torch.cuda.Stream(device)
@@ -311,19 +312,15 @@ class Pipeline:
 
             def settle(p) -> None:
                 """Forward a batch to the writer once it is known to be sound: the f16 matrix path cannot represent an
-                activation beyond 65 504 (engine.range_exceeded); such a batch is computed again with exact f32 products.
-                Runs while the NEXT batch occupies the GPU, so the wait costs nothing."""
-                item, word, pcms = p
-                item.done.synchronize()
-                if int(word[0]) != 0:
+                activation beyond its calibrated headroom (the batch's own range word, LaunchVerdict); such a batch is
+                computed again with exact f32 products.  Runs while the NEXT batch occupies the GPU, so the wait costs
+                nothing."""
+                item, verdict, pcms = p
+                if verdict.wait():
                     log.warning(f"analyzer {aid}: an activation left the f16 range; recomputing {len(item.tasks)} chunk(s) in exact f32")
                     with torch.cuda.stream(stream):
-                        again = engine._exact(lambda: engine.predict_batch(pcms, self.framehop_s))
-                        base = again[0].tensor
-                        total = sum(item.counts)
-                        whole = torch.as_strided(base, (total, n_classes), (n_classes, 1), base.storage_offset())
+                        _, whole, _ = engine.launch(pcms, self.hop, self.step, False, True, mode="f32")
                         torch.from_numpy(item.host).copy_(whole, non_blocking=True)
-                        engine.range_flag_to(word, reset=True)
                         item.done = torch.cuda.Event()
                         item.done.record(stream)
                     engine.overflow_reruns += 1
@@ -375,17 +372,12 @@ class Pipeline:
                             pcms.append(engine.resample(view, t.rate, 16000))     # also s16 -> f32 and the channel mean
                         else:
                             pcms.append(view[:, 0])
-                    res = engine.predict_batch(pcms, self.framehop_s)
-                    counts = [len(r) for r in res]
+                    verdict = LaunchVerdict(stream)
+                    _, whole, counts = engine.launch(pcms, self.hop, self.step, False, True, verdict=verdict)
                     total = sum(counts)
                     host = torch.empty((max(total, 1), n_classes), dtype=torch.float32, pin_memory=True)[:total]
                     if total:
-                        # the per-chunk results are consecutive row blocks of one device tensor
-                        base = res[0].tensor
-                        whole = torch.as_strided(base, (total, n_classes), (n_classes, 1), base.storage_offset())
                         host.copy_(whole, non_blocking=True)
-                    word = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-                    engine.range_flag_to(word)
                     done = torch.cuda.Event()
                     done.record(stream)
                 # the pinned slots go back to the ring when the batch's event has fired (the writer waits for it anyway);
@@ -394,7 +386,7 @@ class Pipeline:
                 held = []
                 if pending is not None:
                     settle(pending)
-                pending = (item, word, pcms)
+                pending = (item, verdict, pcms)
                 t_wait = time.perf_counter()
             if pending is not None:
                 settle(pending)

@@ -21,7 +21,12 @@
  *                                                            embedders/yamnet/embedder.py:33-44
  *   bd_predict               <- ModelGeneralV3.predict       models/model_general_v3/model.py:18-31
  *   bd_predict_batch         <- WorkerInferer.process_chunk over several queued chunks
+ *   bd_predict_chunks           (the same with one pointer per chunk: AssignChunk.samples as the streamer made them,
+ *                                src/stream/worker.py:129-133, and this call's own range word for the writer thread
+ *                                that reads the results later, src/write/worker.py:69)
  *                                                            src/inference/worker.py:71-92, src/analyze.py:218-253
+ *   bd_calibrate             <- (no counterpart: TensorFlow computes the 1x1 convolutions in float32,
+ *                                embedders/yamnet/yamnet.py:64-70; the f16 matrix path needs operand scales)
  *   bd_stage_tap             <- (test hook) any intermediate activation of yamnet()
  *                                                            embedders/yamnet/yamnet.py:96-103
  *
@@ -45,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 1
+#define BD_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define BD_API __attribute__((visibility("default")))
@@ -156,6 +161,18 @@ BD_API int64_t bd_batch_workspace_bytes(bd_handle h, const int64_t* chunk_sample
 BD_API int bd_predict_batch(bd_handle h, const float* pcm_dev, const int64_t* chunk_samples, int32_t n_chunks,
                             int32_t hop_samples, int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
                             float* emb_dev, float* logits_dev, void* stream);
+/* The general form.  chunk_pcm_dev: HOST array of n_chunks device pointers, one per chunk (4-byte aligned; the chunks need
+   not be adjacent, so nothing is concatenated on the device).  mode: arithmetic of the 1x1 convolutions for THIS call
+   only, -1 = the handle's (bd_set_pointwise_mode) - the exact-f32 repeat of a flagged chunk does not touch the handle's
+   state.  range_word: int32 in device memory or in PINNED (device-mapped) host memory, or NULL.  When given, this call's
+   kernels raise THAT word (they store 1 into it; the caller zeroes it beforehand) instead of the engine's sticky one
+   (see bd_range_flag): the word says whether THIS call left the f16 range, however many other calls are queued behind it
+   when somebody finally looks - the reference reads results on its writer thread while the analyzer has already
+   enqueued the next chunk.  No copy and no reset is enqueued: a pinned word costs nothing unless a chunk overflows.
+   Read it after an event recorded behind the call. */
+BD_API int bd_predict_chunks(bd_handle h, const float* const* chunk_pcm_dev, const int64_t* chunk_samples, int32_t n_chunks,
+                             int32_t hop_samples, int32_t patch_step, void* workspace_dev, int64_t workspace_bytes,
+                             float* emb_dev, float* logits_dev, int32_t mode, int32_t* range_word, void* stream);
 
 /* Test hook: run the path up to CNN stage `stage` (0 = conv1 output, 2k-1 / 2k = depthwise /
    pointwise output of layer k+1) for the first `windows` windows and copy that NHWC activation
@@ -181,11 +198,29 @@ BD_API int bd_set_pointwise_variant(bd_handle h, int32_t layer /* 2..14 */, int3
    2 = plain f16 operands, ONE MFMA per product, f32 accumulate (BASELINE config 5's arithmetic): outside the
    reference's 1e-4 logit tolerance by design (~1e-3), for callers that trade accuracy for rate. */
 BD_API int bd_set_pointwise_mode(bd_handle h, int32_t mode);
-/* Modes 1 and 2 carry activations as f16: one beyond 65 504 (the network has plain ReLU, yamnet.py:36-74, nothing bounds
-   it) would become +inf and the result garbage.  The kernels track the largest magnitude they convert and set a sticky
-   per-engine device word when it leaves the f16 range.  bd_range_flag copies that word to *flag_host (1 = some launch
-   since the last reset overflowed: repeat those chunks in mode 0) and, with reset != 0, clears it.  It waits for `stream`
-   - call it where the results are read anyway.  (Folded weights beyond +-60 000 are refused at bd_create.) */
+/* Operand scaling of modes 1 and 2.  f16 has 5 exponent bits: hi = f16(x), lo = f16(x - hi) carry x to 22 bits only
+   while lo is a normal number (|x| >= 2^-3) and hi is finite (|x| <= 65 504).  Both operands of every 1x1 convolution are
+   therefore moved into that window by exact powers of two: each output channel of the folded kernel so that its largest
+   weight lies in [2^12, 2^13) (fixed at bd_create), each layer's input activations so that the largest value a
+   calibration pass saw lies in [2^8, 2^9) (folded into the taps and shift of the depthwise that produces them, so it
+   costs no instruction); the epilogue multiplies the accumulator by the inverse power of two.  Nothing is rounded by the
+   scales, so the results do not depend on the scale BatchNorm folding leaves a layer at.
+   bd_create calibrates on a built-in signal (silence, noise at five levels, tones, clicks, a chirp, square waves: the
+   envelope of what [-1, 1] PCM does to a LOG-mel input) with exact-f32 arithmetic.  bd_calibrate runs the same pass over
+   caller-supplied audio and widens the per-layer maxima (they never shrink).  It waits for `stream` and rewrites device
+   tables with blocking copies: call it while nothing else is in flight on the handle.
+   bd_get_scales: act_exp[13] / act_max[13] for layers 2..14 (either may be NULL); returns 13.
+   bd_set_activation_exponents: test hook that overrides the calibrated exponents (-60..60), e.g. to drive a layer out of
+   range and exercise the range word. */
+BD_API int bd_calibrate(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples, int32_t patch_step,
+                        void* workspace_dev, int64_t workspace_bytes, void* stream);
+BD_API int bd_get_scales(bd_handle h, int32_t* act_exp, float* act_max);
+BD_API int bd_set_activation_exponents(bd_handle h, const int32_t* act_exp);
+/* An activation beyond the calibrated headroom (scaled value > 65 504; the network has plain ReLU, yamnet.py:36-74, nothing
+   bounds it) would become +inf and the result garbage.  The kernels track the largest magnitude they convert and set a
+   sticky per-engine device word when it leaves the f16 range.  bd_range_flag copies that word to *flag_host (1 = some
+   launch since the last reset overflowed: repeat those chunks in mode 0) and, with reset != 0, clears it.  It waits for
+   `stream` - call it where the results are read anyway.  bd_predict_chunks hands out the word per call instead. */
 BD_API int bd_range_flag(bd_handle h, int32_t* flag_host, int32_t reset, void* stream);
 /* The same without waiting: enqueues a copy of the word to `dst` (device memory or PINNED host memory) on `stream`,
    then, with reset != 0, its clearing.  For pipelines that read results through their own events. */
@@ -205,10 +240,11 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    kernel for 512 -> 512 channels (test hook).
    Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);
-/* whi/wlo: [n][k] f16 halves of wt (wt ~= whi + wlo) */
+/* whi/wlo: [n][k] f16 halves of wt * scale[n] (wt[n][:] * scale[n] ~= whi[n][:] + wlo[n][:]); unscale[n] = 1 / (scale[n] *
+   the scale the caller applied to a): c = relu(fma(acc, unscale[n], bias[n])) */
 BD_API int bd_debug_pointwise_f16x3(const float* a_dev, const void* whi_dev, const void* wlo_dev,
-                                    const float* bias_dev, float* c_dev, int64_t m, int32_t n, int32_t k,
-                                    int32_t variant, void* stream);
+                                    const float* unscale_dev, const float* bias_dev, float* c_dev, int64_t m, int32_t n,
+                                    int32_t k, int32_t variant, void* stream);
 
 /* ---- per-stage timing (HIP events on the caller's stream) ----
    With profiling on, one event is recorded at the head of every bd_predict/bd_embed call and one after
