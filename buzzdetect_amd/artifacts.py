@@ -35,7 +35,7 @@ import numpy as np
 _TABLE_MAGIC = 0xDB4775248B80FB57
 
 # tensorflow/core/framework/types.proto
-_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64, 10: np.bool_}
 
 
 # --------------------------------------------------------------------------- #
@@ -233,6 +233,11 @@ def _node_consts(node: bytes) -> Optional[Tuple[str, np.ndarray]]:
                     ints.append(x if x < (1 << 63) else x - (1 << 64))
             else:
                 ints.append(val if val < (1 << 63) else val - (1 << 64))
+        elif fno == 11:  # bool_val
+            if wt == 2:
+                ints.extend(int(b) for b in val)
+            else:
+                ints.append(int(val))
     if dtype not in _DTYPES:
         return None
     dt = np.dtype(_DTYPES[dtype])
@@ -303,3 +308,96 @@ def extract_mel_matrix(saved_model_pb: str) -> np.ndarray:
         if not np.array_equal(first, other):
             raise ValueError(f"{saved_model_pb}: conflicting [257,64] constants")
     return first
+
+
+# --------------------------------------------------------------------------- #
+# SavedModel graph structure (op types and attributes)
+# --------------------------------------------------------------------------- #
+def _attr_value(av: bytes):
+    """AttrValue -> Python value for the kinds the YAMNet graphs use: s, i, f, b, type, shape, list(i / s / f / b)."""
+    for fno, wt, val in _fields(av):
+        if fno == 2:
+            return val.decode(errors="replace")
+        if fno == 3:
+            return val if val < (1 << 63) else val - (1 << 64)
+        if fno == 4:
+            return struct.unpack("<f", val)[0]
+        if fno == 5:
+            return bool(val)
+        if fno == 6:
+            return {"dtype": int(val)}
+        if fno == 7:
+            return {"shape": list(_shape(val))}
+        if fno == 8:
+            return {"tensor": True}
+        if fno == 10:
+            return {"func": True}
+        if fno == 1:                           # ListValue
+            out: List[object] = []
+            for f2, w2, v2 in _fields(val):
+                if f2 == 2:
+                    out.append(v2.decode(errors="replace"))
+                elif f2 == 3:
+                    if w2 == 2:
+                        q = 0
+                        while q < len(v2):
+                            x, q = _varint(v2, q)
+                            out.append(x if x < (1 << 63) else x - (1 << 64))
+                    else:
+                        out.append(v2 if v2 < (1 << 63) else v2 - (1 << 64))
+                elif f2 == 4:
+                    if w2 == 2:
+                        out.extend(struct.unpack(f"<{len(v2) // 4}f", v2))
+                    else:
+                        out.append(struct.unpack("<f", v2)[0])
+                elif f2 == 5:
+                    if w2 == 2:
+                        out.extend(bool(b) for b in v2)
+                    else:
+                        out.append(bool(v2))
+            return out
+    return None
+
+
+@dataclass(frozen=True)
+class GraphNode:
+    function: str                  # "" = the main graph, else the library function that holds the node
+    name: str
+    op: str
+    inputs: Tuple[str, ...]
+    attrs: Dict[str, object]
+    const: Optional[np.ndarray]    # payload of a numeric Const node
+
+
+def saved_model_nodes(path: str) -> List[GraphNode]:
+    """Every NodeDef of a ``saved_model.pb`` (main graph and function library) with its decoded attributes."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    out: List[GraphNode] = []
+    for scope, node in _walk_nodes(buf):
+        name = op = ""
+        inputs: List[str] = []
+        attrs: Dict[str, object] = {}
+        for fno, _, val in _fields(node):
+            if fno == 1:
+                name = val.decode()
+            elif fno == 2:
+                op = val.decode()
+            elif fno == 3:
+                inputs.append(val.decode())
+            elif fno == 5:
+                k = None
+                av = b""
+                for f2, _, v2 in _fields(val):
+                    if f2 == 1:
+                        k = v2.decode()
+                    elif f2 == 2:
+                        av = v2
+                if k is not None:
+                    attrs[k] = _attr_value(av)
+        const = None
+        if op == "Const":
+            got = _node_consts(node)
+            const = got[1] if got is not None else None
+        out.append(GraphNode(scope, name, op, tuple(inputs), attrs, const))
+    return out

@@ -20,6 +20,12 @@ Two kinds of output, both *data* (no reference source text is copied):
    modules cannot be imported here (``ModuleNotFoundError: tensorflow``), so the
    hot path itself has no reference-generated vectors: parity for it is pinned
    only by the extracted constants ("Oracle").
+3. ``tests/golden/graph_facts.json`` — the STRUCTURE of the three SavedModel graphs the
+   reference ships, decoded from ``saved_model.pb`` (op types, attributes, scalar
+   constants of the inlined inference function): strides / ``SAME`` / ``NHWC`` of the 27
+   convolutions, ``epsilon`` / ``is_training`` / ones-scale of the 27 batch norms, the
+   ``[[0,0],[0,112]]`` pad in front of the RFFT, frame 400 / 160 / 512, 15600 / 15360 /
+   7680 / 0.001, the periodic Hann op chain, ReLU (not ReLU6), Mean over [1, 2].
 """
 from __future__ import annotations
 
@@ -197,12 +203,115 @@ def golden_vectors(ref: str, out: str) -> None:
     print(f"golden vectors -> {out}/reference_helpers.json")
 
 
+# --------------------------------------------------------------------------- graph structure
+GRAPHS = {
+    "yamnet_k2_wholehop": "embedders/yamnet_k2/models/yamnet_wholehop/saved_model.pb",
+    "yamnet_k2_halfhop": "embedders/yamnet_k2/models/yamnet_halfhop/saved_model.pb",
+    "yamnet_keras3": "embedders/yamnet/saved_model.pb",
+}
+
+
+def _scalar(n):
+    return None if n.const is None or n.const.size != 1 else n.const.reshape(-1)[0].item()
+
+
+def graph_structure(pb_path: str) -> dict:
+    """What the SavedModel graph itself says about the hot path (everything TensorFlow decides implicitly and the
+    oracle restates): op types and attributes of the inlined inference function, the constants it is called with."""
+    nodes = artifacts.saved_model_nodes(pb_path)
+    by_fn: dict = {}
+    for n in nodes:
+        by_fn.setdefault(n.function, []).append(n)
+
+    def is_inference(v):
+        ops = [n.op for n in v]
+        return (ops.count("RFFT") == 1 and ops.count("Conv2D") == 14 and ops.count("DepthwiseConv2dNative") == 13
+                and "AssignVariableOp" not in ops)
+    cands = sorted(f for f, v in by_fn.items() if f and is_inference(v))
+    assert cands, f"{pb_path}: no inlined inference function found"
+    per_fn = []
+    for fn in cands:
+        v = by_fn[fn]
+        byname = {n.name: n for n in v}
+
+        def const_of(ref: str):
+            return byname.get(ref.split(":")[0])
+
+        facts: dict = {}
+        short = lambda name: name.split("/", 1)[1] if "/" in name else name      # drop the model-name prefix
+
+        # every scalar / small Const of the front end, by node name
+        fe = {}
+        keep = ("/frame_length", "/frame_step", "/fft_length", "rfft/Pad/paddings", "hann_window/periodic",
+                "hann_window/Const", "hann_window/mul_2/x", "hann_window/sub_2/x", "hann_window/mod/y", "/frame/axis")
+        for n in v:
+            if n.op == "Const" and n.const is not None and n.const.size <= 8 and (
+                    n.name.endswith(keep) or "reshape/Reshape/shape/" in n.name):
+                fe[short(n.name)] = n.const.tolist()
+        facts["frontend_consts"] = fe
+        # front-end op chain (everything outside the tf.signal.frame index arithmetic), in graph order
+        chain = []
+        for n in v:
+            if n.op in ("Const", "Identity", "NoOp", "ReadVariableOp") or "/frame/" in n.name or "hann_window" in n.name:
+                continue
+            if n.name.startswith(v[0].name.split("/")[0] + "/tf.") or "/tf." in n.name:
+                attrs = {k: a for k, a in n.attrs.items()
+                         if k in ("transpose_a", "transpose_b", "DstT", "SrcT", "shrink_axis_mask", "N")}
+                chain.append([short(n.name), n.op, attrs])
+        facts["frontend_ops"] = chain
+        facts["hann_window_ops"] = [[short(n.name), n.op] for n in v if "hann_window" in n.name and n.op != "Const"]
+
+        convs, bns, relus = [], [], []
+        for n in v:
+            if n.op in ("Conv2D", "DepthwiseConv2dNative"):
+                convs.append({"name": short(n.name), "op": n.op,
+                              **{k: n.attrs.get(k) for k in ("strides", "padding", "data_format", "dilations",
+                                                             "explicit_paddings")}})
+            elif n.op == "FusedBatchNormV3":
+                scale = const_of(n.inputs[1])
+                bns.append({"name": short(n.name), "epsilon": n.attrs.get("epsilon"),
+                            "is_training": n.attrs.get("is_training"), "data_format": n.attrs.get("data_format"),
+                            "exponential_avg_factor": n.attrs.get("exponential_avg_factor"),
+                            "scale_is_const": scale is not None and scale.op == "Const",
+                            "scale_all_ones": bool(scale is not None and scale.const is not None
+                                                   and np.all(scale.const == 1.0)),
+                            "channels": int(scale.const.size) if scale is not None and scale.const is not None else None})
+            elif n.op in ("Relu", "Relu6", "Sigmoid", "Softmax"):
+                relus.append([short(n.name), n.op])
+        facts["convs"], facts["batchnorms"], facts["activations"] = convs, bns, relus
+        mean = [n for n in v if n.op == "Mean"]
+        assert len(mean) == 1
+        facts["pool"] = {"name": short(mean[0].name), "op": "Mean", "keep_dims": mean[0].attrs.get("keep_dims"),
+                         "reduction_indices": const_of(mean[0].inputs[1]).const.tolist()}
+        per_fn.append(facts)
+    for other in per_fn[1:]:
+        assert other == per_fn[0], f"{pb_path}: inference functions disagree"
+    out = per_fn[0]
+    out["inference_functions"] = len(cands)
+    # constants of the main graph: the arguments the serving call passes to the function (pad_waveform's 15600 / hop,
+    # the log offset; the [257,64] mel matrix is extracted separately)
+    out["main_graph_scalar_consts"] = sorted(
+        ([str(n.const.dtype), _scalar(n)] for n in by_fn.get("", [])
+         if n.op == "Const" and n.const is not None and n.const.size == 1), key=lambda kv: (kv[0], kv[1]))
+    return out
+
+
+def graph_facts(ref: str, out: str) -> None:
+    os.makedirs(out, exist_ok=True)
+    facts = {name: graph_structure(os.path.join(ref, rel)) for name, rel in GRAPHS.items()}
+    facts["_source"] = {name: rel + " [decoded: function library of the SavedModel, no TensorFlow]" for name, rel in GRAPHS.items()}
+    with open(os.path.join(out, "graph_facts.json"), "w") as f:
+        json.dump(facts, f, indent=1, sort_keys=True)
+    print(f"graph structure -> {out}/graph_facts.json")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     args = ap.parse_args()
     product_data(args.reference, os.path.join(REPO, "buzzdetect_amd", "data"))
     golden_vectors(args.reference, os.path.join(REPO, "tests", "golden"))
+    graph_facts(args.reference, os.path.join(REPO, "tests", "golden"))
 
 
 if __name__ == "__main__":
