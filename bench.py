@@ -3,15 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the whole hot path (PCM -> log-mel -> YAMNet -> dense head) over ONE synthetic 1 h
-16 kHz mono recording already resident in HBM, fed exactly as BASELINE config 2 / SURVEY 8d say: batches of
-1024 windows (983.04 s = 15 728 640 samples), i.e. 1024 + 1024 + 1024 + 678 = 3750 windows per step,
-yamnet_k2 embedder at hop 1.0 + model_general_v3 head.  K steps = K recordings in total, whatever N is
-(strong scaling, config 4's shape): recording i goes to rank i mod N; what is left when K is not a multiple
-of N is dealt batch by batch; every round of N recordings ends in ONE RCCL gather of the [3750, 13] logit
-blocks to rank 0, with sizes known on the host (no count exchange, no host synchronisation inside the timed
-region).  `python bench.py --gpus N` starts its own N child ranks (torch.distributed.run) when it is not
-already running under one.  Rank 0 prints ONE JSON line.
+A *step* is one pass of the whole hot path (PCM -> log-mel -> YAMNet -> dense head) over FIFTY synthetic 1 h
+16 kHz mono recordings already resident in HBM, each fed exactly as BASELINE config 2 / SURVEY 8d say: batches
+of 1024 windows (983.04 s = 15 728 640 samples), i.e. 1024 + 1024 + 1024 + 678 = 3750 windows per recording,
+187 500 per step, yamnet_k2 embedder at hop 1.0 + model_general_v3 head.  The driver's `--steps 20` is therefore
+BASELINE config 4's 1000 x 1 h: at N = 1 about 2.3 s of timed GPU work, at N = 8 125 full rounds.  K steps = 50 K
+recordings in total, whatever N is (strong scaling): recording i goes to rank i mod N; what is left when the
+count is not a multiple of N is dealt batch by batch; every round of N recordings ends in ONE RCCL gather of the
+[3750, 13] logit blocks to rank 0, with sizes known on the host (no count exchange, no host synchronisation
+inside the timed region).  `python bench.py --gpus N` starts its own N child ranks (torch.distributed.run) when
+it is not already running under one.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -32,6 +33,7 @@ HOP_PROP = 1.0
 FRAMELENGTH_S = 0.96
 FILE_SECONDS = 3600
 FILE_SAMPLES = FILE_SECONDS * SAMPLE_RATE                # 57 600 000
+FILES_PER_STEP = 50                                      # --steps 20 = config 4's 1000 recordings
 
 # SURVEY §8d / DESIGN.md: algorithmic work per window at hop 1.0
 POINTWISE_FLOP_PER_WINDOW = 132_120_576          # 2 * 66 060 288 MAC in the thirteen 1x1 convolutions
@@ -40,7 +42,7 @@ FRONTEND_BYTES_PER_WINDOW = 61_440 + 24_576      # f32 PCM in + f32 log-mel out
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_SPLIT_F16_TFLOPS = 2500.0 / 3.0             # dense f16 MFMA peak / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 # per-window HBM bytes each depthwise / conv1 launch must move (read input + write output, f32 NHWC)
 _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1, 512), (1, 512),
@@ -117,13 +119,34 @@ def free_port() -> int:
     return port
 
 
+def visible_gpus():
+    """GPUs of this node WITHOUT any HIP call: KFD topology nodes that have SIMDs (CPU nodes report simd_count 0),
+    cut down by a *_VISIBLE_DEVICES list if one is set.  None when the topology cannot be read."""
+    import glob
+    count = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return None
+    for path in files:
+        try:
+            with open(path) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        count += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            count = min(count, len([x for x in os.environ[var].split(",") if x.strip()]))
+    return count
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` from a plain shell: start N fresh child ranks BEFORE this process touches a
-    GPU (nothing here initialises HIP), let rank 0's JSON line through on stdout, hand back the exit code."""
-    import torch
+    GPU (no HIP call and no torch import here), let rank 0's JSON line through on stdout, hand back the exit code."""
     rehearsal = os.environ.get("BD_BENCH_REHEARSAL") == "1"
-    visible = torch.cuda.device_count()          # does not initialise the device on this stack
-    if visible < n and not rehearsal:
+    visible = visible_gpus()
+    if visible is not None and visible < n and not rehearsal:
         log(f"--gpus {n} but only {visible} GPU(s) visible (BD_BENCH_REHEARSAL=1 shares GPU 0 over gloo: control flow only)")
         return 2
     env = dict(os.environ)
@@ -297,8 +320,8 @@ def analyze_leg(device_index: int, hours: int, chunklength: float, framehop_prop
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps of 50 one-hour recordings each")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-windows", type=int, default=4096,
                     help="size of the bounded CPU-baseline sample (about 15-25 s of CPU work over 6 passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -385,9 +408,9 @@ def main() -> int:
 
     issued = [0]
 
-    def run_files(n_files: int, use_streams: bool = True):
-        """n_files recordings through this rank's share of the rounds (see the module docstring)."""
-        for rnd in sharding.plan_rounds(n_files, batch_windows, world):
+    def run_files(n_steps: int, use_streams: bool = True):
+        """n_steps x 50 recordings through this rank's share of the rounds (see the module docstring)."""
+        for rnd in sharding.plan_rounds(n_steps * FILES_PER_STEP, batch_windows, world):
             local, gath, reusable = buffers(rnd.rows)
             slot = issued[0] % RING
             issued[0] += 1
@@ -433,7 +456,7 @@ def main() -> int:
         return dt
 
     if rank == 0:
-        log(f"warm-up {args.warmup} steps, then {args.steps} timed steps (1 h recordings) over {world} GPU(s)")
+        log(f"warm-up {args.warmup} steps, then {args.steps} timed steps ({FILES_PER_STEP} x 1 h recordings each) over {world} GPU(s)")
     run_files(max(args.warmup, 0))
     fence()
 
@@ -441,17 +464,19 @@ def main() -> int:
     for e in engines:
         e.profile_enable(False)
     elapsed = timed_region(args.steps)
-    total_windows = windows_per_file * args.steps
+    windows_per_step = windows_per_file * FILES_PER_STEP
+    total_windows = windows_per_step * args.steps
     value = total_windows / elapsed
     if rank == 0:
-        log(f"{value:.0f} windows/s ({1e3 * elapsed / args.steps:.3f} ms/step of {windows_per_file} windows)")
+        log(f"{value:.0f} windows/s ({1e3 * elapsed / args.steps:.3f} ms/step of {windows_per_step} windows, "
+            f"timed region {elapsed:.3f} s)")
 
     # region 2 (rank 0's own share, one stream): the same batches with every kernel bracketed by HIP events on
     # its stream (costs a few % of wall time, which is why `value` does not come from this region)
     events_on = not args.no_kernel_events
     ms = launches = None
     elapsed_events = None
-    ev_steps = max(1, min(args.steps, 10))
+    ev_steps = 10                    # recordings in the event region
     if events_on:
         engine.profile_read()                                # drop anything recorded so far
         engine.profile_enable(True)
@@ -473,21 +498,26 @@ def main() -> int:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "f32 in / f32 accumulate; 1x1-conv products as split-f16 MFMA (hi+lo halves, 3 MFMAs, 22-bit "
-                          "operands) - max|dlogit| vs the f64 oracle equals the exact-f32-MFMA mode's (value_mode0_f32)",
+            "dtype_note": "f32 in / f32 accumulate; 1x1-conv products as split-f16 MFMA (hi+lo halves of operands scaled by "
+                          "exact powers of two - per weight row at load, per layer from an exact-f32 calibration pass - so "
+                          "that both halves are normal f16: 22-bit operands at any weight scale; 3 MFMAs per product); "
+                          "value_mode0_f32 / roofline_mode0 are the same run on exact-f32 MFMA products",
+            "timed_region_s": round(elapsed, 4),
             "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
-            "config": {"workload": "config 2: one synthetic 1 h 16 kHz mono recording per step, fed as batches of 1024 "
-                                   "windows (1024+1024+1024+678 = 3750 windows, 983.04 s chunks), embedder yamnet_k2 "
+            "config": {"workload": f"config 2 x {FILES_PER_STEP} per step: synthetic 1 h 16 kHz mono recordings, each fed as batches "
+                                   "of 1024 windows (1024+1024+1024+678 = 3750 windows, 983.04 s chunks), embedder yamnet_k2 "
                                    "(mel Const of embedders/yamnet_k2) hop 1.0 + model_general_v3 head; embedder weights "
-                                   "seeded synthetic in the reference layout, head weights real",
-                       "windows_per_step": windows_per_file, "samples_per_step": FILE_SAMPLES,
+                                   "seeded synthetic in the reference layout, head weights real; --steps 20 = config 4's "
+                                   "1000 x 1 h",
+                       "recordings_per_step": FILES_PER_STEP, "windows_per_recording": windows_per_file,
+                       "windows_per_step": windows_per_step, "samples_per_step": FILE_SAMPLES * FILES_PER_STEP,
                        "batch_windows": batch_windows, "hop_samples": hop, "patch_step": step,
                        "analyzer_streams": len(engines),
-                       "sharding": (f"config 4 shape: {args.steps} recordings in total, recording i -> rank i mod {world}, "
+                       "sharding": (f"config 4 shape: {args.steps * FILES_PER_STEP} recordings in total, recording i -> rank i mod {world}, "
                                     f"remainder dealt per batch; one RCCL gather of the [rows,13] logit blocks to rank 0 "
                                     f"per round of {world} recordings, sizes known on the host") if world > 1 else "single GPU",
                        "timing": "value from K clean steps; per-kernel HIP-event times from a second region "
-                                 f"({ev_steps} steps, one stream)"},
+                                 f"({ev_steps} recordings, one stream)"},
         }
         if events_on and launches.sum() > 0 and args.per_slot:
             for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches, pool_fused=args.sep_variant is None).items()):
@@ -496,7 +526,8 @@ def main() -> int:
                 log(f"slot {slot:2d} {nm:10s} {fam:24s} {us:8.1f} us  {nb * wl / us / 1e6:6.2f} TB/s  "
                     f"{fl * wl / us / 1e6:7.1f} TFLOP/s   (avg {wl:.0f} windows/launch)")
         if events_on and launches.sum() > 0:
-            out["ms_per_step_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
+            out["ms_per_recording_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
+            out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * FILES_PER_STEP), 4)
             fams = {}
             for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant is None).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
@@ -543,7 +574,7 @@ def main() -> int:
             stages = {}
             for fam, k in sorted(fams.items(), key=lambda kv: -kv[1]["ms"]):
                 sec = k["ms"] * 1e-3
-                stages[fam] = {"slots": k["slots"], "ms_per_step": round(k["ms"] / ev_steps, 4),
+                stages[fam] = {"slots": k["slots"], "ms_per_recording": round(k["ms"] / ev_steps, 4),
                                "share": round(k["ms"] / total_ms, 4),
                                "GBps_algorithmic": round(k["bytes"] / sec / 1e9, 1),
                                "frac_hbm_peak": round(k["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4),
@@ -665,6 +696,11 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
         e.set_pointwise_mode("f16x3")
     if "f32" in modes:
         out["value_mode0_f32"] = {**modes["f32"], "what": "1x1 convolutions on v_mfma_f32_32x32x2_f32 (exact f32 products)"}
+        tf = modes["f32"]["value"] * CNN_FLOP_PER_WINDOW / 1e12
+        out["roofline_mode0"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                 "what": "whole CNN (137.29 MFLOP per window) at value_mode0_f32's rate against the dense "
+                                         "f32-MFMA peak; the strict-f32 number's own fraction"}
     if "f16" in modes:
         out["value_mode2_f16"] = {**modes["f16"], "what": "config 5 arithmetic: plain f16 operands, one MFMA per product, f32 "
                                                           "accumulate; outside the 1e-4 gate by design, never `value`"}

@@ -22,6 +22,7 @@ from typing import List, Optional
 
 from . import framing, results, sharding
 from .pipeline import FILE_SIZE_MINIMUM, FileJob, Pipeline, Report
+from .pipeline import log as _log
 from .wavio import WavTrack  # noqa: F401  (re-exported: the streamer's reader)
 
 AnalyzeReport = Report
@@ -51,7 +52,9 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
             dir_out: Optional[str] = None, embeddername: str = "yamnet_k2", engine=None,
             rank: Optional[int] = None, world_size: Optional[int] = None, analyzers_gpu: int = 2,
             n_streamers: Optional[int] = None, engines: Optional[list] = None,
-            gather_logits: bool = False) -> AnalyzeReport:
+            gather_logits: bool = False, analyzers_cpu: int = 0, stream_buffer_depth: Optional[int] = None,
+            verbosity_print: Optional[str] = None, verbosity_log: Optional[str] = None, log_progress: bool = False,
+            event_stopanalysis=None) -> AnalyzeReport:
     """Analyse every ``.wav`` under ``dir_audio``; write ``<ident>_buzzdetect.csv`` under ``dir_out``.
 
     ``classes_out`` / ``precision`` choose activations vs detections exactly as in the reference;
@@ -62,7 +65,13 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
     an engine folds and uploads the weights, ~0.1 s).
     ``gather_logits`` (several ranks): BASELINE config 4 - every rank analyses its recordings, the per-window logits
     are gathered to rank 0 over RCCL once per round of ``world_size`` recordings, and rank 0 alone writes the result
-    files (for output folders only rank 0 can reach; without it every rank writes its own files)."""
+    files (for output folders only rank 0 can reach; without it every rank writes its own files).
+    The remaining keyword arguments are the reference's (src/analyze.py:387-404): ``stream_buffer_depth`` chunks may wait
+    between streamers and analyzers (default 2 x streamers); ``event_stopanalysis`` (anything with ``is_set()``) ends the
+    analysis early - every queue is released, the report comes back with ``end_reason == "interrupted"`` and the partial
+    result files are left for the next run to resume; ``verbosity_print`` / ``verbosity_log`` / ``log_progress`` attach
+    the reference's console and ``<dir_out>/<timestamp>.log`` handlers to logger ``buzzdetect`` for the duration of the
+    call (None: leave logging to the caller); ``analyzers_cpu`` is accepted and ignored - this engine has no CPU path."""
     from .engine import HipEngine, hop_samples, patch_step   # device code is only needed once there is work to do
 
     dist = None
@@ -77,6 +86,57 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
     rank = rank or 0
     world_size = world_size or 1
     dir_out = dir_out or os.path.join("models", modelname, "output")
+    handlers = _attach_log_handlers(dir_out, verbosity_print, verbosity_log, log_progress)
+    try:
+        return _analyze(modelname, classes_out, precision, framehop_prop, chunklength, dir_audio, dir_out, embeddername,
+                        engine, rank, world_size, dist, analyzers_gpu, n_streamers, engines, gather_logits, analyzers_cpu,
+                        stream_buffer_depth, event_stopanalysis)
+    finally:
+        for h in handlers:
+            _log.removeHandler(h)
+            h.close()
+
+
+def _attach_log_handlers(dir_out: str, verbosity_print, verbosity_log, log_progress: bool) -> list:
+    """The reference's logger set-up (src/pipeline/logger.py:23-57, src/analyze.py:127-136) on logger ``buzzdetect``."""
+    import logging
+    import time
+    from .pipeline import PROGRESS
+    levels = {"NOTSET": logging.NOTSET, "DEBUG": logging.DEBUG, "PROGRESS": PROGRESS, "INFO": logging.INFO,
+              "WARNING": logging.WARNING, "ERROR": logging.ERROR, "CRITICAL": logging.CRITICAL}
+
+    class PeriodFormatter(logging.Formatter):
+        def formatTime(self, record, datefmt=None):
+            return f"{time.strftime('%Y-%m-%d %H:%M:%S', self.converter(record.created))}.{int(record.msecs):03d}"
+
+    out = []
+    fmt = "%(asctime)s [%(levelname)s] %(message)s"
+    if verbosity_log is not None:
+        os.makedirs(dir_out, exist_ok=True)
+        h = logging.FileHandler(os.path.join(dir_out, time.strftime("%Y-%m-%d_%H%M%S") + ".log"))
+        h.setLevel(levels[verbosity_log])
+        if not log_progress:
+            h.addFilter(lambda record: record.levelno != PROGRESS)
+        h.setFormatter(PeriodFormatter(fmt))
+        out.append(h)
+    if verbosity_print is not None:
+        h = logging.StreamHandler()
+        h.setLevel(levels[verbosity_print])
+        h.setFormatter(PeriodFormatter(fmt))
+        out.append(h)
+    if out:
+        _log.setLevel(logging.DEBUG)
+    for h in out:
+        _log.addHandler(h)
+    return out
+
+
+def _analyze(modelname, classes_out, precision, framehop_prop, chunklength, dir_audio, dir_out, embeddername, engine, rank,
+             world_size, dist, analyzers_gpu, n_streamers, engines, gather_logits, analyzers_cpu, stream_buffer_depth,
+             event_stopanalysis) -> AnalyzeReport:
+    from .engine import HipEngine, hop_samples, patch_step
+    if analyzers_cpu:
+        _log.debug(f"analyzers_cpu={analyzers_cpu} ignored: the MI355X engine has no CPU path")
 
     framelength_s, digits_time, digits_results = 0.96, 2, 2
     framehop_s = framelength_s * framehop_prop
@@ -130,7 +190,8 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
     common = dict(make_engine=make_engine, classes=classes, framehop_s=framehop_s, hop=hop_samples(framehop_s),
                   step=patch_step(framehop_s), chunklength=chunklength, framelength_s=framelength_s,
                   digits_time=digits_time, digits_results=digits_results, classes_out=classes_out, threshold=threshold,
-                  readers=readers, analyzers=analyzers)
+                  readers=readers, analyzers=analyzers, stop_event=event_stopanalysis,
+                  stream_buffer_depth=stream_buffer_depth)
 
     if gather_logits and dist is not None and world_size > 1:
         report = _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, framehop_s, chunklength,
@@ -145,17 +206,16 @@ def analyze(modelname: str = "model_general_v3", classes_out="all", precision: O
     return report
 
 
-def _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, framehop_s, chunklength, digits_time,
-                      digits_results, classes_out, threshold) -> Report:
-    """Config 4: round-robin recordings, one RCCL gather of the logit blocks per round, rank 0 writes every file.
-    All ranks derive the same plan (which recordings, how many rows each) from the files themselves."""
-    import numpy as np
+def gather_plan(todo, dir_out: str, hop: int, step: int, chunklength: float) -> list:
+    """What config 4's gathers move: for every recording still to analyse (path, ident, chunks, windows per chunk), in
+    the order of ``todo``.  It depends on the planner's view of ``dir_out`` (finished recordings are left out), so ONE
+    rank computes it and the others receive it (``broadcast_plan``): block sizes, round count and ownership must agree
+    everywhere or the collectives mismatch."""
     from . import _lib
     from .pipeline import log
     from .wavio import WavFormatError
     lib = _lib.load()
-    hop, step = common["hop"], common["step"]
-    plan = []                     # (path, ident, chunks, windows per chunk)
+    plan = []
     for path, ident in todo:
         rf = results.ResultFile(os.path.join(dir_out, ident))
         if rf.complete or os.path.getsize(path) < FILE_SIZE_MINIMUM:
@@ -177,6 +237,25 @@ def _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, f
         track.close()
         if chunks:
             plan.append((path, ident, chunks, counts))
+    return plan
+
+
+def broadcast_plan(plan, rank: int, src: int = 0, group=None):
+    """The plan of rank ``src`` on every rank (``broadcast_object_list``; a few hundred bytes per recording)."""
+    import torch.distributed as dist
+    box = [plan if rank == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
+def _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, framehop_s, chunklength, digits_time,
+                      digits_results, classes_out, threshold) -> Report:
+    """Config 4: round-robin recordings, one RCCL gather of the logit blocks per round, rank 0 writes every file.
+    Rank 0 plans (which recordings, how many rows each: it is the rank that sees the output folder) and broadcasts."""
+    import numpy as np
+    from .pipeline import log
+    hop, step = common["hop"], common["step"]
+    plan = broadcast_plan(gather_plan(todo, dir_out, hop, step, chunklength) if rank == 0 else None, rank)
     rows_per_file = [sum(c) for _, _, _, c in plan]
 
     def write_file(index: int, rows: "np.ndarray") -> None:          # rank 0, from its writer thread
@@ -213,6 +292,21 @@ def _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, f
         path, ident, _, _ = plan[k]
         jobs.append(FileJob(path=path, ident=ident, shortpath=ident + os.path.splitext(path)[1],
                             rf=results.ResultFile(os.path.join(dir_out, ident)), index=k))
-    report = Pipeline(**common, file_sink=sink, ignore_partial=True).run(jobs)
-    gatherer.finish()
+    error = None
+    try:
+        report = Pipeline(**common, file_sink=sink, ignore_partial=True).run(jobs)
+    except BaseException as exc:              # noqa: BLE001 - the collectives below must still be issued
+        error, report = exc, Report(files_total=len(jobs))
+    # a recording this rank owns and did not deliver (skipped as unreadable, or the pipeline failed): every round's
+    # collective is issued all the same, with the status row set, so that no other rank is left waiting in it
+    for job in jobs:
+        if job.index not in gatherer.submitted:
+            gatherer.submit_failed(job.index, "pipeline failed" if error is not None else "skipped")
+    failed = gatherer.finish()
+    for f in failed:
+        msg = f"not delivered by rank {sharding.owner_of(f, world_size)}, no result file written: {plan[f][1]}"
+        log.warning(f"writer: {msg}")
+        report.messages.append(msg)
+    if error is not None:
+        raise error
     return report

@@ -23,6 +23,9 @@ that consumes ~45 MB/s of 16-bit PCM per 10 k windows/s is not left waiting:
 
 An exception in ANY stage poisons the pipeline: the first one is kept, every queue is released, `run` re-raises it
 after all threads have ended (the reference's workers die silently and leave the others blocked).
+The caller's `stop_event` (the reference's early exit, src/pipeline/coordination.py:182-188: poison every queue) ends a
+run the same way but without an error: `run` returns its report with end_reason "interrupted"; what has been written
+stays in the partial result files, whole chunks only, and the next run resumes from their coverage.
 """
 from __future__ import annotations
 
@@ -106,6 +109,7 @@ class Report:
     windows: int = 0
     audio_seconds: float = 0.0
     messages: List[str] = field(default_factory=list)
+    end_reason: str = "completed"     # or "interrupted": the caller's stop event ended the run (coordination.py:147-154)
 
 
 class PinnedRing:
@@ -148,7 +152,7 @@ class Pipeline:
                  chunklength: float, framelength_s: float, digits_time: int, digits_results: int, classes_out,
                  threshold: Optional[float], readers: int = 4, analyzers: int = 2, device=None,
                  file_sink: Optional[Callable[[FileJob, List[Tuple[float, "np.ndarray"]]], None]] = None,
-                 ignore_partial: bool = False):
+                 ignore_partial: bool = False, stop_event=None, stream_buffer_depth: Optional[int] = None):
         import torch
         self.torch = torch
         self.make_engine = make_engine
@@ -163,9 +167,14 @@ class Pipeline:
         self.file_sink, self.ignore_partial = file_sink, ignore_partial
         self.q_files: "queue.Queue" = queue.Queue()
         self.q_units: "queue.Queue" = queue.Queue(maxsize=8 * self.n_readers)
-        self.q_analyze: "queue.Queue" = queue.Queue(maxsize=2 * self.n_readers)      # coordination.py:129-138
+        # chunks buffered between streamers and analyzers: the reference's stream_buffer_depth, by default 2 x streamers
+        # (coordination.py:129-138)
+        depth = int(stream_buffer_depth) if stream_buffer_depth else 2 * self.n_readers
+        self.q_analyze: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self.stop_event = stop_event          # anything with is_set(): threading.Event, multiprocessing.Event
         self.q_write: "queue.Queue" = queue.Queue()
-        self.ring = PinnedRing(4 * self.n_readers + 16 * self.n_analyzers)     # queue + readers' hands + batches being copied
+        # queue + readers' hands + batches being copied
+        self.ring = PinnedRing(max(1, depth) + 2 * self.n_readers + 16 * self.n_analyzers)
         self.aborted = threading.Event()
         self.error: Optional[BaseException] = None
         self.lock = threading.Lock()
@@ -207,7 +216,7 @@ class Pipeline:
                 self.report.messages.append(message)
 
     def _plan_file(self, job: FileJob) -> None:
-        if job.rf.complete:
+        if job.rf.complete and not self.ignore_partial:     # (gather mode: the plan is rank 0's, this rank just delivers)
             return self._skip("planner", job, f"Skipping {job.shortpath}; already analyzed")
         if os.path.getsize(job.path) < FILE_SIZE_MINIMUM:
             return self._skip("planner", job, f"Skipping {job.shortpath}; below minimum analyzeable size")
@@ -497,6 +506,22 @@ class Pipeline:
         readers = [threading.Thread(target=self._reader, args=(i,), name=f"streamer-{i}", daemon=True) for i in range(self.n_readers)]
         analyzers = [threading.Thread(target=self._analyzer, args=(i,), name=f"analyzer-{i}", daemon=True) for i in range(self.n_analyzers)]
         writer = threading.Thread(target=self._writer, name="writer", daemon=True)
+        finished = threading.Event()
+
+        def watch_stop() -> None:
+            while not finished.wait(0.02):
+                if self.stop_event.is_set():
+                    with self.lock:
+                        if self.error is None and not self.aborted.is_set():
+                            self.report.end_reason = "interrupted"
+                            log.warning("coordinator: stop requested; ending the analysis (partial results stay resumable)")
+                    self.aborted.set()
+                    return
+
+        watcher = None
+        if self.stop_event is not None:
+            watcher = threading.Thread(target=watch_stop, name="stop-watch", daemon=True)
+            watcher.start()
         for t in [planner] + readers + analyzers + [writer]:
             t.start()
         planner.join()
@@ -513,6 +538,9 @@ class Pipeline:
         self._force_put(self.q_write, EXIT)
         writer.join()
         log.debug("coordinator: writer done")
+        finished.set()
+        if watcher is not None:
+            watcher.join()
         if self.error is not None:
             raise self.error
         return self.report

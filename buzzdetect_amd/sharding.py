@@ -151,8 +151,13 @@ class RoundGatherer:
     gathers - one per ROUND of ``world`` recordings (recording i belongs to rank i mod world, round i // world) - are
     collectives and must be issued in the same order everywhere.  ``submit`` hands in the rows of a finished recording;
     rounds are gathered as soon as they and all earlier rounds are ready; on ``dst`` every gathered recording is passed
-    to ``on_file(file_index, rows)``.  Block sizes come from ``rows_per_file``, which every rank computes for itself
-    from the recordings' headers: no count exchange."""
+    to ``on_file(file_index, rows)``.  Block sizes come from ``rows_per_file``, which must be the SAME list on every rank
+    (rank 0 plans, the plan is broadcast: ``analyze._analyze_gathered``): no count exchange per round.
+
+    A rank that cannot deliver a recording it owns (unreadable file, a failure in its pipeline) still has to take part in
+    that round's collective, or every other rank blocks in it forever: ``submit_failed`` contributes the block with its
+    status row set (the ``ROW_ALIGN`` rows appended to every block; row 0, column 0: 0 = rows valid, 1 = not delivered);
+    ``dst`` does not pass such a recording on and lists it in ``failed``."""
 
     def __init__(self, rows_per_file: Sequence[int], n_cols: int, on_file, device="cpu", dst: int = 0, group=None):
         self.rows_per_file = [int(r) for r in rows_per_file]
@@ -161,8 +166,11 @@ class RoundGatherer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_rounds = (self.n_files + self.world - 1) // self.world
-        self._ready = {}                      # round -> rows of this rank's recording in it
+        self._ready = {}                      # round -> rows of this rank's recording in it (None: not delivered)
         self._next = 0
+        self.submitted = set()                # recordings of this rank handed in so far (either way)
+        self.failed: List[int] = []           # on dst: recordings some rank could not deliver
+        self.failed_local = {}                # recording -> reason, on the rank that owns it
 
     def round_rows(self, g: int) -> int:
         files = range(g * self.world, min((g + 1) * self.world, self.n_files))
@@ -177,6 +185,16 @@ class RoundGatherer:
             raise ValueError(f"recording {file_index}: got {tuple(rows.shape)} rows, planned "
                              f"({self.rows_per_file[file_index]}, {self.n_cols})")
         self._ready[file_index // self.world] = rows
+        self.submitted.add(file_index)
+        self._pump()
+
+    def submit_failed(self, file_index: int, reason: str = "") -> None:
+        """This rank owns ``file_index`` and will not deliver its rows: take part in the round with the status row set."""
+        if owner_of(file_index, self.world) != self.rank:
+            raise ValueError(f"recording {file_index} does not belong to rank {self.rank}")
+        self._ready[file_index // self.world] = None
+        self.submitted.add(file_index)
+        self.failed_local[file_index] = reason
         self._pump()
 
     def _mine(self, g: int) -> Optional[int]:
@@ -190,22 +208,30 @@ class RoundGatherer:
             if mine is not None and g not in self._ready:
                 return                        # this rank's recording of the round is still being analysed
             n = self.round_rows(g)
-            block = torch.zeros((n, self.n_cols), dtype=torch.float32, device=self.device)
+            block = torch.zeros((n + ROW_ALIGN, self.n_cols), dtype=torch.float32, device=self.device)
             if mine is not None:
                 rows = self._ready.pop(g)
-                block[: rows.shape[0]] = rows.to(self.device)
-            out, _ = gather_round(block, n, dst=self.dst, group=self.group)
+                if rows is None:
+                    block[n, 0] = 1.0
+                else:
+                    block[: rows.shape[0]] = rows.to(self.device)
+            out, _ = gather_round(block, n + ROW_ALIGN, dst=self.dst, group=self.group)
             if self.rank == self.dst:
                 host = out.cpu()
                 for r in range(self.world):
                     f = g * self.world + r
                     if f < self.n_files:
-                        self.on_file(f, host[r, : self.rows_per_file[f]].numpy())
+                        if float(host[r, n, 0]) != 0.0:
+                            self.failed.append(f)
+                        else:
+                            self.on_file(f, host[r, : self.rows_per_file[f]].numpy())
             self._next += 1
 
-    def finish(self) -> None:
-        """Every local recording has been submitted: run the remaining rounds (a rank without a recording in the last
-        round contributes an empty block)."""
+    def finish(self) -> List[int]:
+        """Every local recording has been submitted (``submit`` or ``submit_failed``): run the remaining rounds (a rank
+        without a recording in the last round contributes an empty block).  On ``dst`` returns the recordings that were
+        not delivered."""
         self._pump()
         if self._next != self.n_rounds:
             raise RuntimeError(f"rank {self.rank}: rounds {self._next}..{self.n_rounds - 1} never became ready")
+        return list(self.failed)

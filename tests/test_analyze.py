@@ -273,3 +273,128 @@ def test_analyze_gathers_logits_to_rank_0_world_size_2(engine, tmp_path):
         b = (tmp_path / "gathered" / f"{rel}_buzzdetect.csv").read_bytes()
         assert a == b
         assert not (tmp_path / "gathered" / f"{rel}_buzzpart.csv").exists()
+
+
+@pytest.mark.gpu
+def test_stop_event_ends_the_run_and_a_rerun_completes_it(engine, tmp_path, monkeypatch):
+    """The reference's early exit (src/pipeline/coordination.py:182-188, analyze(event_stopanalysis=...)): setting the
+    event releases every queue like a failure does, but analyze() RETURNS - end_reason "interrupted" - and what was
+    written stays in the partial files, whole chunks only; the next run resumes from their coverage and ends with the
+    bytes of an uninterrupted run."""
+    import threading
+    import time
+    from buzzdetect_amd import results as R
+    from buzzdetect_amd import wavio
+    from buzzdetect_amd.analyze import analyze
+    audio = tmp_path / "audio"
+    _three_recordings(audio)
+    ref = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "ref"), engine=engine,
+                  stream_buffer_depth=1, analyzers_cpu=1)
+    assert ref.end_reason == "completed" and ref.files_done == 3 and ref.chunks == 12
+
+    stop = threading.Event()
+    written = {"n": 0}
+    real_append = R.ResultFile.append_text
+
+    def counting_append(self, head, body):
+        real_append(self, head, body)
+        written["n"] += 1
+        if written["n"] == 2:
+            stop.set()                                  # "after the second chunk"
+
+    fast_read = wavio.WavTrack.read_raw_into
+    monkeypatch.setattr(R.ResultFile, "append_text", counting_append)
+    monkeypatch.setattr(wavio.WavTrack, "read_raw_into",
+                        lambda self, a, n, out: (time.sleep(0.1), fast_read(self, a, n, out))[1])
+    out = {}
+
+    def run():
+        try:
+            out["rep"] = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "cut"),
+                                 engine=engine, n_streamers=1, stream_buffer_depth=1, event_stopanalysis=stop)
+        except BaseException as exc:                    # noqa: BLE001
+            out["exc"] = exc
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "analyze() did not return after the stop event"
+    assert "exc" not in out, out.get("exc")
+    rep = out["rep"]
+    assert rep.end_reason == "interrupted" and rep.files_done < 3
+    assert 2 <= written["n"] < 12
+    parts = [p for p in (tmp_path / "cut").rglob("*_buzzpart.csv")]
+    assert parts, "nothing left to resume from"
+    monkeypatch.setattr(R.ResultFile, "append_text", real_append)
+    monkeypatch.setattr(wavio.WavTrack, "read_raw_into", fast_read)
+    again = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "cut"), engine=engine)
+    assert again.end_reason == "completed" and again.chunks == 12 - written["n"]
+    for rel in ("a/one", "two", "three32k"):
+        assert (tmp_path / "cut" / f"{rel}_buzzdetect.csv").read_bytes() == (tmp_path / "ref" / f"{rel}_buzzdetect.csv").read_bytes()
+        assert not (tmp_path / "cut" / f"{rel}_buzzpart.csv").exists()
+    # a stop event that is already set: nothing is analysed, nothing hangs
+    early = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "none"), engine=engine,
+                    event_stopanalysis=stop)
+    assert early.end_reason == "interrupted" and early.files_done == 0
+
+
+@pytest.mark.gpu
+def test_reference_logging_arguments(engine, tmp_path):
+    """verbosity_log / log_progress (src/pipeline/logger.py:23-57): a time-stamped .log file in the output folder,
+    PROGRESS lines only on request."""
+    import re
+    from buzzdetect_amd.analyze import analyze
+    audio = tmp_path / "audio"
+    _three_recordings(audio)
+    for progress in (False, True):
+        out = tmp_path / f"out{int(progress)}"
+        analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(out), engine=engine,
+                verbosity_log="DEBUG", log_progress=progress)
+        logs = list(out.glob("*.log"))
+        assert len(logs) == 1 and re.match(r"\d{4}-\d\d-\d\d_\d{6}\.log$", logs[0].name)
+        text = logs[0].read_text()
+        assert re.search(r"^\d{4}-\d\d-\d\d \d\d:\d\d:\d\d\.\d{3} \[INFO\] planner: buffering", text, flags=re.M)
+        assert ("[PROGRESS] analyzer 0: analyzed" in text) == progress
+    import logging
+    assert not logging.getLogger("buzzdetect").handlers           # the handlers are gone after the call
+
+
+def _gather_rank_resume(rank, world, port, audio, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from buzzdetect_amd.analyze import analyze
+        # rank 1 is given an output folder of its own in which NOTHING is complete: were every rank to plan for itself
+        # (round 2's code), the two plans would differ (2 vs 3 recordings) and the gathers would mismatch or hang
+        rep = analyze("model_general_v3", chunklength=5, dir_audio=audio, dir_out=out if rank == 0 else out + "_rank1",
+                      gather_logits=True, analyzers_gpu=1)
+        assert rep.files_done == 1                      # the two recordings left, one per rank
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gather_mode_resumes_with_rank_0s_plan(engine, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    from buzzdetect_amd.analyze import analyze
+    audio = tmp_path / "audio"
+    _three_recordings(audio)
+    analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "solo"), engine=engine)
+    out = tmp_path / "gathered"
+    (out / "a").mkdir(parents=True)
+    done = (tmp_path / "solo" / "two_buzzdetect.csv").read_bytes()
+    (out / "two_buzzdetect.csv").write_bytes(done)                 # an earlier run finished this recording
+    import shutil
+    shutil.copy(tmp_path / "solo" / "buzzdetect_manifest.json", out / "buzzdetect_manifest.json")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gather_rank_resume, args=(2, port, str(audio), str(out)), nprocs=2, join=True)
+    for rel in ("a/one", "two", "three32k"):
+        assert (out / f"{rel}_buzzdetect.csv").read_bytes() == (tmp_path / "solo" / f"{rel}_buzzdetect.csv").read_bytes()

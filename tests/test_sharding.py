@@ -163,10 +163,15 @@ def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
     assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    # without the rehearsal switch a box with fewer GPUs than ranks is refused before anything is started
+    # without the rehearsal switch a box with fewer GPUs than ranks is refused before anything is started - and the
+    # parent finds that out from the KFD topology, not through HIP (it must not touch a GPU before its children exist)
     monkeypatch.delenv("BD_BENCH_REHEARSAL")
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
     calls.clear()
     assert bench.main() == 2 and not calls
+    src = open(os.path.join(os.path.dirname(__file__), "..", "bench.py")).read()
+    launch = src[src.index("def self_launch"):src.index("# ---", src.index("def self_launch"))]
+    assert "import torch" not in launch and "device_count" not in launch
 
 
 def _worker_round_gatherer(rank, world, port, out_dir):
@@ -199,4 +204,79 @@ def _worker_round_gatherer(rank, world, port, out_dir):
 def test_round_gatherer_world_size_2_gloo(tmp_path):
     import numpy  # noqa: F401
     mp.spawn(_worker_round_gatherer, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def _worker_round_gatherer_failure(rank, world, port, out_dir):
+    """a rank that cannot deliver a recording must still issue that round's collective."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows_per_file = [5, 9, 2, 7, 4]
+        got = {}
+        g = sharding.RoundGatherer(rows_per_file, 13, lambda f, rows: got.__setitem__(f, rows.copy()))
+        for f in sharding.shard_indices(5, rank, world):
+            if f == 3:                                        # rank 1 could not read its second recording
+                g.submit_failed(f, "unreadable")
+            else:
+                g.submit(f, np.full((rows_per_file[f], 13), float(f)))
+        failed = g.finish()                                   # returns on BOTH ranks: nobody is left in a collective
+        if rank == 0:
+            assert failed == [3] and sorted(got) == [0, 1, 2, 4]
+            assert all(np.all(rows == float(f)) for f, rows in got.items())
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+        else:
+            assert failed == [] and g.failed_local == {3: "unreadable"}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_round_gatherer_undelivered_recording_does_not_hang(tmp_path):
+    mp.spawn(_worker_round_gatherer_failure, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def _write_wav(path, seconds, rate=16000):
+    import wave
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes((np.arange(int(seconds * rate)) % 251).astype("<i2").tobytes())
+
+
+def _worker_plan(rank, world, port, root):
+    """on a resume rank 0 skips finished recordings; a rank with another view of the output folder must not
+    derive a different plan (other block sizes, other owners): rank 0 plans, everybody receives that plan."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from buzzdetect_amd import analyze as A
+        audio = os.path.join(root, "audio")
+        todo = [(p, A.build_ident(p, audio)) for p in A.search_audio(audio)]
+        assert len(todo) == 3
+        dir_out = os.path.join(root, f"out{rank}")            # rank 0: recording "b" complete; rank 1: nothing there
+        own = A.gather_plan(todo, dir_out, 15360, 96, 9.6)
+        assert [i for _, i, _, _ in own] == (["a", "c"] if rank == 0 else ["a", "b", "c"])
+        plan = A.broadcast_plan(own if rank == 0 else None, rank)
+        assert [i for _, i, _, _ in plan] == ["a", "c"]
+        assert [c for _, _, _, c in plan] == [[10, 10, 2], [10, 3]]      # 20.5 s and 12 s in 9.6 s chunks (H4: tail windows)
+        assert [ch for _, _, ch, _ in plan][1] == [(0.0, 9.6), (9.6, 12.0)]
+        if rank == 0:
+            open(os.path.join(root, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_plan_is_rank_zeros_plan_on_resume(tmp_path):
+    audio = tmp_path / "audio"
+    audio.mkdir()
+    for name, sec in (("a", 20.5), ("b", 15.0), ("c", 12.0)):
+        _write_wav(str(audio / f"{name}.wav"), sec)
+    (tmp_path / "out0").mkdir()
+    (tmp_path / "out1").mkdir()
+    (tmp_path / "out0" / "b_buzzdetect.csv").write_text("start,activation_ins_buzz\n0.0,1.0\n")
+    mp.spawn(_worker_plan, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
