@@ -508,18 +508,23 @@ class Pipeline:
         writer = threading.Thread(target=self._writer, name="writer", daemon=True)
         finished = threading.Event()
 
+        def stop_requested() -> bool:
+            if not self.stop_event.is_set():
+                return False
+            with self.lock:
+                if self.error is None and not self.aborted.is_set():
+                    self.report.end_reason = "interrupted"
+                    log.warning("coordinator: stop requested; ending the analysis (partial results stay resumable)")
+            self.aborted.set()
+            return True
+
         def watch_stop() -> None:
-            while not finished.wait(0.02):
-                if self.stop_event.is_set():
-                    with self.lock:
-                        if self.error is None and not self.aborted.is_set():
-                            self.report.end_reason = "interrupted"
-                            log.warning("coordinator: stop requested; ending the analysis (partial results stay resumable)")
-                    self.aborted.set()
-                    return
+            while not stop_requested() and not finished.wait(0.02):
+                pass
 
         watcher = None
         if self.stop_event is not None:
+            stop_requested()                  # already set: no worker gets to do anything
             watcher = threading.Thread(target=watch_stop, name="stop-watch", daemon=True)
             watcher.start()
         for t in [planner] + readers + analyzers + [writer]:
