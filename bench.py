@@ -39,10 +39,12 @@ FILES_PER_STEP = 50                                      # --steps 20 = config 4
 POINTWISE_FLOP_PER_WINDOW = 132_120_576          # 2 * 66 060 288 MAC in the thirteen 1x1 convolutions
 CNN_FLOP_PER_WINDOW = 137_289_728
 FRONTEND_BYTES_PER_WINDOW = 61_440 + 24_576      # f32 PCM in + f32 log-mel out
+STFT_HOP_BYTES = 160 * 4                         # new PCM bytes a frame brings (the 240-sample overlap amortises to 0)
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_SPLIT_F16_TFLOPS = 2500.0 / 3.0             # dense f16 MFMA peak / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FRONTEND_FILE = os.path.join("profiles", "r03_pmc_frontend_alone.csv")
 
 # per-window HBM bytes each depthwise / conv1 launch must move (read input + write output, f32 NHWC)
 _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1, 512), (1, 512),
@@ -249,6 +251,8 @@ def h2d_leg(engine, streams, device, hop: int, framehop_s: float, batches: int, 
     ring = [torch.empty(n, dtype=dt, device=device) for _ in range(3)]
     copied = [torch.cuda.Event() for _ in ring]
     consumed = [None] * len(ring)
+    spare = [torch.cuda.Event() for _ in ring]       # events are recorded again and again, never created per batch: a
+                                                     # stream of fresh events makes the HIP runtime grow its signal pool
 
     def run(count):
         for i in range(count):
@@ -263,9 +267,8 @@ def h2d_leg(engine, streams, device, hop: int, framehop_s: float, batches: int, 
                 s.wait_event(copied[slot])
                 pcm = engine[i % len(engine)].resample(ring[slot], SAMPLE_RATE, SAMPLE_RATE) if s16 else ring[slot]
                 engine[i % len(engine)].predict(pcm, framehop_s)
-                ev = torch.cuda.Event()
-                ev.record(s)
-                consumed[slot] = ev
+                spare[slot].record(s)
+                consumed[slot] = spare[slot]
 
     run(4)
     torch.cuda.synchronize()
@@ -335,6 +338,8 @@ def main() -> int:
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable layers: 9 = 8-wave kernel only, 12 = with the 12-wave kernel (no epilogue fusion; tuning)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
+    ap.add_argument("--files-per-step", type=int, default=FILES_PER_STEP,
+                    help="recordings per step (50: --steps 20 is config 4's 1000 x 1 h; profiling runs use fewer)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -345,6 +350,7 @@ def main() -> int:
     from buzzdetect_amd import sharding
     from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
 
+    files_per_step = max(1, args.files_per_step)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -410,7 +416,7 @@ def main() -> int:
 
     def run_files(n_steps: int, use_streams: bool = True):
         """n_steps x 50 recordings through this rank's share of the rounds (see the module docstring)."""
-        for rnd in sharding.plan_rounds(n_steps * FILES_PER_STEP, batch_windows, world):
+        for rnd in sharding.plan_rounds(n_steps * files_per_step, batch_windows, world):
             local, gath, reusable = buffers(rnd.rows)
             slot = issued[0] % RING
             issued[0] += 1
@@ -456,7 +462,7 @@ def main() -> int:
         return dt
 
     if rank == 0:
-        log(f"warm-up {args.warmup} steps, then {args.steps} timed steps ({FILES_PER_STEP} x 1 h recordings each) over {world} GPU(s)")
+        log(f"warm-up {args.warmup} steps, then {args.steps} timed steps ({files_per_step} x 1 h recordings each) over {world} GPU(s)")
     run_files(max(args.warmup, 0))
     fence()
 
@@ -464,7 +470,7 @@ def main() -> int:
     for e in engines:
         e.profile_enable(False)
     elapsed = timed_region(args.steps)
-    windows_per_step = windows_per_file * FILES_PER_STEP
+    windows_per_step = windows_per_file * files_per_step
     total_windows = windows_per_step * args.steps
     value = total_windows / elapsed
     if rank == 0:
@@ -504,16 +510,16 @@ def main() -> int:
                           "value_mode0_f32 / roofline_mode0 are the same run on exact-f32 MFMA products",
             "timed_region_s": round(elapsed, 4),
             "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
-            "config": {"workload": f"config 2 x {FILES_PER_STEP} per step: synthetic 1 h 16 kHz mono recordings, each fed as batches "
+            "config": {"workload": f"config 2 x {files_per_step} per step: synthetic 1 h 16 kHz mono recordings, each fed as batches "
                                    "of 1024 windows (1024+1024+1024+678 = 3750 windows, 983.04 s chunks), embedder yamnet_k2 "
                                    "(mel Const of embedders/yamnet_k2) hop 1.0 + model_general_v3 head; embedder weights "
                                    "seeded synthetic in the reference layout, head weights real; --steps 20 = config 4's "
                                    "1000 x 1 h",
-                       "recordings_per_step": FILES_PER_STEP, "windows_per_recording": windows_per_file,
-                       "windows_per_step": windows_per_step, "samples_per_step": FILE_SAMPLES * FILES_PER_STEP,
+                       "recordings_per_step": files_per_step, "windows_per_recording": windows_per_file,
+                       "windows_per_step": windows_per_step, "samples_per_step": FILE_SAMPLES * files_per_step,
                        "batch_windows": batch_windows, "hop_samples": hop, "patch_step": step,
                        "analyzer_streams": len(engines),
-                       "sharding": (f"config 4 shape: {args.steps * FILES_PER_STEP} recordings in total, recording i -> rank i mod {world}, "
+                       "sharding": (f"config 4 shape: {args.steps * files_per_step} recordings in total, recording i -> rank i mod {world}, "
                                     f"remainder dealt per batch; one RCCL gather of the [rows,13] logit blocks to rank 0 "
                                     f"per round of {world} recordings, sizes known on the host") if world > 1 else "single GPU",
                        "timing": "value from K clean steps; per-kernel HIP-event times from a second region "
@@ -527,7 +533,7 @@ def main() -> int:
                     f"{fl * wl / us / 1e6:7.1f} TFLOP/s   (avg {wl:.0f} windows/launch)")
         if events_on and launches.sum() > 0:
             out["ms_per_recording_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
-            out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * FILES_PER_STEP), 4)
+            out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * files_per_step), 4)
             fams = {}
             for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant is None).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
@@ -601,7 +607,7 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
     """Numbers reported BESIDE `value` (never as it): host-resident input, file -> CSV, other arithmetic modes."""
     import numpy as np
     import torch
-    k = max(8, min(40, args.steps))
+    k = 300                            # batches per leg: ~0.2 s of GPU work each (a 20-batch leg measures launch jitter)
     v, gbs = h2d_leg(engines, streams, device, hop, framehop_s, k, s16=True)
     out["value_h2d_s16"] = {"value": v, "unit": "windows/s", "pcie_GBps": gbs,
                             "what": "config-2 batches starting in pinned HOST memory as 16-bit PCM: async H2D on a copy "
@@ -611,6 +617,51 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
     out["value_h2d_f32"] = {"value": v, "unit": "windows/s", "pcie_GBps": gbs,
                             "what": "the same with float32 PCM on the host (the reference's dtype_in)"}
     log(f"host-resident f32 batches: {v:.0f} windows/s ({gbs} GB/s over PCIe)")
+
+    # the front-end kernel alone on one 1024-window batch (98 304 frames), HIP events on its stream: the north star's
+    # ">= 60 % of the HBM roofline" is a statement about THIS kernel; in situ it is ~6 % of a step
+    x_fe = synthetic_audio(device, WINDOWS_PER_BATCH * hop, 4711)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        lm = engines[0].frontend(x_fe, hop)
+    torch.cuda.synchronize()
+    reps = 100
+    e0.record()
+    for _ in range(reps):
+        lm = engines[0].frontend(x_fe, hop)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    fe_bytes = lm.shape[0] * (STFT_HOP_BYTES + 64 * 4)
+    # issue bound from the kernel's own counters (rocprofv3 --pmc SQ_INSTS_VALU on tools/fe_bench.py, committed under
+    # profiles/): vector instructions per launch / 1024 SIMDs x ~4 cycles per instruction (v_pk_*_f32 measure 3.3-4.5
+    # cycles per SIMD, tools/ubench_lane_ops.hip) at the ~2.1 GHz the kernel runs at - a floor no memory-side change beats
+    fe_frames = lm.shape[0]
+    valu = None
+    try:
+        import csv
+        with open(os.path.join(REPO, PMC_FRONTEND_FILE)) as f:
+            rows = [r for r in csv.DictReader(f) if r["kernel"] == "logmel_kernel"]
+        valu = max(float(r["SQ_INSTS_VALU"]) for r in rows)
+    except (OSError, ValueError, KeyError):
+        pass
+    issue = None
+    if valu:
+        floor_us = valu / 1024.0 * 4.0 / 2.1e3
+        issue = {"valu_wave_instructions_per_launch": valu, "source": PMC_FRONTEND_FILE, "simds": 1024,
+                 "cycles_per_instruction": 4.0, "clock_GHz": 2.1, "issue_floor_us": round(floor_us, 1),
+                 "frac_of_launch": round(floor_us / us, 3),
+                 "what": "vector-instruction issue time alone; the rest of a launch is LDS transposes (LDS ~50 % busy) and two "
+                         "workgroup barriers per 64 frames: the kernel is issue / latency bound, not HBM bound (DESIGN.md 4.3)"}
+    out["frontend_roofline"] = {
+        "kernel": "logmel_kernel alone, 98 304 frames (one 1024-window batch), PCM resident in HBM",
+        "bound": "hbm", "achieved": round(fe_bytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": round(fe_bytes / us / 1e3 / PEAK_HBM_GBS, 4), "avg_launch_us": round(us, 2), "bytes_per_launch": fe_bytes,
+        "traffic": None, "north_star_gate_frac": 0.60, "gate_met": bool(fe_bytes / us / 1e3 / PEAK_HBM_GBS >= 0.60),
+        "issue_bound": issue}
+    log(f"front end alone: {us:.1f} us per {fe_frames} frames = {fe_bytes / us / 1e3:.0f} GB/s "
+        f"({100 * fe_bytes / us / 1e3 / PEAK_HBM_GBS:.1f} % of the HBM peak)")
+    del x_fe, lm
 
     legs = {}
     for name, hours, chunk, hp in (("config2_1h_hop1.0", 1, WINDOWS_PER_BATCH * FRAMELENGTH_S, 1.0),

@@ -316,9 +316,9 @@ class HipEngine:
             staging[:n].copy_(torch.from_numpy(a))
             t = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)[:n]
             t.copy_(staging[:n], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self._stream())
-            self._pinned_events[slot] = ev
+            if self._pinned_events[slot] is None:          # one event per slot, recorded again for every copy
+                self._pinned_events[slot] = torch.cuda.Event()
+            self._pinned_events[slot].record(self._stream())
         if t.data_ptr() % 16:
             t = t.clone()
         return t

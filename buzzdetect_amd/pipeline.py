@@ -147,6 +147,25 @@ class PinnedRing:
         self._free.put(slot)
 
 
+class EventPool:
+    """HIP events, recycled.  Every batch needs a "results are on the host" event; a stream of freshly created events
+    makes the HIP runtime grow its signal pool while the GPU is busy - a one-off stall of tens of milliseconds in the
+    middle of a run (tools/stall_probe.py) - so the writer hands each event back once it has waited for it."""
+
+    def __init__(self, torch):
+        self._torch = torch
+        self._free: "queue.SimpleQueue" = queue.SimpleQueue()
+
+    def take(self):
+        try:
+            return self._free.get_nowait()
+        except queue.Empty:
+            return self._torch.cuda.Event()
+
+    def give(self, event) -> None:
+        self._free.put(event)
+
+
 class Pipeline:
     def __init__(self, *, make_engine: Callable[[], object], classes: Sequence[str], framehop_s: float, hop: int, step: int,
                  chunklength: float, framelength_s: float, digits_time: int, digits_results: int, classes_out,
@@ -175,6 +194,7 @@ class Pipeline:
         self.q_write: "queue.Queue" = queue.Queue()
         # queue + readers' hands + batches being copied
         self.ring = PinnedRing(max(1, depth) + 2 * self.n_readers + 16 * self.n_analyzers)
+        self.events = EventPool(torch)
         self.aborted = threading.Event()
         self.error: Optional[BaseException] = None
         self.lock = threading.Lock()
@@ -313,6 +333,7 @@ class Pipeline:
             device = engine.device
             stream = torch.cuda.Stream(device)
             copy_stream = torch.cuda.Stream(device)         # host-to-device copies of batch n + 1 run under the kernels of batch n
+            copied = torch.cuda.Event()
             n_classes = engine.n_classes
             log.info(f"analyzer {aid}: processing on GPU")
             t_wait = time.perf_counter()
@@ -330,8 +351,7 @@ class Pipeline:
                     with torch.cuda.stream(stream):
                         _, whole, _ = engine.launch(pcms, self.hop, self.step, False, True, mode="f32")
                         torch.from_numpy(item.host).copy_(whole, non_blocking=True)
-                        item.done = torch.cuda.Event()
-                        item.done.record(stream)
+                        item.done.record(stream)          # (the writer has not seen this item yet: the event is ours)
                     engine.overflow_reruns += 1
                 self._put(self.q_write, item)
 
@@ -369,8 +389,8 @@ class Pipeline:
                         dev = torch.empty(t.nbytes, dtype=torch.uint8, device=device)
                         dev.copy_(pinned, non_blocking=True)
                         devs.append(dev)
-                    copied = torch.cuda.Event()
-                    copied.record(copy_stream)
+                    copied.record(copy_stream)           # one event per analyzer, recorded again for every batch: the
+                                                         # wait below captures the state it has at this moment
                 with torch.cuda.stream(stream):
                     stream.wait_event(copied)
                     pcms = []
@@ -387,7 +407,7 @@ class Pipeline:
                     host = torch.empty((max(total, 1), n_classes), dtype=torch.float32, pin_memory=True)[:total]
                     if total:
                         host.copy_(whole, non_blocking=True)
-                    done = torch.cuda.Event()
+                    done = self.events.take()
                     done.record(stream)
                 # the pinned slots go back to the ring when the batch's event has fired (the writer waits for it anyway);
                 # the batch itself goes to the writer one batch later, after its range word has been looked at
@@ -457,6 +477,7 @@ class Pipeline:
                     self._finalize(item)
                     continue
                 item.done.synchronize()
+                self.events.give(item.done)
                 for t in item.tasks:                       # the H2D copies that read the pinned slots are long done
                     self.ring.release(t.slot)
                 seconds = time.perf_counter() - item.t_start

@@ -5,6 +5,6 @@
 pat=${1:-"slot"}
 for round in 1 2; do
   for v in A B; do
-    BUZZDETECT_HIP_LIB=$PWD/buzzdetect_amd/csrc/lib$v.so timeout -k 10 300 python bench.py --steps 20 --warmup 3 --per-slot --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep -E "$pat|windows/s \(" | sed "s/^/[$v$round] /"
+    BUZZDETECT_HIP_LIB=$PWD/buzzdetect_amd/csrc/lib$v.so timeout -k 10 300 python bench.py --steps 20 --warmup 3 --files-per-step 1 --per-slot --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep -E "$pat|windows/s \(" | sed "s/^/[$v$round] /"
   done
 done

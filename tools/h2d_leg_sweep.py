@@ -15,7 +15,7 @@ import bench
 from buzzdetect_amd.engine import HipEngine, hop_samples
 
 
-def leg(engines, streams, device, hop, ring_depth, what):
+def leg(engines, streams, device, hop, ring_depth, what, reuse_events=True):
     n = bench.WINDOWS_PER_BATCH * hop
     host = []
     for i in range(2):
@@ -25,6 +25,7 @@ def leg(engines, streams, device, hop, ring_depth, what):
     ring = [torch.empty(n, dtype=torch.int16, device=device) for _ in range(ring_depth)]
     copied = [torch.cuda.Event() for _ in ring]
     consumed = [None] * len(ring)
+    spare = [torch.cuda.Event() for _ in ring]        # one event per slot, recorded again and again
 
     def run(count):
         for i in range(count):
@@ -42,7 +43,7 @@ def leg(engines, streams, device, hop, ring_depth, what):
                 if what != "copy":
                     pcm = e.resample(ring[slot], 16000, 16000)
                     e.predict(pcm, 0.96)
-                ev = torch.cuda.Event()
+                ev = spare[slot] if reuse_events else torch.cuda.Event()
                 ev.record(s)
                 consumed[slot] = ev
 
@@ -57,12 +58,15 @@ def leg(engines, streams, device, hop, ring_depth, what):
 def main():
     device = torch.device("cuda", 0)
     hop = hop_samples(0.96)
-    for n_streams in (2, 3):
+    for n_streams in (2,):
         engines = [HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=0) for _ in range(n_streams)]
         streams = [torch.cuda.Stream(device) for _ in engines]
         for depth in (3, 6):
-            for what in ("both", "copy", "compute"):
-                print(f"{n_streams} compute streams, ring {depth}, {what:8s}: {leg(engines, streams, device, hop, depth, what):,.0f} windows/s", flush=True)
+            for reuse in (True, False):
+                for what in ("both", "copy", "compute"):
+                    r = leg(engines, streams, device, hop, depth, what, reuse)
+                    print(f"{n_streams} compute streams, ring {depth}, {'one event per slot' if reuse else 'new event per batch'}, "
+                          f"{what:8s}: {r:,.0f} windows/s", flush=True)
 
 
 if __name__ == "__main__":

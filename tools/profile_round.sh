@@ -4,8 +4,8 @@
 # Output under gpurun_out/prof_*; summarise with tools/summarize_rocprof.py, tools/pmc_traffic.py, tools/summarize_pmc.py.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extras --streams 1"
-S="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-extras --streams 1"
+B="python3 $R/bench.py --steps 10 --warmup 2 --files-per-step 1 --no-cpu-baseline --no-kernel-events --no-extras --streams 1"
+S="python3 $R/bench.py --steps 2 --warmup 1 --files-per-step 1 --no-cpu-baseline --no-kernel-events --no-extras --streams 1"
 rm -rf $R/gpurun_out/prof_trace $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write $R/gpurun_out/prof_sq1 $R/gpurun_out/prof_sq2
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_trace --output-format csv -- $B > $R/gpurun_out/prof_trace.log 2>&1 &&
 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch --output-format csv -- $S > $R/gpurun_out/prof_fetch.log 2>&1 &&
