@@ -68,3 +68,36 @@ for pieces in (1, 4, 16):
     print(f"together ({pieces:2d} pieces per copy): copies done after {start.elapsed_time(ev_c):7.1f} ms "
           f"({N * nbytes / start.elapsed_time(ev_c) / 1e6:5.1f} GB/s), compute done after {start.elapsed_time(ev_k):7.1f} ms "
           f"({N * 1024 / start.elapsed_time(ev_k) / 1e3:5.3f} M windows/s); wall {1e3 * tot:.1f} ms")
+
+# ---- the bench leg's dependency pattern, piece by piece (ring of 3 device buffers) ----
+copied = [torch.cuda.Event() for _ in range(8)]
+consumed = [torch.cuda.Event() for _ in range(8)]
+ring = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(8)]
+
+
+def leg(n, depth, wait_consumed, wait_copied, convert):
+    seen = [False] * depth
+    for i in range(n):
+        slot = i % depth
+        with torch.cuda.stream(copy_stream):
+            if wait_consumed and seen[slot]:
+                copy_stream.wait_event(consumed[slot])
+            ring[slot].copy_(host[i % 3], non_blocking=True)
+            copied[slot].record(copy_stream)
+        s = streams[i % 2]
+        with torch.cuda.stream(s):
+            if wait_copied:
+                s.wait_event(copied[slot])
+            e = engs[i % 2]
+            pcm = e.resample(ring[slot].view(torch.int16), 16000, 16000) if convert else x
+            e.predict(pcm, 0.96, out=outs[i % 2])
+            consumed[slot].record(s)
+            seen[slot] = True
+
+
+for depth in (3, 6):
+    for wc, wk, cv in ((False, False, False), (True, False, False), (False, True, False), (True, True, False), (True, True, True)):
+        leg(6, depth, wc, wk, cv)
+        t = timed(lambda: leg(200, depth, wc, wk, cv))
+        print(f"ring {depth}: copy waits for consumed={wc!s:5} compute waits for copied={wk!s:5} convert={cv!s:5}: "
+              f"{200 * 1024 / t / 1e6:5.3f} M windows/s, {200 * nbytes / t / 1e9:5.1f} GB/s")
