@@ -70,7 +70,16 @@ class _VerdictPool:
             self._idle.append((word, event))
 
 
-_verdicts = _VerdictPool()
+_verdict_pools: dict = {}                  # device index -> pool (an event belongs to the device it was first recorded on)
+_verdict_pools_lock = threading.Lock()
+
+
+def _verdicts_of(device_index: int) -> _VerdictPool:
+    with _verdict_pools_lock:
+        pool = _verdict_pools.get(device_index)
+        if pool is None:
+            pool = _verdict_pools[device_index] = _VerdictPool()
+        return pool
 
 
 class LaunchVerdict:
@@ -80,7 +89,8 @@ class LaunchVerdict:
     analyzer has long enqueued the next chunk, src/inference/worker.py:71-74 - learns about exactly its own launches."""
 
     def __init__(self, stream: torch.cuda.Stream):
-        self.word, self.event = _verdicts.take()
+        self._pool = _verdicts_of(stream.device_index)
+        self.word, self.event = self._pool.take()
         self.stream = stream
 
     def wait(self) -> bool:
@@ -90,7 +100,7 @@ class LaunchVerdict:
 
     def __del__(self):
         try:
-            _verdicts.give_back(self.word, self.event)
+            self._pool.give_back(self.word, self.event)
         except Exception:                      # interpreter shutdown
             pass
 
