@@ -136,8 +136,8 @@ def test_plugin_halfhop_and_free_hop_on_gpu(dropin_cwd, weights_bundle):
 @pytest.mark.gpu
 def test_worker_thread_contract_two_analyzers_on_one_device(dropin_cwd, weights_bundle):
     """src/inference/worker.py:21,78 and docs/source/tuning.rst:111: every analyzer THREAD constructs its own model
-    (initialize=False), initialises it in-thread, and only ever calls predict from that thread; two of them share a GPU.
-    Rows must be bit-equal to what a single thread computes, on every repetition."""
+    (initialize=False), initialises it in-thread, and only ever calls predict from that thread; two of them share a GPU;
+    the results are read on the WRITER thread.  Rows must be bit-equal to what a single thread computes, on every repetition."""
     import threading
     from oracle import yamnet_oracle as O
     from src.inference.models import load_model
@@ -147,6 +147,11 @@ def test_worker_thread_contract_two_analyzers_on_one_device(dropin_cwd, weights_
     got, errors = {}, []
     start = threading.Barrier(2)
 
+    # the analyzers only ENQUEUE (process_chunk: predict, then coordinator.put_write, src/inference/worker.py:71-74); ONE
+    # writer thread calls .numpy() on the results later (src/write/worker.py:69), while the analyzers keep predicting
+    import queue
+    q_write: "queue.Queue" = queue.Queue()
+
     def worker(wid):
         try:
             model = load_model("model_general_v3", framehop_prop=1.0, initialize=False)      # WorkerInferer.__init__
@@ -154,16 +159,32 @@ def test_worker_thread_contract_two_analyzers_on_one_device(dropin_cwd, weights_
             model.initialize()                                                                # WorkerInferer.run, in-thread
             for rep in range(5):
                 for i, c in enumerate(chunks):
-                    got[(wid, rep, i)] = model.predict(c).numpy().copy()
+                    q_write.put(((wid, rep, i), model.predict(c)))
+        except BaseException as exc:              # noqa: BLE001
+            errors.append(exc)
+        finally:
+            q_write.put(None)
+
+    def writer():
+        done = 0
+        try:
+            while done < 2:
+                item = q_write.get(timeout=120)
+                if item is None:
+                    done += 1
+                    continue
+                key, res = item
+                got[key] = res.numpy().copy()
         except BaseException as exc:              # noqa: BLE001
             errors.append(exc)
 
-    threads = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(2)] + [threading.Thread(target=writer)]
     for t in threads:
         t.start()
     for t in threads:
         t.join(120)
     assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
     assert len(got) == 2 * 5 * len(chunks)
     for (wid, rep, i), rows in got.items():
         assert np.array_equal(rows, want[i]), (wid, rep, i)
