@@ -105,3 +105,54 @@ def test_create_without_device_is_enodevice(lib):
     handle = C.c_void_p()
     assert lib.bd_create(C.byref(handle), 0, C.byref(w)) == -2          # BD_ENODEVICE, no CPU fallback
     assert b"no CPU path" in lib.bd_last_error()
+
+
+def test_round3_entry_points_reject_bad_arguments_without_a_device(lib):
+    """bd_predict_chunks / bd_calibrate / bd_get_scales / bd_set_activation_exponents: argument errors are BD_EINVAL with a
+    message, before any device call."""
+    ptrs = (C.c_void_p * 1)(None)
+    lens = (C.c_int64 * 1)(0)
+    assert lib.bd_predict_chunks(None, ptrs, lens, 1, 15360, 96, None, 0, None, None, -1, None, None) == -1
+    assert b"no output" in lib.bd_last_error()
+    dummy = (C.c_float * 4)()
+    assert lib.bd_predict_chunks(None, None, lens, 1, 15360, 96, None, 0, None, dummy, -1, None, None) == -1
+    assert lib.bd_predict_chunks(None, ptrs, lens, 65, 15360, 96, None, 0, None, dummy, -1, None, None) == -1
+    assert b"1..64" in lib.bd_last_error()
+    assert lib.bd_predict_chunks(None, ptrs, lens, 1, 15360, 96, None, 0, None, dummy, -1, None, None) == -1
+    assert b"null handle" in lib.bd_last_error()
+    assert lib.bd_calibrate(None, None, 0, 15360, 96, None, 0, None) == -1
+    assert lib.bd_get_scales(None, None, None) == -1
+    exps = (C.c_int32 * 13)()
+    assert lib.bd_set_activation_exponents(None, exps) == -1
+
+
+@pytest.mark.gpu
+def test_predict_chunks_argument_errors_on_device(engine):
+    import torch
+    lib_ = _lib.load()
+    x = torch.zeros(15600, device=engine.device)
+    out = torch.empty((1, engine.n_classes), device=engine.device)
+    ws_bytes = _lib.check(lib_.bd_workspace_bytes(engine._handle, x.numel(), 15360, 96))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=engine.device)
+    ptrs = (C.c_void_p * 1)(x.data_ptr())
+    lens = (C.c_int64 * 1)(x.numel())
+    s = torch.cuda.current_stream().cuda_stream
+
+    def call(mode=-1, word=None, p=ptrs):
+        return lib_.bd_predict_chunks(engine._handle, p, lens, 1, 15360, 96, ws.data_ptr(), ws.numel(), None, out.data_ptr(),
+                                      mode, word, s)
+
+    assert call() == 0
+    assert call(mode=3) == -1 and b"mode" in lib_.bd_last_error()
+    pageable = np.zeros(1, np.int32)                    # neither device memory nor pinned: the kernels could not write it
+    assert call(word=pageable.ctypes.data) == -1 and b"range_word" in lib_.bd_last_error()
+    odd = (C.c_void_p * 1)(x.data_ptr() + 2)
+    assert call(p=odd) == -1 and b"4-byte" in lib_.bd_last_error()
+    pinned = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+    assert call(word=pinned[2:].data_ptr()) == 0        # a word in the middle of a pinned block
+    torch.cuda.synchronize()
+    assert pinned.tolist() == [0, 0, 0, 0]
+    bad = (C.c_int32 * 13)(*([0] * 12 + [61]))
+    assert lib_.bd_set_activation_exponents(engine._handle, bad) == -1
+    exps, _ = engine.scales()
+    assert np.all(np.abs(exps) < 60)
