@@ -398,3 +398,40 @@ def test_gather_mode_resumes_with_rank_0s_plan(engine, tmp_path):
     mp.spawn(_gather_rank_resume, args=(2, port, str(audio), str(out)), nprocs=2, join=True)
     for rel in ("a/one", "two", "three32k"):
         assert (out / f"{rel}_buzzdetect.csv").read_bytes() == (tmp_path / "solo" / f"{rel}_buzzdetect.csv").read_bytes()
+
+
+@pytest.mark.gpu
+def test_config1_shape_on_the_device(weights_bundle, tmp_path):
+    """BASELINE config 1 as far as this build can take it: the reference's getting-started run analyses
+    audio_in/testbuzz.mp3 - 32 kHz mono, 3.82 s (docs/source/getting_started.rst:60-65) - with
+    embedders/yamnet + model_general_v3 and ONE worker on the CPU.  MP3 decoding (PyAV / libsndfile) is out of scope and
+    there is no CPU path, so the same shape runs here as a 32 kHz mono 16-bit WAV of that length through analyze() with the
+    Keras-3 'yamnet' embedder's mel constant, one analyzer, one streamer, default chunk length: 4 rows (hazard H4: the last
+    one mostly zero padding), the reference's columns, values against the f64 oracle of the same chain."""
+    import pandas as pd
+    from buzzdetect_amd.analyze import analyze
+    rate, n = 32000, int(round(61144 * 8 / 128000 * 32000))          # 61 144 bytes at 128 kbit/s
+    t = np.arange(n) / rate
+    x = 0.25 * np.sin(2 * np.pi * 230 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * np.random.default_rng(4).standard_normal(n)
+    audio = tmp_path / "audio_in"
+    audio.mkdir()
+    write_wav(audio / "testbuzz.wav", x, rate)
+    rep = analyze("model_general_v3", classes_out="all", framehop_prop=1, chunklength=200, dir_audio=str(audio),
+                  dir_out=str(tmp_path / "out"), embeddername="yamnet", analyzers_gpu=1, n_streamers=1, analyzers_cpu=1)
+    assert (rep.files_done, rep.chunks, rep.windows) == (1, 1, 4)
+    df = pd.read_csv(tmp_path / "out" / "testbuzz_buzzdetect.csv")
+    assert df["start"].tolist() == [0.0, 0.96, 1.92, 2.88]
+    assert list(df.columns) == ["start"] + [f"activation_{c}" for c in weights_bundle["classes"]]
+    b = weights_bundle
+    q = (np.clip(x, -1, 1 - 2 ** -15) * 32768.0).round().astype(np.int16).astype(np.float32) / 32768.0
+    # the reference rounds chunk edges to two decimals (results_coverage.py:59-70) and truncates to samples
+    # (src/stream/worker.py:110-111): the chunk is (0, 3.82) = samples [0, 122 240), 48 short of the file (hazard H3's kin)
+    from buzzdetect_amd import framing
+    (chunk,) = framing.gaps_to_chunklist([(0, n / rate)], framing.round_chunklength(200))
+    a0, a1 = framing.chunk_sample_range(chunk, rate)
+    assert (tuple(float(c) for c in chunk), a0, a1) == ((0.0, 3.82), 0, 122240)
+    mono = RO.resample(q[a0:a1], rate).astype(np.float32)
+    ref = O.predict(mono, b["blob"], b["mel_keras3"], b["head_kernel"], b["head_bias"], 15360, 96, np.float64)
+    assert ref.shape == (4, 13)
+    got = df[[f"activation_{c}" for c in b["classes"]]].to_numpy()
+    assert np.abs(got - ref.round(2)).max() <= 0.011
