@@ -380,7 +380,8 @@ def main() -> int:
 
     engines = [HipEngine(embeddername="yamnet_k2", modelname="model_general_v3", device=dev_index)
                for _ in range(max(1, args.streams))]
-    streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in engines[1:]]
+    # every analyzer gets a stream of its own (same-box A/B against putting the first one on the default stream: no difference)
+    streams = [torch.cuda.Stream(device) for _ in engines]
     comm_stream = torch.cuda.Stream(device)
     engine = engines[0]
     for e in engines:
