@@ -336,7 +336,7 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the host-resident (H2D-inclusive), analyze() and arithmetic-mode legs")
     ap.add_argument("--per-slot", action="store_true", help="print per-kernel times to stderr")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="analyzer streams per GPU: batches are dealt round-robin to this many engines, each on "
                          "its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253)")
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable layers: 9 = 8-wave kernel only, 12 = with the 12-wave kernel (no epilogue fusion; tuning)")
