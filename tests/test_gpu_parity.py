@@ -643,6 +643,58 @@ def test_hostile_weight_scales_stay_inside_the_gate(weights_bundle, layer, gain)
         eng.close()
 
 
+def _channel_scaled_blob(weights_bundle, layer, exps):
+    """As _scaled_blob, but with a power of two PER CHANNEL: input channel c of `layer`'s 1x1 convolution is carried
+    2^exps[c] times larger (depthwise kernel, BatchNorm mean and beta of that channel), column c of the 1x1 kernel
+    2^-exps[c] times smaller.  The network is exactly the same function."""
+    import json
+    from buzzdetect_amd import weights as W
+    blob = weights_bundle["blob"].copy()
+    with open(os.path.join(os.path.dirname(W.__file__), "data", "embedder_manifest.json")) as f:
+        entries = {e["name"]: e for e in json.load(f)["tensors"]}
+    k = 2 + 4 * (layer - 2)
+
+    def view(name):
+        e = entries[name]
+        off, n = e["offset"] // 4, int(np.prod(e["shape"]))
+        return blob[off:off + n].reshape(e["shape"])
+
+    g = np.ldexp(np.float32(1.0), np.asarray(exps, dtype=np.int32)).astype(np.float32)
+    view(f"layer_with_weights-{k}/depthwise_kernel")[:] *= g[None, None, :, None]
+    view(f"layer_with_weights-{k + 1}/moving_mean")[:] *= g
+    view(f"layer_with_weights-{k + 1}/beta")[:] *= g
+    view(f"layer_with_weights-{k + 2}/kernel")[:] /= g[None, None, :, None]
+    return blob
+
+
+@pytest.mark.parametrize("layer,spread", [(6, 8), (9, 10), (12, 12)])
+def test_channels_of_one_layer_at_very_different_scales(weights_bundle, layer, spread):
+    """What BatchNorm folding does to real weights: the channels of one layer's GEMM input sit at different scales, with
+    the 1x1 kernel's columns compensating.  One activation exponent per layer has to serve them all: with the layer's
+    largest channel at 2^8..2^9, a channel 2^spread smaller still has a normal low half down to 2^(spread - 11) of ITS
+    largest value.  Channels 2^8 .. 2^12 apart (random per channel, an exactly equivalent network) stay inside the gate."""
+    from buzzdetect_amd.engine import HipEngine
+    b = weights_bundle
+    cin = {6: 256, 9: 512, 12: 512}[layer]
+    rng = np.random.default_rng(layer * 31 + spread)
+    exps = -rng.integers(0, spread + 1, size=cin)
+    blob = _channel_scaled_blob(b, layer, exps)
+    x = O.synthetic_audio(HOP * 7 + 15600, seed=7000 + layer)
+    ref = O.predict(x, blob, b["mel"], b["head_kernel"], b["head_bias"], HOP, STEP, np.float64)
+    base = oracle_logits(x, b)
+    assert np.abs(ref - base).max() < 1e-9                 # the same function, as constructed
+    eng = HipEngine(embedder_blob=blob)
+    try:
+        eng.set_pointwise_mode("f32")
+        err_f32 = np.abs(eng.predict(x, 0.96).numpy() - ref).max()
+        eng.set_pointwise_mode("f16x3")
+        got = eng.predict(x, 0.96).numpy()
+        assert np.abs(got - ref).max() < max(1e-4, 2 * err_f32), (np.abs(got - ref).max(), err_f32)
+        assert eng.overflow_reruns == 0
+    finally:
+        eng.close()
+
+
 def test_scales_follow_calibration_audio():
     """bd_calibrate only ever widens: a pass over more audio leaves every per-layer maximum at least where it was, the
     exponents follow the maxima, and results stay inside the gate's noise (a power-of-two change of scale moves only
