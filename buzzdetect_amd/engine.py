@@ -391,6 +391,11 @@ class HipEngine:
             raise ValueError("a launch set takes 1..64 chunks")
         if want_logits and self.n_classes == 0:
             raise RuntimeError("engine was created without a classifier head")
+        for p in parts:
+            if (not isinstance(p, torch.Tensor) or p.dim() != 1 or p.dtype != torch.float32 or p.device != self.device
+                    or not p.is_contiguous() or p.data_ptr() % 4):
+                raise ValueError("launch() takes one-dimensional contiguous float32 tensors on the engine's device "
+                                 "(to_device() makes one out of anything predict() accepts)")
         nc = len(parts)
         lengths = (C.c_int64 * nc)(*[int(p.numel()) for p in parts])
         ptrs = (C.c_void_p * nc)(*[p.data_ptr() if p.numel() else None for p in parts])
