@@ -44,6 +44,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f
 PEAK_SPLIT_F16_TFLOPS = 2500.0 / 3.0             # dense f16 MFMA peak / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+# What the board's 1400 W limit leaves of the paper peak: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, constant operands,
+# held for 3 s, settles at 1987 TFLOP/s (2.0 GHz, 1345 W) - tools/ubench_power.hip, profiles/r03_ubench_power.txt.  The headline
+# loop itself runs AT the limit (the `power` object of the line), so this is the ceiling its matrix work is priced against in
+# `frac_of_sustained`; `frac` stays relative to the paper peak.
+SUSTAINED_F16_MFMA_TFLOPS = 1987.0
 PMC_FRONTEND_FILE = os.path.join("profiles", "r03_pmc_frontend_alone.csv")
 
 # per-window HBM bytes each depthwise / conv1 launch must move (read input + write output, f32 NHWC)
@@ -119,6 +124,73 @@ def free_port() -> int:
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+class PowerWatch:
+    """Board power and shader clock of one GPU from its hwmon files (sysfs, no HIP call), polled every 10 ms by a thread."""
+
+    def __init__(self, torch, dev_index: int):
+        import glob
+        self.dir = None
+        self.samples = []
+        self._stop = None
+        try:
+            props = torch.cuda.get_device_properties(dev_index)
+            want = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"
+            for card in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(card)).startswith(want):
+                    hw = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self.dir = hw[0]
+        except (AttributeError, OSError):
+            pass
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        import threading
+        if self.dir:
+            self._stop = threading.Event()
+
+            def poll():
+                while not self._stop.is_set():
+                    self.samples.append((time.perf_counter(), self._read("freq1_input"), self._read("power1_input")))
+                    time.sleep(0.01)
+
+            self._thread = threading.Thread(target=poll, daemon=True)
+            self._t0 = time.perf_counter()
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._stop is not None:
+            self._t1 = time.perf_counter()
+            self._stop.set()
+            self._thread.join()
+        return False
+
+    def summary(self):
+        """Averages over the second half of the watched region (the sensor lags the load by ~0.3 s)."""
+        if not self.dir or not self.samples:
+            return None
+        mid = 0.5 * (self._t0 + self._t1)
+        late = [s for s in self.samples if s[0] >= mid and s[1] and s[2]]
+        if not late:
+            return None
+        cap = self._read("power1_cap")
+        watts = sum(s[2] for s in late) / len(late) / 1e6
+        return {"avg_W": round(watts, 1), "cap_W": round(cap / 1e6, 1) if cap else None,
+                "frac_of_cap": round(watts / (cap / 1e6), 3) if cap else None,
+                "sclk_MHz_avg": round(sum(s[1] for s in late) / len(late) / 1e6, 1), "sclk_MHz_max": 2400, "samples": len(late),
+                "source": "hwmon power1_input / freq1_input of this GPU, 10 ms polls, second half of the timed region",
+                "what": "the timed region runs at the board's power limit with the shader clock pulled below its 2.4 GHz maximum: "
+                        "the hot path is power-bound (DESIGN.md 7b; per-kernel figures in profiles/r03_power_profile.txt, "
+                        "what the limit leaves of the paper peaks in profiles/r03_ubench_power.txt)"}
 
 
 def visible_gpus():
@@ -474,7 +546,8 @@ def main() -> int:
     # region 1: the number reported as `value` — nothing but the hot path (and, for N > 1, the gathers)
     for e in engines:
         e.profile_enable(False)
-    elapsed = timed_region(args.steps)
+    with PowerWatch(torch, dev_index) as watch:
+        elapsed = timed_region(args.steps)
     windows_per_step = windows_per_file * files_per_step
     total_windows = windows_per_step * args.steps
     value = total_windows / elapsed
@@ -531,6 +604,10 @@ def main() -> int:
                        "timing": "value from K clean steps; per-kernel HIP-event times from a second region "
                                  f"({ev_steps} recordings, one stream)"},
         }
+        power = watch.summary() if rank == 0 else None
+        if power:
+            out["power"] = power
+            log(f"board power {power['avg_W']} W of {power['cap_W']} W, shader clock {power['sclk_MHz_avg']} MHz")
         if events_on and launches.sum() > 0 and args.per_slot:
             for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches, pool_fused=args.sep_variant is None).items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
@@ -563,6 +640,10 @@ def main() -> int:
                     "peak_note": "achieved = algorithmic f32-equivalent FLOP/s (1x1 conv + depthwise of the layers this "
                                  "kernel runs); every product is 3 f16 MFMAs, so peak = 2500 TFLOP/s dense f16 / 3",
                     "executed_f16_mfma_tflops": round(3 * achieved, 1),
+                    "peak_sustained": round(SUSTAINED_F16_MFMA_TFLOPS / 3.0, 1),
+                    "frac_of_sustained": round(3 * achieved / SUSTAINED_F16_MFMA_TFLOPS, 4),
+                    "peak_sustained_note": "back-to-back f16 MFMAs alone hold 1987 TFLOP/s at the 1400 W board limit (2.0 GHz; "
+                                           "profiles/r03_ubench_power.txt), not the 2500 of the 2.4 GHz paper peak",
                     "hbm_GBps_algorithmic": round(d["bytes"] / sec / 1e9, 1),
                 }
             else:

@@ -2,6 +2,7 @@
 // per-chunk launch plan, index arithmetic and per-stage event timing.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -116,6 +117,20 @@ struct Scope {
         if (on) mark(e, s, slot);
     }
 };
+
+// Developer build (-DBD_KERNEL_TRACE) only: BD_REPEAT_SLOT=<profile slot> BD_REPEAT_N=<n> launches that slot's kernel n times
+// per pass (same operands: the kernels are idempotent), so that one kernel dominates a run - its sustained clock and the
+// board power it draws alone can then be read from hwmon (tools/power_profile.py).  The shipped library reads no environment.
+#ifdef BD_KERNEL_TRACE
+static int repeat_of(int slot) {
+    static const int want = getenv("BD_REPEAT_SLOT") ? atoi(getenv("BD_REPEAT_SLOT")) : -1;
+    static const int n = getenv("BD_REPEAT_N") ? atoi(getenv("BD_REPEAT_N")) : 1;
+    return slot == want ? n : 1;
+}
+#define BD_REPEAT_EXTRA(slot) for (int rep_ = repeat_of(slot) - 1; rep_ > 0; --rep_)
+#else
+#define BD_REPEAT_EXTRA(slot) if (false)
+#endif
 
 // ---- index arithmetic: embedders/yamnet/features.py:82-108, :42-46, :65-76 ----
 int64_t padded_length(int64_t n, int32_t hop) {
@@ -770,6 +785,9 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         Scope sc(e, stream, 0);
         bd::launch_logmel(chunk_pcm[c], chunk_samples[c], plan.frames[c],
                           logmel + (int64_t)plan.map.frame_base[c] * BD_MEL_BANDS, e->d_tables, stream);
+        BD_REPEAT_EXTRA(0)
+            bd::launch_logmel(chunk_pcm[c], chunk_samples[c], plan.frames[c],
+                              logmel + (int64_t)plan.map.frame_base[c] * BD_MEL_BANDS, e->d_tables, stream);
     }
     const float* const lm = logmel;
     for (int64_t w0 = 0; w0 < g.n_windows; w0 += group) {
@@ -793,6 +811,8 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             {
                 Scope sc(e, stream, 5);      // timed in the slot of pointwise 3 (slots 1-4 stay empty)
                 bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+                BD_REPEAT_EXTRA(5)
+                    bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
             }
             last = buf_a;
             last_floats = (int64_t)gw * 24 * 16 * 128;
@@ -824,10 +844,13 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 stop_stage < 0 && skip_dw_layer != l) {
                 float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
                 if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream)) {
+                    BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream);
                     if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                     if (logits) {
                         Scope sc(e, stream, 28);
                         bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
+                        BD_REPEAT_EXTRA(28)
+                            bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
                     }
                     pooled_done = true;
                     break;
@@ -839,6 +862,8 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             if (e->fuse_sep && e->fuse_next_dw && mode != 0 && e->sep_variant <= 1 && l + 1 < 13 &&
                 (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
                 bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream)) {
+                BD_REPEAT_EXTRA(3 + 2 * l)
+                    (void)bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 skip_dw_layer = l + 1;
                 last = buf_b;
@@ -847,6 +872,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             if (e->fuse_sep && mode != 0 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
                 bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
+                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
                 float* t = buf_a;
@@ -870,6 +896,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             {
                 Scope sc(e, stream, 3 + 2 * l);
                 bd::launch_pointwise(buf_b, buf_a, (int64_t)gw * L.h_out * L.w_out, L, stream);
+                BD_REPEAT_EXTRA(3 + 2 * l) bd::launch_pointwise(buf_b, buf_a, (int64_t)gw * L.h_out * L.w_out, L, stream);
             }
             last = buf_a;
             last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
