@@ -1375,12 +1375,30 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
 // Twelve waves per CU leave 168 registers per wave, 96 of them accumulators: A fragments are read per 32-row tile
 // and weight fragments per 16-deep k step, double-buffered.  The output goes out in three 32-row chunks.
 // Plain instantiation only (no epilogue fusion); same products in the same order: bit-identical.
+//
+// A run of such layers (8-11: the same 6 x 4 map, 512 -> 512) can go out as ONE launch: a tile is four whole windows, a
+// window's rows depend on no other window's, so a workgroup takes its own tile through all the layers of the run, writing each
+// layer's output to the other of two buffers and reading it back (same CU, same L2) as the next layer's slabs.  Between
+// layers: the tile's stores complete (vmcnt 0), a workgroup barrier, and the CU's L1 is invalidated (workgroup scope).
+// Per layer the instructions are those of a single-layer launch: bit-identical.
+struct W12Chain {
+    const float* dw_w[4];
+    const float* dw_b[4];
+    const _Float16* whi[4];
+    const _Float16* wlo[4];
+    const float* pw_u[4];
+    const float* pw_b[4];
+};
+// (selects, not an indexed load: indexing a by-value kernel argument with a run-time index makes a scratch copy of it)
+template <typename T>
+__device__ __forceinline__ T w12_pick(const T (&a)[4], int i) {
+    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
+}
+
 template <int XPMAX, bool TRACE, bool PLAIN, int KT = 0>   // KT: the number of input channels when known at compile time
 __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8-11: tap and slab strides become immediates)
-    const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-    const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_u,
-    const float* __restrict__ pw_b,
-    float* __restrict__ Cout, long long M, int K_, int H, int W, unsigned* __restrict__ dbg,
+    float* B0, float* B1, const W12Chain ch, int nl,        // layer i reads B[i & 1] and writes B[(i & 1) ^ 1]
+    long long M, int K_, int H, int W, unsigned* __restrict__ dbg,
     unsigned* __restrict__ range_flag) {
     const int K = KT > 0 ? KT : K_;
     float rmax = 0.0f;
@@ -1396,9 +1414,6 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
     float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K]
     float* const Cc = Wall + 10 * K;                                   // [32][BN + 4]
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = K / 32;                    // even, >= 4
     const int P = H * W;                      // whole windows: P divides BM
     const unsigned m0u = blockIdx.x * (unsigned)BM;
@@ -1408,11 +1423,26 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
     int tsn = 0;
 #define W12_TS(WH)                                                                                        \
     if constexpr (TRACE) {                                                                                \
-        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 8) && tsn < 32)                         \
+        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 8) && tsn < 32 && li == 0)              \
             dbg[((wave >> 3) * 32 + tsn) * 2 + (WH)] = (unsigned)__builtin_readcyclecounter();            \
         if (WH) ++tsn;                                                                                    \
     }
 
+    for (int li = 0; li < nl; ++li) {
+    // the thread's index tables are rebuilt per layer (a hundred instructions): kept across the layer loop they would
+    // not fit the 168 registers and the compiler spills them INTO the stage loops
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* const X = (li & 1) ? B1 : B0;
+    float* const Cout = (li & 1) ? B0 : B1;
+    const float* const dw_w = w12_pick(ch.dw_w, li);
+    const float* const dw_b = w12_pick(ch.dw_b, li);
+    const _Float16* const Wfhi = w12_pick(ch.whi, li);
+    const _Float16* const Wflo = w12_pick(ch.wlo, li);
+    const float* const pw_u = w12_pick(ch.pw_u, li);
+    const float* const pw_b = w12_pick(ch.pw_b, li);
     if (wave >= 8) {
         // ================================================================= producers (as sep_ws_kernel, XD + VS)
         const int pt = tid - 512;
@@ -1489,25 +1519,28 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
             *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
         }                                                                                                 \
     }
-        if (pt < 24) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+        if (pt < 24) {
+            float z = 0.f;
+            asm volatile("" : "+v"(z));        // (a zero the compiler would otherwise keep - and spill - across the layers)
+            *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{z, z, z, z};
+        }
+        {
+            // taps + shift of this layer into Wall by LDS-DMA, 1 KB per instruction, issued BEFORE the slabs: the counted wait
+            // below (all but the two youngest slabs) then covers them.  (Ten v4f per lane through registers, as the 8-wave
+            // kernel does it, no longer fit beside the layer loop's state: the compiler spilled them one load at a time.)
+            // Lanes past the table re-read its last entry into the first bytes of Cc, which the epilogue overwrites.
+            const int n_w = 9 * (K / 4), n_all = 10 * (K / 4);
+            for (int c = pw; c * 64 < n_all; c += 4) {
+                int i = c * 64 + lane;
+                i = i < n_all ? i : n_all - 1;
+                const float* src = i < n_w ? dw_w + 4 * (size_t)i : dw_b + 4 * (size_t)(i - n_w);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Wall + c * 256), 16, 0, 0);
+            }
+        }
         W12_DMA(0, 0)
         W12_DMA(32, 1)
         W12_DMA(64, 2)
-        {
-            constexpr int TI = 10;
-            const int n_w = 9 * (K / 4), n_all = 10 * (K / 4);
-            v4f tw_[TI];
-#pragma unroll
-            for (int j = 0; j < TI; ++j) {
-                const int i = pt + 256 * j;
-                if (i < n_all) tw_[j] = *reinterpret_cast<const v4f*>(i < n_w ? dw_w + 4 * (size_t)i : dw_b + 4 * (size_t)(i - n_w));
-            }
-#pragma unroll
-            for (int j = 0; j < TI; ++j) {
-                const int i = pt + 256 * j;
-                if (i < n_all) *reinterpret_cast<v4f*>(Wall + 4 * (size_t)i) = tw_[j];
-            }
-        }
         W12_PSYNC(2 * ND)
         W12_DW(0, 0, 0)
         W12_PSYNC(ND)
@@ -1623,29 +1656,53 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
             }
             __syncthreads();
         }
-        return;
     }
-    // ---- epilogue, producer part: help store the three chunks ----
+    if (wave >= 8) {
+        // ---- epilogue, producer part: help store the three chunks ----
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));       // addresses computed here, not ahead of the stage loop
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        __syncthreads();
-        for (int id = tid; id < 32 * (BN / 4); id += 768) {
-            const int ml = id / (BN / 4), c4_ = id % (BN / 4);
-            const long long m = m0 + 32 * i + ml;
-            if (m < M) *reinterpret_cast<v4f*>(Cout + (size_t)m * N + c4_ * 4) = *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);
+        for (int i = 0; i < TM; ++i) {
+            __syncthreads();
+            for (int id = tid_e; id < 32 * (BN / 4); id += 768) {
+                const int ml = id / (BN / 4), c4_ = id % (BN / 4);
+                const long long m = m0 + 32 * i + ml;
+                if (m < M) *reinterpret_cast<v4f*>(Cout + (size_t)m * N + c4_ * 4) = *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    range_report(rmax, range_flag);
+    if (li + 1 < nl) {                        // this tile's rows of the next layer's input: written and visible to this CU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // L1 only (workgroup scope): the buffer read next was last read two layers ago.  NOT `buffer_inv sc1`: the agent-scope
+        // form also drops this XCD's L2 contents - issued by 12 waves of 32 drifting workgroups it cost the run a third of its
+        // speed (layers 2-4 of a run 58-68 us each instead of 41-44; 1.389 vs 1.496 M windows/s on one stream).
+        asm volatile("buffer_inv sc0" ::: "memory");
+    }
+    }   // layers of the run
+    if (threadIdx.x >= 512) range_report(rmax, range_flag);
 #undef W12_TS
 }
 
+// Layers L[0 .. nl) (1 <= nl <= 4, all of one shape) in one launch: layer i reads (i odd ? b : a) and writes the other
+// buffer, so the run's output is in b for odd nl and in a for even nl.  nl == 1 is the plain single-layer launch.
 template <int XPMAX, bool PLAIN = false>
-void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream) {
+void launch_sep_w12(float* a, float* b, const SepLayer* L, int nl, long long M, hipStream_t stream) {
     if constexpr (!PLAIN) {                   // mode 2: the same kernel with one MFMA per product
-        if (L.pw_mode == 2) return launch_sep_w12<XPMAX, true>(X, L, out, M, stream);
+        if (L[0].pw_mode == 2) return launch_sep_w12<XPMAX, true>(a, b, L, nl, M, stream);
     }
-    const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + (size_t)40 * L.cin + 32u * (512 + 4) * 4;
+    W12Chain ch{};
+    for (int i = 0; i < nl; ++i) {
+        ch.dw_w[i] = dw_w_of(L[i]);
+        ch.dw_b[i] = dw_b_of(L[i]);
+        ch.whi[i] = static_cast<const _Float16*>(L[i].pw_fhi);
+        ch.wlo[i] = static_cast<const _Float16*>(L[i].pw_flo);
+        ch.pw_u[i] = L[i].pw_u;
+        ch.pw_b[i] = L[i].pw_b;
+    }
+    const int cin = L[0].cin, H = L[0].h_out, W = L[0].w_out;
+    const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + (size_t)40 * cin + 32u * (512 + 4) * 4;
     constexpr size_t lds_max = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + 40u * 512u + 32u * (512 + 4) * 4;
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&sep_w12_kernel<XPMAX, false, PLAIN>, (int)lds_max, lds_once);
@@ -1661,9 +1718,8 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         }
         (void)hipMemsetAsync(dbg, 0, 512, stream);
-        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
-                           static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, out, M,
-                           L.cin, L.h_out, L.w_out, dbg, L.range_flag);
+        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, a, b, ch, nl, M,
+                           cin, H, W, dbg, L[0].range_flag);
         (void)hipStreamSynchronize(stream);
         unsigned h[128];
         (void)hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
@@ -1681,17 +1737,15 @@ void launch_sep_w12(const float* X, const SepLayer& L, float* out, long long M, 
         return;
     }
 #endif
-    if (L.cin == 512) {
+    if (cin == 512) {
         static std::once_flag lds_once512[kMaxDevices];
         allow_dynamic_lds(&sep_w12_kernel<XPMAX, false, PLAIN, 512>, (int)lds_max, lds_once512);
-        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN, 512>), dim3((unsigned)tiles), dim3(768), lds, stream, X, dw_w_of(L),
-                           dw_b_of(L), static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u,
-                           L.pw_b, out, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
+        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN, 512>), dim3((unsigned)tiles), dim3(768), lds, stream, a, b, ch, nl,
+                           M, cin, H, W, nullptr, L[0].range_flag);
         return;
     }
-    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
-                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, out, M,
-                       L.cin, L.h_out, L.w_out, nullptr, L.range_flag);
+    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, a, b, ch, nl, M, cin,
+                       H, W, nullptr, L[0].range_flag);
 }
 
 // --------------------------------------------------------------------------- pointwise with the weights in registers
@@ -2819,11 +2873,28 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
     }
     if ((P == 96 || P == 24 || P == 6) && L.cout % 256 == 0) {
         // 512 -> 512 channels: the 12-wave kernel computes the depthwise once per row tile instead of once per 256 columns
-        if (variant != 9 && L.cout == 512 && L.cin <= 512) launch_sep_w12<96>(in, L, out, M, stream);
+        if (variant != 9 && L.cout == 512 && L.cin <= 512) launch_sep_w12<96>(const_cast<float*>(in), out, &L, 1, M, stream);
         else launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
         return true;
     }
     return false;
+}
+
+// A run of stride-1 512 -> 512 layers on the 6 x 4 map (layers 8-11) as one launch of the 12-wave kernel.  Returns how many
+// layers of L[0 .. max_layers) it ran (0: none - the caller goes layer by layer); the output of an odd count is in b, of an
+// even count in a.  A layer whose successor is a stride-2 one is left to launch_separable_fused_next_dw.
+int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream) {
+    int n = 0;
+    while (n < 4 && n + 1 < max_layers) {     // n + 1 < max_layers: L[n + 1] exists
+        const SepLayer& l = L[n];
+        if (l.stride != 1 || l.cin != 512 || l.cout != 512 || l.h_out != 6 || l.w_out != 4 || L[n + 1].stride != 1) break;
+        if (l.pw_mode != L[0].pw_mode) break;
+        ++n;
+    }
+    const long long M = (long long)windows * 24;
+    if (n < 2 || windows <= 0 || M >= (1LL << 31)) return 0;
+    launch_sep_w12<96>(a, b, L, n, M, stream);
+    return n;
 }
 
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,

@@ -58,6 +58,7 @@ struct bd_engine {
     bool fuse_stem3 = true;           // (always equal to fuse_stem: the layers 1-2 only kernel is gone)
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
+    bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
     int sep_variant = 0;
     bool l4_band_tiles = false;       // layer 4 + depthwise 5 as overlapping band tiles of the generic kernel (bd_set_fusion separable = 2)
     float* d_pool = nullptr;          // one allocation for every folded tensor
@@ -870,6 +871,21 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * L.cout;
                 continue;
             }
+            if (e->fuse_sep && e->fuse_run && mode != 0 && e->sep_variant <= 1 && stop_stage < 0 && skip_dw_layer != l) {
+                const int ran = bd::launch_separable_run(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
+                if (ran > 0) {
+                    l += ran - 1;
+                    if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);      // the whole run in its last layer's slot
+                    if (ran & 1) {
+                        float* t = buf_a;
+                        buf_a = buf_b;
+                        buf_b = t;
+                    }
+                    last = buf_a;
+                    last_floats = (int64_t)gw * sep[l].h_out * sep[l].w_out * sep[l].cout;
+                    continue;
+                }
+            }
             if (e->fuse_sep && mode != 0 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
                 bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
                 BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream);
@@ -1168,15 +1184,16 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
-    if (separable != 0 && separable != 1 && separable != 2 && separable != 9 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 9 or 12");
+    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 9 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 9 or 12");
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_stem4 = stem >= 3;
     h->fuse_sep = separable != 0;
-    h->fuse_next_dw = separable == 1 || separable == 2;
+    h->fuse_next_dw = separable >= 1 && separable <= 3;
+    h->fuse_run = separable == 1 || separable == 2;
     h->l4_band_tiles = separable == 2;
-    h->sep_variant = separable > 2 ? separable : 0;
+    h->sep_variant = separable > 3 ? separable : 0;
     return BD_OK;
 }
 

@@ -273,7 +273,8 @@ class HipEngine:
     def set_fusion(self, stem=True, separable=True) -> None:
         """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, False = off) and fused
         depthwise+pointwise kernels (True = default path, 2 = the same with layer 4 as band tiles of the generic kernel,
-        9 / 12 = plain fused layers on the 8-wave / 12-wave kernel, False = one kernel per op)."""
+        3 = the same with one launch per layer for layers 8-11 instead of one for the four, 9 / 12 = plain fused layers on
+        the 8-wave / 12-wave kernel, False = one kernel per op)."""
         stem_code = 3 if stem is True else int(stem)
         with self._lock:
             _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))

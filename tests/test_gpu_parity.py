@@ -354,7 +354,7 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 2, 9, 12):            # 2: layer 4 as band tiles instead of a window per workgroup
+        for variant in (1, 2, 3, 9, 12):         # 2: layer 4 as band tiles instead of a window per workgroup; 3: layers 8-11 one launch each
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
@@ -364,6 +364,27 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
                 assert np.array_equal(got, ref), (variant, st)
             assert np.array_equal(engine.predict(x, 0.96).numpy(), plain_logits)
     finally:
+        engine.set_fusion(True, True)
+
+
+@pytest.mark.parametrize("windows", [1, 4, 5, 131, 1025])
+def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, windows):
+    """Default path: every workgroup of the 12-wave kernel takes its four windows through layers 8-11 in ONE launch (each
+    layer's output written to the other buffer and read back by the same workgroup).  Against one launch per layer
+    (bd_set_fusion separable = 3): the same bits, in both f16 modes, whole and partial tiles, first and last workgroup."""
+    x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=800 + windows)
+    try:
+        for mode in ("f16x3", "f16"):
+            engine.set_pointwise_mode(mode)
+            engine.set_fusion(True, 3)
+            ref_logits = engine.predict(x, 0.96).numpy()
+            ref_emb = engine.embed(x, 0.96).numpy()
+            engine.set_fusion(True, True)
+            for _ in range(2):                   # twice: the second pass reads buffers the first one left behind
+                assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), mode
+            assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), mode
+    finally:
+        engine.set_pointwise_mode("f16x3")
         engine.set_fusion(True, True)
 
 

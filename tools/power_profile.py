@@ -46,6 +46,7 @@ def child(seconds):
     from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
     hw = hwmon_of(0)
     eng = HipEngine(device=0)
+    eng.set_fusion(True, 3)            # layers 8-11 one launch each: a repeated launch must not consume its own output
     hop, step = hop_samples(0.96), patch_step(0.96)
     x = torch.randn(1024 * hop + 240, device="cuda") * 0.1
     out = torch.empty((1024, 13), device="cuda")
