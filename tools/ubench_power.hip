@@ -2,6 +2,7 @@
 //   mfma      back-to-back v_mfma_f32_32x32x16_f16 on every SIMD (1 and 2 waves per SIMD), and the same at reduced duty
 //   valu      v_pk_fma_f32 / v_fma_f32 streams
 //   lds       ds_read_b128 streams
+//   l2        every CU streaming the same L2-resident 2 MB
 //   hbm       a float4 copy of 2 x 1 GiB
 // each held for a few seconds.  Not part of the product; evidence for DESIGN.md's "power-bound" section.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_power tools/ubench_power.hip -lpthread && tools/ubench_power [seconds]
@@ -99,6 +100,21 @@ __global__ __launch_bounds__(512) void lds_kernel(float* sink, int iters) {
             s.w += v.w;
         }
         at += 64;
+    }
+    if (s.x + s.y + s.z + s.w == 12345.678f) sink[0] = s.x;
+}
+
+// every workgroup streams the same `n` float4 (2 MB: resident in each XCD's L2, far too large for the 32 KB L1) `iters` times
+__global__ __launch_bounds__(512) void l2_kernel(const float4* __restrict__ in, float* sink, int n, int iters) {
+    float4 s = {0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        for (int i = threadIdx.x; i < n; i += 512 * 4) {
+            const float4 a = in[i], b = in[i + 512], c = in[i + 1024], d = in[i + 1536];
+            s.x += a.x + b.x + c.x + d.x;
+            s.y += a.y + b.y + c.y + d.y;
+            s.z += a.z + b.z + c.z + d.z;
+            s.w += a.w + b.w + c.w + d.w;
+        }
     }
     if (s.x + s.y + s.z + s.w == 12345.678f) sink[0] = s.x;
 }
@@ -238,6 +254,16 @@ int main(int argc, char** argv) {
     {
         auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(lds_kernel, dim3(cus), dim3(512), 0, 0, sink, it_l); });
         report("ds_read_b128, 2 waves/SIMD", r, (double)cus * 512 * it_l * 8 * 16, "TB/s", 1e-12);
+    }
+    {
+        const int n = 1 << 17;                 // float4: 2 MB
+        float4* in;
+        CHECK(hipMalloc(&in, (size_t)n * 16));
+        CHECK(hipMemset(in, 1, (size_t)n * 16));
+        const int it_2 = 40;
+        auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(l2_kernel, dim3(cus), dim3(512), 0, 0, in, sink, n, it_2); });
+        report("global_load_dwordx4 of an L2-resident 2 MB", r, (double)cus * n * 16 * it_2, "TB/s", 1e-12);
+        CHECK(hipFree(in));
     }
     {
         const size_t n = (size_t)1 << 26;      // float4: 1 GiB each way
