@@ -105,8 +105,10 @@ def slot_plan(launches, pool_fused=True):
                     # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own
                     # (epilogue fusion exists only in the 8-wave kernel)
                     # (layer 4 + depthwise 5 have their own kernel: a window per workgroup, no overlapping bands)
-                    plan[pw_slot - 2] = (nm + f"+dw{layer}", "l4_window_kernel" if layer == 5 else "sep_ws_kernel",
-                                         nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
+                    # (512 output channels - layers 6 and 12 - run the 12-wave kernel, which then applies this depthwise to
+                    #  256 channels at a time: cnn.hip launch_separable_fused_next_dw)
+                    prev_fam = "l4_window_kernel" if layer == 5 else ("sep_w12_kernel" if pool_fused and c == 512 else "sep_ws_kernel")
+                    plan[pw_slot - 2] = (nm + f"+dw{layer}", prev_fam, nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
                 # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
                 fam = "sep_w12_kernel" if (pool_fused and c == 512 and cout == 512) else "sep_ws_kernel"

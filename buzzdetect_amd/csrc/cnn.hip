@@ -1395,11 +1395,16 @@ __device__ __forceinline__ T w12_pick(const T (&a)[4], int i) {
     return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
 }
 
-template <int XPMAX, bool TRACE, bool PLAIN, int KT = 0>   // KT: the number of input channels when known at compile time
+//
+// NDW = 1 (layers 6 and 12, whose successor is a stride-2 layer; single-layer launches only): the tile is not written; the NEXT
+// layer's stride-2 depthwise (taps ndw_w, shift ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS - 256 channels
+// at a time, consumer waves 0-3 then 4-7 parking their columns in an f32 tile that overlays the (dead) stage buffers - and
+// only that result goes to B1.  The 8-wave kernel does the same per 256-column tile, i.e. runs the layer's own depthwise twice.
+template <int XPMAX, bool TRACE, bool PLAIN, int KT = 0, int NDW = 0>   // KT: the number of input channels when known at compile time
 __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8-11: tap and slab strides become immediates)
     float* B0, float* B1, const W12Chain ch, int nl,        // layer i reads B[i & 1] and writes B[(i & 1) ^ 1]
     long long M, int K_, int H, int W, unsigned* __restrict__ dbg,
-    unsigned* __restrict__ range_flag) {
+    unsigned* __restrict__ range_flag, const float* __restrict__ ndw_w = nullptr, const float* __restrict__ ndw_b = nullptr) {
     const int K = KT > 0 ? KT : K_;
     float rmax = 0.0f;
     constexpr int BM = 96, BN = 512, N = 512;
@@ -1413,6 +1418,7 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
     char* const Al = Ah + 2 * A_BYTES;
     float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K]
     float* const Cc = Wall + 10 * K;                                   // [32][BN + 4]
+    constexpr int NDW_TAPS_AT = BM * (256 + 4) * 4;                    // NDW = 1: the next layer's taps + shift [10][N], behind the f32 tile
 
     const int nk = K / 32;                    // even, >= 4
     const int P = H * W;                      // whole windows: P divides BM
@@ -1428,6 +1434,52 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
         if (WH) ++tsn;                                                                                    \
     }
 
+    // next layer's stride-2 depthwise on channels 256 HALF .. of the tile parked in Ct (whole windows: every tap is in LDS);
+    // the arithmetic of sep_ws_kernel's NDW = 1 epilogue.  A wave's 64 lanes are the 64 channel quads of ONE output position
+    // (12 waves x 2 positions = the tile's 24), so position, padding tests and row arithmetic are scalar, and the map's size is
+    // a constant of the instantiation (layer 6: 12 x 8 with K = 256, layer 12: 6 x 4 with K = 512): no division survives.
+#define W12_NDW(HALF)                                                                                     \
+    {                                                                                                     \
+        const float* Ct_ = reinterpret_cast<const float*>(smem_raw);                                      \
+        constexpr int CTW = 256 + 4;                                                                      \
+        constexpr int HH = KT == 256 ? 12 : 6, WW = KT == 256 ? 8 : 4, PP = HH * WW;                      \
+        constexpr int OW2 = WW / 2, P2 = (HH / 2) * OW2, NPOS = (BM / PP) * P2;                           \
+        static_assert(NPOS == 24, "two output positions per wave");                                       \
+        int tn_ = tid;                                                                                    \
+        asm volatile("" : "+v"(tn_));       /* taps requested HERE: hoisted to the kernel's start they were spilled */ \
+        const int c4 = tn_ & 63, nc = 256 * (HALF) + c4 * 4;                                              \
+        const int slot = __builtin_amdgcn_readfirstlane(tn_ >> 6);                                        \
+        v4f wt[9];                                                                                        \
+        const float* Nw_ = reinterpret_cast<const float*>(smem_raw + NDW_TAPS_AT);   /* [10][N], there since the prologue */ \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(Nw_ + t * N + nc); \
+        const v4f shift = *reinterpret_cast<const v4f*>(Nw_ + 9 * N + nc);                                \
+        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};                                                           \
+        _Pragma("unroll") for (int pp = 0; pp < NPOS; pp += 12) {                                         \
+            const int ps = pp + slot;                                                                     \
+            const int wl = ps / P2, pos2 = ps % P2;                                                       \
+            if (m0 + (long long)wl * PP >= M) continue;                                                   \
+            const int oh = pos2 / OW2, ow = pos2 % OW2;                                                   \
+            const float* base_ = Ct_ + (wl * PP + 2 * oh * WW + 2 * ow) * CTW + c4 * 4;                   \
+            v4f acc2 = shift;                                                                             \
+            _Pragma("unroll") for (int kh = 0; kh < 3; ++kh)                                              \
+                _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                        \
+                    v4f v = zero4;           /* SAME padding: 0 before, 1 after - a wave-uniform test */  \
+                    if (2 * oh + kh < HH && 2 * ow + kw < WW) v = *reinterpret_cast<const v4f*>(base_ + (kh * WW + kw) * CTW); \
+                    acc2 = __builtin_elementwise_fma(v, wt[kh * 3 + kw], acc2);                           \
+                }                                                                                         \
+            acc2.x = fmaxf(acc2.x, 0.0f);                                                                 \
+            acc2.y = fmaxf(acc2.y, 0.0f);                                                                 \
+            acc2.z = fmaxf(acc2.z, 0.0f);                                                                 \
+            acc2.w = fmaxf(acc2.w, 0.0f);                                                                 \
+            const long long row2 = (long long)(m0u / (unsigned)PP + wl) * P2 + pos2;                      \
+            *reinterpret_cast<v4f*>(B1 + (size_t)row2 * N + nc) = acc2;                                   \
+        }                                                                                                 \
+    }
+#define W12_WALL(I)                                                                                       \
+    if constexpr (TRACE) {                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) dbg[128 + blockIdx.x * 8 + (I)] = (unsigned)wall_clock64(); \
+    }
+    W12_WALL(0)
     for (int li = 0; li < nl; ++li) {
     // the thread's index tables are rebuilt per layer (a hundred instructions): kept across the layer loop they would
     // not fit the 168 registers and the compiler spills them INTO the stage loops
@@ -1538,6 +1590,16 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
                                                  (__attribute__((address_space(3))) void*)(Wall + c * 256), 16, 0, 0);
             }
         }
+        if constexpr (NDW == 1) {             // ... and the NEXT layer's taps + shift for the epilogue, 20 KB behind the f32 tile
+            float* const Nw = reinterpret_cast<float*>(smem_raw + NDW_TAPS_AT);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const int i = (pw + 4 * c) * 64 + lane;            // float4 index into [10][N / 4]: 9 rows of taps, then the shift
+                const float* src = i < 9 * (N / 4) ? ndw_w + 4 * (size_t)i : ndw_b + 4 * (size_t)(i - 9 * (N / 4));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Nw + (pw + 4 * c) * 256), 16, 0, 0);
+            }
+        }
         W12_DMA(0, 0)
         W12_DMA(32, 1)
         W12_DMA(64, 2)
@@ -1632,11 +1694,48 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
 #undef W12_BLOAD
         // ---- epilogue, consumer part: bias + ReLU, 32 rows at a time through the chunk ----
         float bias_[TN], unsc_[TN];
+        if constexpr (NDW == 0) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bias_[j] = pw_b[64 * wc + j * 32 + frow];
-            unsc_[j] = pw_u[64 * wc + j * 32 + frow];
+            for (int j = 0; j < TN; ++j) {
+                bias_[j] = pw_b[64 * wc + j * 32 + frow];
+                unsc_[j] = pw_u[64 * wc + j * 32 + frow];
+            }
         }
+        if constexpr (NDW == 1) {
+            float* const Ct = reinterpret_cast<float*>(smem_raw);      // [BM][256 + 4]: every stage buffer is dead by now
+            // (written out per half: in a loop over the halves the compiler computes all 96 outputs ahead of it and spills them)
+#define W12_PARK()                                                                                        \
+    {                                                                                                     \
+        int fr_ = frow;                     /* addresses and outputs formed HERE: left to itself the compiler forms */ \
+        float us_[TN], bs_[TN];             /* both during the last stage's MFMAs and spills them */      \
+        asm volatile("" : "+v"(fr_));                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                  \
+            us_[j] = pw_u[64 * wc + j * 32 + fr_];                                                        \
+            bs_[j] = pw_b[64 * wc + j * 32 + fr_];                                                        \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
+            float* const cb_ = Ct + (32 * i + 4 * fh) * (256 + 4) + 64 * (wc & 3) + fr_;                  \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                            \
+                    cb_[((r & 3) + 8 * (r >> 2)) * (256 + 4) + j * 32] = fmaxf(fmaf(acc[i][j][r], us_[j], bs_[j]), 0.0f); \
+        }                                                                                                 \
+    }
+            W12_WALL(1)
+            if (wc < 4) { W12_PARK() }
+            W12_WALL(2)
+            __syncthreads();
+            W12_WALL(3)
+            W12_NDW(0)
+            W12_WALL(4)
+            __syncthreads();
+            if (wc >= 4) { W12_PARK() }
+            __syncthreads();
+            W12_WALL(5)
+            W12_NDW(1)
+            __syncthreads();
+            W12_WALL(6)
+#undef W12_PARK
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1661,6 +1760,14 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
         // ---- epilogue, producer part: help store the three chunks ----
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));       // addresses computed here, not ahead of the stage loop
+        if constexpr (NDW == 1) {
+            __syncthreads();
+            W12_NDW(0)
+            __syncthreads();
+            __syncthreads();
+            W12_NDW(1)
+            __syncthreads();
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             __syncthreads();
@@ -1682,7 +1789,11 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
     }
     }   // layers of the run
     if (threadIdx.x >= 512) range_report(rmax, range_flag);
+    if constexpr (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W12_WALL(7)
+#undef W12_WALL
 #undef W12_TS
+#undef W12_NDW
 }
 
 // Layers L[0 .. nl) (1 <= nl <= 4, all of one shape) in one launch: layer i reads (i odd ? b : a) and writes the other
@@ -1746,6 +1857,70 @@ void launch_sep_w12(float* a, float* b, const SepLayer* L, int nl, long long M, 
     }
     hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, a, b, ch, nl, M, cin,
                        H, W, nullptr, L[0].range_flag);
+}
+
+// Layer L (stride 1, 512 output channels, whole-window tiles) on the 12-wave kernel followed by the stride-2 depthwise of
+// `next` in its epilogue: out = [windows][H/2][W/2][512].
+template <int KT, bool PLAIN = false>
+void launch_sep_w12_ndw(const float* in, float* out, const SepLayer& L, const SepLayer& next, long long M, hipStream_t stream) {
+    if constexpr (!PLAIN) {
+        if (L.pw_mode == 2) return launch_sep_w12_ndw<KT, true>(in, out, L, next, M, stream);
+    }
+    W12Chain ch{};
+    ch.dw_w[0] = dw_w_of(L);
+    ch.dw_b[0] = dw_b_of(L);
+    ch.whi[0] = static_cast<const _Float16*>(L.pw_fhi);
+    ch.wlo[0] = static_cast<const _Float16*>(L.pw_flo);
+    ch.pw_u[0] = L.pw_u;
+    ch.pw_b[0] = L.pw_b;
+    constexpr size_t lds = 96u * (256 + 4) * 4 + 40u * 512;     // f32 tile (it overlays the stage buffers) + the next layer's taps
+    static_assert(3u * (96 + 1) * 128 + 4u * 96 * 64 + 40u * KT <= 96u * (256 + 4) * 4, "stage buffers under the tile");
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&sep_w12_kernel<96, false, PLAIN, KT, 1>, (int)lds, lds_once);
+    const long long tiles = (M + 95) / 96;
+#ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=5: wall clock (10 ns ticks) of the phases of every workgroup
+    const char* tr = getenv("BD_WS_TRACE");
+    if (tr && tr[0] == '5') {
+        constexpr size_t kDbgBytes = 512 + 1024 * 8 * 4;
+        static unsigned* dbg = nullptr;
+        static int shots = 0;
+        if (!dbg) {
+            (void)hipMalloc(&dbg, kDbgBytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<96, true, PLAIN, KT, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        (void)hipMemsetAsync(dbg, 0, kDbgBytes, stream);
+        hipLaunchKernelGGL((sep_w12_kernel<96, true, PLAIN, KT, 1>), dim3((unsigned)tiles), dim3(768), lds, stream,
+                           const_cast<float*>(in), out, ch, 1, M, L.cin, L.h_out, L.w_out, dbg, L.range_flag, dw_w_of(next),
+                           dw_b_of(next));
+        (void)hipStreamSynchronize(stream);
+        static unsigned h[kDbgBytes / 4];
+        (void)hipMemcpy(h, dbg, kDbgBytes, hipMemcpyDeviceToHost);
+        if (++shots == 6) {
+            const int nb = tiles < 1024 ? (int)tiles : 1024;
+            unsigned t0 = ~0u;
+            for (int bl = 0; bl < nb; ++bl) t0 = h[128 + bl * 8] < t0 ? h[128 + bl * 8] : t0;
+            static const char* names[8] = {"start", "stage loop done", "half 0 parked", "barrier", "depthwise 0 done", "half 1 parked + barrier",
+                                           "depthwise 1 done", "stores complete"};
+            fprintf(stderr, "[trace] 12-wave kernel with next-layer depthwise, K = %d, %d workgroups; x 10 ns since the first start (min / avg / max):\n", KT, nb);
+            for (int i = 0; i < 8; ++i) {
+                unsigned lo = ~0u, hi = 0;
+                double sum = 0;
+                for (int bl = 0; bl < nb; ++bl) {
+                    const unsigned t = h[128 + bl * 8 + i] - t0;
+                    lo = t < lo ? t : lo;
+                    hi = t > hi ? t : hi;
+                    sum += t;
+                }
+                fprintf(stderr, "[trace]   %-26s %6u %8.0f %6u\n", names[i], lo, sum / nb, hi);
+            }
+        }
+        return;
+    }
+#endif
+    hipLaunchKernelGGL((sep_w12_kernel<96, false, PLAIN, KT, 1>), dim3((unsigned)tiles), dim3(768), lds, stream,
+                       const_cast<float*>(in), out, ch, 1, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag, dw_w_of(next),
+                       dw_b_of(next));
 }
 
 // --------------------------------------------------------------------------- pointwise with the weights in registers
@@ -2837,7 +3012,7 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
 // Fused depthwise+pointwise of layer L followed by the stride-2 depthwise of the NEXT layer; `out` receives
 // that depthwise's output [windows][H/2][W/2][L.cout].  Only for whole-window tiles (12x8 and 6x4 maps).
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
-                                    bool band_tiles, hipStream_t stream) {
+                                    bool band_tiles, hipStream_t stream, bool twelve_waves) {
     const int P = L.h_out * L.w_out;
     if (L.stride == 1 && next.stride == 2 && windows > 0 && P == 384 && L.w_out == 16 && L.cin >= 128 && L.cin % 64 == 0 &&
         L.cout == 128 && next.cin == 128) {       // layer 4 + depthwise 5
@@ -2849,6 +3024,17 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
     if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & (L.w_out - 1)) || L.h_out % 3) return false;
     const long long M = (long long)windows * P;
     if (M >= (1LL << 31)) return false;       // the kernel's tile arithmetic is 32-bit
+    // 512 output channels: all of them in one workgroup of the 12-wave kernel (the layer's depthwise runs once per row tile,
+    // not once per 256-column tile); bd_set_fusion separable = 4 keeps the 8-wave kernel (test hook)
+    // (the instantiations carry their map: layer 6 = 12 x 8 with 256 input channels, layer 12 = 6 x 4 with 512)
+    if (twelve_waves && L.cout == 512 && L.cin == 256 && L.h_out == 12 && L.w_out == 8) {
+        launch_sep_w12_ndw<256>(in, out, L, next, M, stream);
+        return true;
+    }
+    if (twelve_waves && L.cout == 512 && L.cin == 512 && L.h_out == 6 && L.w_out == 4) {
+        launch_sep_w12_ndw<512>(in, out, L, next, M, stream);
+        return true;
+    }
     launch_sep_ws<256, 96, 0, 1, 96, 1, 1, 1, 1>(in, L, out, M, stream, &next);
     return true;
 }

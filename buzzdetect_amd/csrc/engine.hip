@@ -59,6 +59,7 @@ struct bd_engine {
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
+    bool ndw_w12 = true;              // layers 6 and 12 (+ the next layer's depthwise) on the 12-wave kernel (separable = 4: 8-wave)
     int sep_variant = 0;
     bool l4_band_tiles = false;       // layer 4 + depthwise 5 as overlapping band tiles of the generic kernel (bd_set_fusion separable = 2)
     float* d_pool = nullptr;          // one allocation for every folded tensor
@@ -862,9 +863,9 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
             if (e->fuse_sep && e->fuse_next_dw && mode != 0 && e->sep_variant <= 1 && l + 1 < 13 &&
                 (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
-                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream)) {
+                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream, e->ndw_w12)) {
                 BD_REPEAT_EXTRA(3 + 2 * l)
-                    (void)bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream);
+                    (void)bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream, e->ndw_w12);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 skip_dw_layer = l + 1;
                 last = buf_b;
@@ -1184,16 +1185,17 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
-    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 9 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 9 or 12");
+    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 9 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 9 or 12");
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_stem4 = stem >= 3;
     h->fuse_sep = separable != 0;
-    h->fuse_next_dw = separable >= 1 && separable <= 3;
-    h->fuse_run = separable == 1 || separable == 2;
+    h->fuse_next_dw = separable >= 1 && separable <= 4;
+    h->fuse_run = separable == 1 || separable == 2 || separable == 4;
+    h->ndw_w12 = separable != 4;
     h->l4_band_tiles = separable == 2;
-    h->sep_variant = separable > 3 ? separable : 0;
+    h->sep_variant = separable > 4 ? separable : 0;
     return BD_OK;
 }
 
