@@ -3,7 +3,7 @@
 //   valu      v_pk_fma_f32 / v_fma_f32 streams
 //   lds       ds_read_b128 streams
 //   l2        every CU streaming the same L2-resident 2 MB
-//   hbm       a float4 copy of 2 x 1 GiB
+//   copy      a float4 copy of 2 x 64 MiB (Infinity-Cache resident) and of 2 x 1 GiB (HBM)
 // each held for a few seconds.  Not part of the product; evidence for DESIGN.md's "power-bound" section.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_power tools/ubench_power.hip -lpthread && tools/ubench_power [seconds]
 #include <hip/hip_runtime.h>
@@ -264,6 +264,17 @@ int main(int argc, char** argv) {
         auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(l2_kernel, dim3(cus), dim3(512), 0, 0, in, sink, n, it_2); });
         report("global_load_dwordx4 of an L2-resident 2 MB", r, (double)cus * n * 16 * it_2, "TB/s", 1e-12);
         CHECK(hipFree(in));
+    }
+    {
+        const size_t n = (size_t)1 << 22;      // float4: 64 MiB each way - beyond the 8 x 4 MB of L2, inside the 256 MB Infinity Cache
+        float4 *in, *out;
+        CHECK(hipMalloc(&in, n * 16));
+        CHECK(hipMalloc(&out, n * 16));
+        CHECK(hipMemset(in, 1, n * 16));
+        auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(copy_kernel, dim3(cus * 16), dim3(256), 0, 0, in, out, n); });
+        report("float4 copy, 64 MiB read + 64 MiB written", r, 2.0 * n * 16, "TB/s", 1e-12);
+        CHECK(hipFree(in));
+        CHECK(hipFree(out));
     }
     {
         const size_t n = (size_t)1 << 26;      // float4: 1 GiB each way
