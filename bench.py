@@ -105,9 +105,9 @@ def slot_plan(launches, pool_fused=True):
                     # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own
                     # (epilogue fusion exists only in the 8-wave kernel)
                     # (layer 4 + depthwise 5 have their own kernel: a window per workgroup, no overlapping bands)
-                    # (512 output channels - layers 6 and 12 - run the 12-wave kernel, which then applies this depthwise to
+                    # (512 output channels - layer 12 - run the 12-wave kernel, which then applies this depthwise to
                     #  256 channels at a time: cnn.hip launch_separable_fused_next_dw)
-                    prev_fam = "l4_window_kernel" if layer == 5 else ("sep_w12_kernel" if pool_fused and c == 512 else "sep_ws_kernel")
+                    prev_fam = "l4_window_kernel" if layer == 5 else ("sep_w12_ndw_kernel" if pool_fused and c == 512 else "sep_ws_kernel")
                     plan[pw_slot - 2] = (nm + f"+dw{layer}", prev_fam, nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
                 # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
@@ -202,9 +202,10 @@ class PowerWatch:
                 "frac_of_cap": round(watts / (cap / 1e6), 3) if cap else None,
                 "sclk_MHz_avg": round(sum(s[1] for s in late) / len(late) / 1e6, 1), "sclk_MHz_max": 2400, "samples": len(late),
                 "source": "hwmon power1_input / freq1_input of this GPU, 10 ms polls, second half of the timed region",
-                "what": "the timed region runs at the board's power limit with the shader clock pulled below its 2.4 GHz maximum: "
-                        "the hot path is power-bound (DESIGN.md 7b; per-kernel figures in profiles/r03_power_profile.txt, "
-                        "what the limit leaves of the paper peaks in profiles/r03_ubench_power.txt)"}
+                "what": "the board's power management holds the shader clock below its 2.4 GHz maximum for the whole timed "
+                        "region (at the 1400 W limit on most boxes of the pool, 60-100 W below it on some): the hot path is "
+                        "power-bound (DESIGN.md 7b; per-kernel figures in profiles/r03_power_profile.txt, what the limit "
+                        "leaves of the paper peaks in profiles/r03_ubench_power.txt)"}
 
 
 def visible_gpus():
@@ -640,8 +641,9 @@ def main() -> int:
                 f["flops"] += fl * windows_per_file * ev_steps
                 f["slots"].append(nm)
             total_ms = float(ms.sum())
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "stem3_kernel", "pw_res_kernel",
-                         "l4_window_kernel")
+            # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise in the epilogue, layer 12)
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_w12_ndw_kernel", "stem3_kernel",
+                         "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
             sec = d["ms"] * 1e-3

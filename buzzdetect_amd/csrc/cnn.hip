@@ -1396,7 +1396,7 @@ __device__ __forceinline__ T w12_pick(const T (&a)[4], int i) {
 }
 
 //
-// NDW = 1 (layers 6 and 12, whose successor is a stride-2 layer; single-layer launches only): the tile is not written; the NEXT
+// NDW = 1 (layer 12, whose successor is a stride-2 layer; single-layer launches, 6 x 4 map only): the tile is not written; the NEXT
 // layer's stride-2 depthwise (taps ndw_w, shift ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS - 256 channels
 // at a time, consumer waves 0-3 then 4-7 parking their columns in an f32 tile that overlays the (dead) stage buffers - and
 // only that result goes to B1.  The 8-wave kernel does the same per 256-column tile, i.e. runs the layer's own depthwise twice.
@@ -1437,12 +1437,12 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
     // next layer's stride-2 depthwise on channels 256 HALF .. of the tile parked in Ct (whole windows: every tap is in LDS);
     // the arithmetic of sep_ws_kernel's NDW = 1 epilogue.  A wave's 64 lanes are the 64 channel quads of ONE output position
     // (12 waves x 2 positions = the tile's 24), so position, padding tests and row arithmetic are scalar, and the map's size is
-    // a constant of the instantiation (layer 6: 12 x 8 with K = 256, layer 12: 6 x 4 with K = 512): no division survives.
+    // a constant of the instantiation (layer 12: 6 x 4): no division survives.
 #define W12_NDW(HALF)                                                                                     \
     {                                                                                                     \
         const float* Ct_ = reinterpret_cast<const float*>(smem_raw);                                      \
         constexpr int CTW = 256 + 4;                                                                      \
-        constexpr int HH = KT == 256 ? 12 : 6, WW = KT == 256 ? 8 : 4, PP = HH * WW;                      \
+        constexpr int HH = 6, WW = 4, PP = HH * WW;                                                       \
         constexpr int OW2 = WW / 2, P2 = (HH / 2) * OW2, NPOS = (BM / PP) * P2;                           \
         static_assert(NPOS == 24, "two output positions per wave");                                       \
         int tn_ = tid;                                                                                    \
@@ -3024,13 +3024,9 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
     if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & (L.w_out - 1)) || L.h_out % 3) return false;
     const long long M = (long long)windows * P;
     if (M >= (1LL << 31)) return false;       // the kernel's tile arithmetic is 32-bit
-    // 512 output channels: all of them in one workgroup of the 12-wave kernel (the layer's depthwise runs once per row tile,
-    // not once per 256-column tile); bd_set_fusion separable = 4 keeps the 8-wave kernel (test hook)
-    // (the instantiations carry their map: layer 6 = 12 x 8 with 256 input channels, layer 12 = 6 x 4 with 512)
-    if (twelve_waves && L.cout == 512 && L.cin == 256 && L.h_out == 12 && L.w_out == 8) {
-        launch_sep_w12_ndw<256>(in, out, L, next, M, stream);
-        return true;
-    }
+    // 512 output channels (layer 12): all of them in one workgroup of the 12-wave kernel (the layer's depthwise runs once per
+    // row tile, not once per 256-column tile); bd_set_fusion separable = 4 keeps the 8-wave kernel (test hook)
+    // (layer 12: 512 -> 512 on the 6 x 4 map - the instantiation carries the map.  Layer 6 is 256 -> 256: one column tile.)
     if (twelve_waves && L.cout == 512 && L.cin == 512 && L.h_out == 6 && L.w_out == 4) {
         launch_sep_w12_ndw<512>(in, out, L, next, M, stream);
         return true;

@@ -13,7 +13,14 @@ from collections import defaultdict
 
 def family(name):
     m = re.search(r"\d+([a-z0-9_]+_kernel)", name) if name.startswith("_ZN2bd") else re.search(r"(\w+_kernel)", name)
-    return m.group(1) if m else None
+    if not m:
+        return None
+    fam = m.group(1)
+    if fam == "sep_w12_kernel":      # <XPMAX, TRACE, PLAIN, KT, NDW>: the NDW = 1 instantiations (layers 6, 12) are bench.py's sep_w12_ndw_kernel
+        args = re.findall(r"Li(\d+)E", name) if name.startswith("_ZN2bd") else re.findall(r"(\d+)", name.split("<", 1)[-1])
+        if len(args) >= 3 and args[2] == "1":
+            fam = "sep_w12_ndw_kernel"
+    return fam
 
 
 def collect(d, counter):
