@@ -876,6 +876,21 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             // first the three slab requests, then the taps + shift of all K channels ([10][K] floats, ordinary loads):
             // the compiler drains vmcnt before the first tap is written to LDS, which also covers the slabs - one
             // memory round trip for the whole prologue instead of two
+            if constexpr (NDW == 1) {
+                // the NEXT layer's taps + shift of this tile's BN columns for the epilogue, [10][BN] behind the f32 tile: ten 1 KB
+                // rows by LDS-DMA, issued before the slabs so that the counted waits below cover them
+                static_assert(BN == 256, "one DMA instruction per row of taps");
+                float* const Nw = reinterpret_cast<float*>(smem_raw + (size_t)BM * (BN + 4) * 4);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int t = pw + 4 * c;
+                    if (t < 10) {
+                        const float* src = (t < 9 ? ndw_w + (size_t)t * N : ndw_b) + n0 + 4 * lane;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(Nw + t * BN), 16, 0, 0);
+                    }
+                }
+            }
             BD_X_DMA(0, 0)
             BD_X_DMA(32, 1)
             BD_X_DMA(64, 2)
@@ -1221,43 +1236,54 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             s4.x /= fp; s4.y /= fp; s4.z /= fp; s4.w /= fp;
             *reinterpret_cast<v4f*>(out2 + (size_t)((unsigned)m0 / (unsigned)P + wl) * N + n0 + c4 * 4) = s4;
         }
-    } else if (NDW) {
+    } else if constexpr (NDW == 1) {
         // ---- next layer's depthwise (stride 2) on the tile: windows are whole, so every tap is in LDS ----
+        // A wave's 64 lanes are the 64 channel quads of ONE output position (8 waves x 3 positions = the tile's 24), so the
+        // position, its padding tests and its row arithmetic are scalar; the two maps this runs on (12 x 8: layer 6, 6 x 4:
+        // layer 12 on the test-hook path) are compile-time cases, so no division survives; taps and shift were brought to
+        // LDS by the producers' prologue.  (Round 2's form - a position per thread with run-time divisions and nine divergent
+        // padding branches - was a third of a layer-6 tile's time.)
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
-        constexpr int C4 = BN / 4;
-        const int P = H * W;
-        const int OW2 = W / 2, P2 = (H / 2) * OW2;
-        const int tasks = (BM / P) * P2 * C4;
-        // 512 is a multiple of the C4 channel quads of a row: a thread keeps its quad in all its tasks, so the nine taps and
-        // the shift are read once; the four channels of a tap are two packed FMAs (the same IEEE fmas as four plain ones)
-        static_assert(512 % C4 == 0, "a thread's tasks share their channels");
-        const int c4 = tid % C4;
+        constexpr int C4 = BN / 4, CTW = BN + 4;
+        static_assert(C4 == 64 && XD == 1, "a wave per output position; taps by the DMA prologue");
+        const float* Nw = reinterpret_cast<const float*>(smem_raw + (size_t)BM * (BN + 4) * 4);
+        const int c4 = tid & 63;
+        const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
         v4f wt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ndw_w + (size_t)t * N + n0 + c4 * 4);
-        const v4f shift = *reinterpret_cast<const v4f*>(ndw_b + n0 + c4 * 4);
-        for (int id = tid; id < tasks; id += 512) {
-            const int q = id / C4;
-            const int pos2 = q % P2, wl = q / P2;
-            if (m0 + (long long)wl * P >= M) continue;
-            const int oh = pos2 / OW2, ow = pos2 % OW2;
-            v4f acc = shift;
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(Nw + t * BN + c4 * 4);
+        const v4f shift = *reinterpret_cast<const v4f*>(Nw + 9 * BN + c4 * 4);
+        const unsigned m0u = (unsigned)m0;
+        auto positions = [&](auto hh_, auto ww_) {
+            constexpr int HH = decltype(hh_)::value, WW = decltype(ww_)::value, PP = HH * WW;
+            constexpr int OW2 = WW / 2, P2 = (HH / 2) * OW2, NPOS = (BM / PP) * P2;
+            static_assert(NPOS == 24, "three output positions per wave");
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+            for (int pp = 0; pp < NPOS; pp += 8) {
+                const int ps = pp + slot;
+                const int wl = ps / P2, pos2 = ps % P2;
+                if (m0 + (long long)wl * PP >= M) continue;
+                const int oh = pos2 / OW2, ow = pos2 % OW2;
+                const float* base = Ct + (wl * PP + 2 * oh * WW + 2 * ow) * CTW + c4 * 4;
+                v4f acc = shift;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ih = 2 * oh + kh, iw = 2 * ow + kw;
-                    v4f v = {0.f, 0.f, 0.f, 0.f};
-                    if (ih < H && iw < W) v = *reinterpret_cast<const v4f*>(Ct + (wl * P + ih * W + iw) * (BN + 4) + c4 * 4);
-                    acc = __builtin_elementwise_fma(v, wt[kh * 3 + kw], acc);
-                }
-            acc.x = fmaxf(acc.x, 0.0f);
-            acc.y = fmaxf(acc.y, 0.0f);
-            acc.z = fmaxf(acc.z, 0.0f);
-            acc.w = fmaxf(acc.w, 0.0f);
-            const long long row2 = (long long)((unsigned)m0 / (unsigned)P + wl) * P2 + pos2;
-            *reinterpret_cast<v4f*>(out2 + (size_t)row2 * N + n0 + c4 * 4) = acc;
-        }
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        v4f v = {0.f, 0.f, 0.f, 0.f};        // SAME padding: 0 before, 1 after - a wave-uniform test
+                        if (2 * oh + kh < HH && 2 * ow + kw < WW) v = *reinterpret_cast<const v4f*>(base + (kh * WW + kw) * CTW);
+                        acc = __builtin_elementwise_fma(v, wt[kh * 3 + kw], acc);
+                    }
+                acc.x = fmaxf(acc.x, 0.0f);
+                acc.y = fmaxf(acc.y, 0.0f);
+                acc.z = fmaxf(acc.z, 0.0f);
+                acc.w = fmaxf(acc.w, 0.0f);
+                const long long row2 = (long long)(m0u / (unsigned)PP + wl) * P2 + pos2;
+                *reinterpret_cast<v4f*>(out2 + (size_t)row2 * N + n0 + c4 * 4) = acc;
+            }
+        };
+        if (H == 12) positions(std::integral_constant<int, 12>{}, std::integral_constant<int, 8>{});
+        else positions(std::integral_constant<int, 6>{}, std::integral_constant<int, 4>{});
     } else {
         // ---- all 8 waves: tile -> HBM as whole rows, 16 bytes per lane ----
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
@@ -1294,7 +1320,7 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
     }
     constexpr size_t lds_pipe0 = (XD ? 3u : 2u * KS) * (XPMAX + 1) * 128 + (XD ? 0u : 2u * KS * 1280) + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
     const size_t lds_pipe = lds_pipe0 + (XD && !PWO ? (size_t)40 * L.cin : 0);   // XD: + taps and shift of all input channels
-    constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4;
+    constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4 + (NDW == 1 ? 40u * BN : 0u);   // NDW = 1: + the next layer's taps and shift
     const size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
     constexpr size_t lds_pipe_max = lds_pipe0 + (XD && !PWO ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
     constexpr size_t lds_max = lds_pipe_max > lds_tile ? lds_pipe_max : lds_tile;
@@ -3021,7 +3047,8 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
         return true;
     }
     if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;
-    if (!(P == 96 || P == 24) || next.cin != L.cout || (L.h_out & 1) || (L.w_out & (L.w_out - 1)) || L.h_out % 3) return false;
+    // (the epilogue's position arithmetic is compiled for these two maps)
+    if (!((L.h_out == 12 && L.w_out == 8) || (L.h_out == 6 && L.w_out == 4)) || next.cin != L.cout) return false;
     const long long M = (long long)windows * P;
     if (M >= (1LL << 31)) return false;       // the kernel's tile arithmetic is 32-bit
     // 512 output channels (layer 12): all of them in one workgroup of the 12-wave kernel (the layer's depthwise runs once per
