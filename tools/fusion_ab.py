@@ -35,8 +35,8 @@ def recordings(n):
     for r in range(n):
         at = 0
         for b, (a, e) in enumerate(edges):
-            j = k % n_streams
-            k += 1
+            j = (k + (r if os.environ.get("BD_AB_ROTATE") else 0)) % n_streams     # BD_AB_ROTATE=1: the short last batch of a
+            k += 1                                                                   # recording moves from stream to stream
             w = 1024 if b < 3 else 678
             with torch.cuda.stream(streams[j]):
                 engs[j].launch([files[r % 3][a:e]], hop, step, False, True, out=out[r % 2][at:at + w])
