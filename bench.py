@@ -423,9 +423,11 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the host-resident (H2D-inclusive), analyze() and arithmetic-mode legs")
     ap.add_argument("--per-slot", action="store_true", help="print per-kernel times to stderr")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="analyzer streams per GPU: batches are dealt round-robin to this many engines, each on "
-                         "its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="analyzer streams per GPU: batches are dealt round-robin, in issue order, to this many engines, each "
+                         "on its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253).  Three, not four: "
+                         "with four streams and four batches per recording every stream sees the same batch of every recording "
+                         "and the streams run in lock-step (1.63 vs 1.66 M windows/s, DESIGN.md 7)")
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable layers: 9 = 8-wave kernel only, 12 = with the 12-wave kernel (no epilogue fusion; tuning)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
@@ -505,6 +507,7 @@ def main() -> int:
         return blocks[rows]
 
     issued = [0]
+    dealt = [0]
 
     def run_files(n_steps: int, use_streams: bool = True):
         """n_steps x 50 recordings through this rank's share of the rounds (see the module docstring)."""
@@ -515,7 +518,8 @@ def main() -> int:
             mine = rnd.units[rank]
             used = set()
             for u, at in zip(mine, sharding.unit_offsets(mine)):
-                j = (u.batch % len(engines)) if use_streams else 0
+                j = (dealt[0] % len(engines)) if use_streams else 0       # batches dealt round-robin in issue order
+                dealt[0] += 1
                 s = streams[j]
                 if j not in used and reusable[slot] is not None:
                     s.wait_event(reusable[slot])           # the gather that last read this block is done
