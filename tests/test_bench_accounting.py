@@ -1,0 +1,49 @@
+"""bench.py's bookkeeping (no GPU): the per-slot FLOP / byte plan must add up to the network whatever the fusion layout, so that
+`roofline.achieved` is priced on the algorithm and not on how many launches it was cut into."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+from oracle import yamnet_oracle as O
+
+# profile slots that see a launch per batch (engine.hip run_chunks): slot 2 l + 1 is layer l + 2's pointwise / fused kernel
+DEFAULT = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                    # layers 8-11 as one launch, timed in layer 11's slot
+PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # bd_set_fusion separable = 3
+
+
+def _plan(slots):
+    launches = np.zeros(29, dtype=np.int64)
+    launches[slots] = 40
+    return bench.slot_plan(launches)
+
+
+def _network_flops():
+    """2 x MACs of conv1, every depthwise and every pointwise of a 96 x 64 patch (yamnet.py:26-106) + pool + head."""
+    h, w, c = 48, 32, 32
+    total = 2 * 9 * h * w * c
+    for stride, cout in O.LAYER_DEFS[1:]:
+        h, w = h // stride, w // stride
+        total += 2 * 9 * h * w * c + 2 * h * w * c * cout
+        c = cout
+    return total + h * w * c + 2 * 1024 * 13
+
+
+def test_slot_plan_adds_up_to_the_network_in_both_layouts():
+    for slots in (DEFAULT, PER_LAYER):
+        plan = _plan(slots)
+        assert sorted(plan) == sorted(slots)
+        assert sum(v[3] for v in plan.values()) == _network_flops()
+    a, b = _plan(DEFAULT), _plan(PER_LAYER)
+    assert sum(v[2] for v in a.values()) == sum(v[2] for v in b.values())       # same bytes: the run still stores every layer
+
+
+def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():
+    plan = _plan(DEFAULT)
+    assert plan[21][:2] == ("sep8-11", "sep_w12_kernel")
+    assert plan[21][3] == 4 * _plan(PER_LAYER)[15][3]
+    assert plan[23][:2] == ("sep12+dw13", "sep_w12_ndw_kernel")                 # 512 -> 512 with layer 13's depthwise: 12-wave kernel
+    assert plan[11][:2] == ("sep6+dw7", "sep_ws_kernel")                        # 256 -> 256: one column tile, 8-wave kernel
+    assert plan[27][:2] == ("sep14+pool", "sep_ws_kernel") and plan[28][0] == "head"
