@@ -113,7 +113,8 @@ def slot_plan(launches, pool_fused=True):
                 # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
                 fam = "sep_w12_kernel" if (pool_fused and c == 512 and cout == 512) else "sep_ws_kernel"
                 if layer == 14 and pool_fused:    # the average pool rides in the epilogue: [1024] out per window
-                    plan[pw_slot] = ("sep14+pool", fam, (h * w * c + cout) * 4, dw[1] + pw[1] + ho * wo * cout)
+                    # (12-wave kernel, two 512-column halves per row tile: cnn.hip launch_separable_fused_pool)
+                    plan[pw_slot] = ("sep14+pool", "sep_w12_ndw_kernel", (h * w * c + cout) * 4, dw[1] + pw[1] + ho * wo * cout)
                 elif run and fam == "sep_w12_kernel":
                     plan[pw_slot] = (f"sep{run[0]}-{layer}", fam, run[1] + (h * w * c + ho * wo * cout) * 4, run[2] + dw[1] + pw[1])
                     run = None
@@ -645,7 +646,8 @@ def main() -> int:
                 f["flops"] += fl * windows_per_file * ev_steps
                 f["slots"].append(nm)
             total_ms = float(ms.sum())
-            # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise in the epilogue, layer 12)
+            # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise (layer 12) or the
+            #  average pool (layer 14) in the epilogue)
             mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_w12_ndw_kernel", "stem3_kernel",
                          "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])

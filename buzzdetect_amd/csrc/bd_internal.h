@@ -120,6 +120,7 @@ void launch_pool_head(const float* act, int windows, const float* head_wt, const
                       int n_classes, float* emb, float* logits, hipStream_t stream);
 void launch_head(const float* pooled, int windows, const float* head_wt, const float* head_b, int n_classes,
                  float* logits, hipStream_t stream);
-bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
+bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream,
+                                 bool twelve_waves = false);
 
 }  // namespace bd

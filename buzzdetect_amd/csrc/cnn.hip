@@ -1426,6 +1426,9 @@ __device__ __forceinline__ T w12_pick(const T (&a)[4], int i) {
 // layer's stride-2 depthwise (taps ndw_w, shift ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS - 256 channels
 // at a time, consumer waves 0-3 then 4-7 parking their columns in an f32 tile that overlays the (dead) stage buffers - and
 // only that result goes to B1.  The 8-wave kernel does the same per 256-column tile, i.e. runs the layer's own depthwise twice.
+// NDW = 2 (layer 14: 1024 -> 1024 on the 3 x 2 map, 16 windows per tile): blockIdx.y picks one of the layer's 512-column halves
+// (the depthwise runs twice per row tile where the 8-wave kernel's four 256-column tiles run it four times); the tile is not
+// written: its windows are average-pooled, 256 channels at a time, and only [windows][1024] goes to B1.
 template <int XPMAX, bool TRACE, bool PLAIN, int KT = 0, int NDW = 0>   // KT: the number of input channels when known at compile time
 __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8-11: tap and slab strides become immediates)
     float* B0, float* B1, const W12Chain ch, int nl,        // layer i reads B[i & 1] and writes B[(i & 1) ^ 1]
@@ -1445,6 +1448,8 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
     float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K]
     float* const Cc = Wall + 10 * K;                                   // [32][BN + 4]
     constexpr int NDW_TAPS_AT = BM * (256 + 4) * 4;                    // NDW = 1: the next layer's taps + shift [10][N], behind the f32 tile
+    const int n0 = NDW == 2 ? (int)blockIdx.y * BN : 0;                // NDW = 2: this workgroup's half of the layer's 1024 columns
+    constexpr int NT = NDW == 2 ? 2 * BN : BN;                         // columns of the layer (row length of its output)
 
     const int nk = K / 32;                    // even, >= 4
     const int P = H * W;                      // whole windows: P divides BM
@@ -1501,6 +1506,27 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
             *reinterpret_cast<v4f*>(B1 + (size_t)row2 * N + nc) = acc2;                                   \
         }                                                                                                 \
     }
+    // NDW = 2: average pool (yamnet.py:104) of the 16 windows parked in Ct, channels n0 + 256 HALF ..: a wave takes windows
+    // slot and slot + 12, its lanes the 64 channel quads; summed in position order and divided by P exactly as
+    // pool_head_kernel and the 8-wave kernel do
+#define W12_POOL(HALF)                                                                                    \
+    {                                                                                                     \
+        const float* Ct_ = reinterpret_cast<const float*>(smem_raw);                                      \
+        constexpr int CTW = 256 + 4, PP = 6;                                                              \
+        int tn_ = tid;                                                                                    \
+        asm volatile("" : "+v"(tn_));                                                                     \
+        const int c4 = tn_ & 63;                                                                          \
+        const int slot = __builtin_amdgcn_readfirstlane(tn_ >> 6);                                        \
+        for (int wl = slot; wl < BM / PP; wl += 12) {                                                     \
+            if (m0 + (long long)wl * PP >= M) continue;                                                   \
+            v4f s4 = *reinterpret_cast<const v4f*>(Ct_ + (wl * PP) * CTW + c4 * 4);                       \
+            _Pragma("unroll") for (int q = 1; q < PP; ++q) s4 += *reinterpret_cast<const v4f*>(Ct_ + (wl * PP + q) * CTW + c4 * 4); \
+            const float fp = (float)PP;                                                                   \
+            s4.x /= fp; s4.y /= fp; s4.z /= fp; s4.w /= fp;                                               \
+            *reinterpret_cast<v4f*>(B1 + (size_t)(m0u / (unsigned)PP + wl) * NT + n0 + 256 * (HALF) + c4 * 4) = s4; \
+        }                                                                                                 \
+    }
+#define W12_EPI(HALF) { if constexpr (NDW == 1) W12_NDW(HALF) else W12_POOL(HALF) }
 #define W12_WALL(I)                                                                                       \
     if constexpr (TRACE) {                                                                                \
         if (threadIdx.x == 0 && blockIdx.x < 1024) dbg[128 + blockIdx.x * 8 + (I)] = (unsigned)wall_clock64(); \
@@ -1663,8 +1689,8 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
         // fragment base: column tile 2 wc + j, k16 step q -> + (j * (K/16) + q) * 512 halves
-        const _Float16* const wbh = Wfhi + ((size_t)(2 * wc) * (K / 16) * 64 + lane) * 8;
-        const _Float16* const wbl = Wflo + ((size_t)(2 * wc) * (K / 16) * 64 + lane) * 8;
+        const _Float16* const wbh = Wfhi + ((size_t)(n0 / 32 + 2 * wc) * (K / 16) * 64 + lane) * 8;
+        const _Float16* const wbl = Wflo + ((size_t)(n0 / 32 + 2 * wc) * (K / 16) * 64 + lane) * 8;
         const int jstep = (K / 16) * 512;     // halves between the two column tiles
         f16x8 bh0[TN], bl0[TN], bh1[TN], bl1[TN];     // fragments of an even / an odd k16 step
 #define W12_BLOAD(BH, BL, Q)                                                                              \
@@ -1727,7 +1753,7 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
                 unsc_[j] = pw_u[64 * wc + j * 32 + frow];
             }
         }
-        if constexpr (NDW == 1) {
+        if constexpr (NDW != 0) {
             float* const Ct = reinterpret_cast<float*>(smem_raw);      // [BM][256 + 4]: every stage buffer is dead by now
             // (written out per half: in a loop over the halves the compiler computes all 96 outputs ahead of it and spills them)
 #define W12_PARK()                                                                                        \
@@ -1736,8 +1762,8 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
         float us_[TN], bs_[TN];             /* both during the last stage's MFMAs and spills them */      \
         asm volatile("" : "+v"(fr_));                                                                     \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                  \
-            us_[j] = pw_u[64 * wc + j * 32 + fr_];                                                        \
-            bs_[j] = pw_b[64 * wc + j * 32 + fr_];                                                        \
+            us_[j] = pw_u[n0 + 64 * wc + j * 32 + fr_];                                                   \
+            bs_[j] = pw_b[n0 + 64 * wc + j * 32 + fr_];                                                   \
         }                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
             float* const cb_ = Ct + (32 * i + 4 * fh) * (256 + 4) + 64 * (wc & 3) + fr_;                  \
@@ -1751,13 +1777,13 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
             W12_WALL(2)
             __syncthreads();
             W12_WALL(3)
-            W12_NDW(0)
+            W12_EPI(0)
             W12_WALL(4)
             __syncthreads();
             if (wc >= 4) { W12_PARK() }
             __syncthreads();
             W12_WALL(5)
-            W12_NDW(1)
+            W12_EPI(1)
             __syncthreads();
             W12_WALL(6)
 #undef W12_PARK
@@ -1786,12 +1812,12 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
         // ---- epilogue, producer part: help store the three chunks ----
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));       // addresses computed here, not ahead of the stage loop
-        if constexpr (NDW == 1) {
+        if constexpr (NDW != 0) {
             __syncthreads();
-            W12_NDW(0)
+            W12_EPI(0)
             __syncthreads();
             __syncthreads();
-            W12_NDW(1)
+            W12_EPI(1)
             __syncthreads();
         } else
 #pragma unroll
@@ -1820,6 +1846,8 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
 #undef W12_WALL
 #undef W12_TS
 #undef W12_NDW
+#undef W12_POOL
+#undef W12_EPI
 }
 
 // Layers L[0 .. nl) (1 <= nl <= 4, all of one shape) in one launch: layer i reads (i odd ? b : a) and writes the other
@@ -1947,6 +1975,30 @@ void launch_sep_w12_ndw(const float* in, float* out, const SepLayer& L, const Se
     hipLaunchKernelGGL((sep_w12_kernel<96, false, PLAIN, KT, 1>), dim3((unsigned)tiles), dim3(768), lds, stream,
                        const_cast<float*>(in), out, ch, 1, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag, dw_w_of(next),
                        dw_b_of(next));
+}
+
+// Layer 14 (1024 -> 1024 on the 3 x 2 map) on the 12-wave kernel, two 512-column halves per row tile, average pool in the
+// epilogue: pooled = [windows][1024].
+template <bool PLAIN = false>
+void launch_sep_w12_pool(const float* in, float* pooled, const SepLayer& L, long long M, hipStream_t stream) {
+    if constexpr (!PLAIN) {
+        if (L.pw_mode == 2) return launch_sep_w12_pool<true>(in, pooled, L, M, stream);
+    }
+    W12Chain ch{};
+    ch.dw_w[0] = dw_w_of(L);
+    ch.dw_b[0] = dw_b_of(L);
+    ch.whi[0] = static_cast<const _Float16*>(L.pw_fhi);
+    ch.wlo[0] = static_cast<const _Float16*>(L.pw_flo);
+    ch.pw_u[0] = L.pw_u;
+    ch.pw_b[0] = L.pw_b;
+    constexpr size_t lds_pipe = 3u * (96 + 1) * 128 + 4u * 96 * 64 + 40u * 1024;
+    constexpr size_t lds_tile = 96u * (256 + 4) * 4;
+    constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
+    static std::once_flag lds_once[kMaxDevices];
+    allow_dynamic_lds(&sep_w12_kernel<96, false, PLAIN, 1024, 2>, (int)lds, lds_once);
+    const long long tiles = (M + 95) / 96;
+    hipLaunchKernelGGL((sep_w12_kernel<96, false, PLAIN, 1024, 2>), dim3((unsigned)tiles, 2), dim3(768), lds, stream,
+                       const_cast<float*>(in), pooled, ch, 1, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag, nullptr, nullptr);
 }
 
 // --------------------------------------------------------------------------- pointwise with the weights in registers
@@ -3168,13 +3220,15 @@ void launch_head(const float* pooled, int windows, const float* head_wt, const f
 
 // Last layer (3x2 map): fused depthwise+pointwise with the global average pool in the epilogue;
 // pooled = [windows][L.cout].
-bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream) {
+bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream,
+                                 bool twelve_waves) {
     const int P = L.h_out * L.w_out;
     if (L.stride != 1 || windows <= 0 || P != 6 || L.w_out != 2 || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0)
         return false;
     const long long M = (long long)windows * P;
     if (M >= (1LL << 31)) return false;
-    launch_sep_ws<256, 96, 0, 2, 96, 1, 1, 1, 1>(in, L, pooled, M, stream);
+    if (twelve_waves && L.cin == 1024 && L.cout == 1024) launch_sep_w12_pool(in, pooled, L, M, stream);
+    else launch_sep_ws<256, 96, 0, 2, 96, 1, 1, 1, 1>(in, L, pooled, M, stream);
     return true;
 }
 

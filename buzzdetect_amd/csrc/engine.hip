@@ -60,6 +60,7 @@ struct bd_engine {
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
     bool ndw_w12 = true;              // layer 12 (+ the next layer's depthwise) on the 12-wave kernel (separable = 4: 8-wave)
+    bool pool_w12 = true;             // layer 14 + pool on the 12-wave kernel, two 512-column halves (separable = 5: 8-wave, four quarters)
     int sep_variant = 0;
     bool l4_band_tiles = false;       // layer 4 + depthwise 5 as overlapping band tiles of the generic kernel (bd_set_fusion separable = 2)
     float* d_pool = nullptr;          // one allocation for every folded tensor
@@ -845,8 +846,8 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             if (l == 12 && e->fuse_sep && e->fuse_next_dw && mode != 0 && e->sep_variant <= 1 &&
                 stop_stage < 0 && skip_dw_layer != l) {
                 float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
-                if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream)) {
-                    BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream);
+                if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream, e->pool_w12)) {
+                    BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream, e->pool_w12);
                     if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                     if (logits) {
                         Scope sc(e, stream, 28);
@@ -1185,17 +1186,19 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
-    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 9 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 9 or 12");
+    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 9 &&
+        separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 9 or 12");
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_stem4 = stem >= 3;
     h->fuse_sep = separable != 0;
-    h->fuse_next_dw = separable >= 1 && separable <= 4;
-    h->fuse_run = separable == 1 || separable == 2 || separable == 4;
+    h->fuse_next_dw = separable >= 1 && separable <= 5;
+    h->fuse_run = separable == 1 || separable == 2 || separable == 4 || separable == 5;
     h->ndw_w12 = separable != 4;
+    h->pool_w12 = separable != 5;
     h->l4_band_tiles = separable == 2;
-    h->sep_variant = separable > 4 ? separable : 0;
+    h->sep_variant = separable > 5 ? separable : 0;
     return BD_OK;
 }
 

@@ -239,7 +239,9 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    in which every workgroup takes its four windows through the four layers (timed in layer 11's
                    pointwise slot).  2: the same with layer 4 as overlapping band tiles of the generic kernel (test
                    hook).  3: as 1 with one launch per layer for layers 8-11 (test hook).  4: as 1 with layer 12 on the
-                   8-wave kernel (256-column tiles) instead of the 12-wave one (test hook).  9 / 12: plain fused layers
+                   8-wave kernel (256-column tiles) instead of the 12-wave one (test hook).  5: as 1 with layer 14 + pool on the
+                   8-wave kernel (four 256-column tiles on all CUs: faster alone, slower in a full pipeline) instead of the
+                   12-wave one (two 512-column halves; test hook).  9 / 12: plain fused layers
                    on the 8-wave kernel only / with the 12-wave kernel for 512 -> 512 channels (test hook).
    Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);

@@ -46,4 +46,5 @@ def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():
     assert plan[21][3] == 4 * _plan(PER_LAYER)[15][3]
     assert plan[23][:2] == ("sep12+dw13", "sep_w12_ndw_kernel")                 # 512 -> 512 with layer 13's depthwise: 12-wave kernel
     assert plan[11][:2] == ("sep6+dw7", "sep_ws_kernel")                        # 256 -> 256: one column tile, 8-wave kernel
-    assert plan[27][:2] == ("sep14+pool", "sep_ws_kernel") and plan[28][0] == "head"
+    assert plan[27][:2] == ("sep14+pool", "sep_w12_ndw_kernel") and plan[28][0] == "head"     # two 512-column halves + pool
+    assert plan[25][:2] == ("pw13", "sep_ws_kernel")

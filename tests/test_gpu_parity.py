@@ -354,8 +354,8 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 2, 3, 4, 9, 12):      # 2: layer 4 as band tiles instead of a window per workgroup; 3: layers 8-11 one launch each;
-                                                 # 4: layer 12 (+ the next depthwise) on the 8-wave kernel instead of the 12-wave one
+        for variant in (1, 2, 3, 4, 5, 9, 12):   # 2: layer 4 as band tiles instead of a window per workgroup; 3: layers 8-11 one launch each;
+                                                 # 4 / 5: layer 12 (+ the next depthwise) / layer 14 (+ pool) on the 8-wave kernel instead of the 12-wave one
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
@@ -380,8 +380,10 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
             engine.set_fusion(True, 3)
             ref_logits = engine.predict(x, 0.96).numpy()
             ref_emb = engine.embed(x, 0.96).numpy()
-            engine.set_fusion(True, 4)           # ... and layer 12 with the next layer's depthwise: 8-wave vs 12-wave kernel
-            assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), mode
+            for hook in (4, 5):                  # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel
+                engine.set_fusion(True, hook)
+                assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), (mode, hook)
+                assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), (mode, hook)
             engine.set_fusion(True, True)
             for _ in range(2):                   # twice: the second pass reads buffers the first one left behind
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), mode
