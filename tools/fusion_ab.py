@@ -43,9 +43,15 @@ def recordings(n):
             at += w
 
 
+def setting(e, code):
+    """code < 100: bd_set_fusion separable code; 100 + v: default fusion with bd_set_pointwise_variant(13, v) (10 = 8-wave tile kernel)"""
+    e.set_fusion(True, code if code < 100 else 1)
+    e.set_pointwise_variant(13, code - 100 if code >= 100 else 0)
+
+
 def rate(code, n=100):
     for e in engs:
-        e.set_fusion(True, code)
+        setting(e, code)
     recordings(6)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -55,7 +61,7 @@ def rate(code, n=100):
 
 
 def digest(code):
-    engs[0].set_fusion(True, code)
+    setting(engs[0], code)
     with torch.cuda.stream(streams[0]):
         engs[0].launch([files[0][:edges[0][1]]], hop, step, False, True, out=out[0][:1024])
     torch.cuda.synchronize()
