@@ -781,3 +781,35 @@ def test_persistent_kernels_at_grid_boundaries(engine, windows):
         assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb)
     finally:
         engine.set_fusion(True, True)
+
+
+def test_three_streams_under_load_give_the_idle_gpu_bits(engine):
+    """The fused kernels hand data from layer to layer through global memory inside one launch (layers 8-11) and overlay
+    LDS tiles: an ordering mistake there would only show under load.  240 batches on three analyzer streams (an engine each, as
+    bench.py and the pipeline run them), every batch compared on the device with the logits it gave on an idle GPU.
+    (tools/stress_identity.py is the long form: 69 480 batches, no difference.)"""
+    import torch
+    from buzzdetect_amd.engine import HipEngine
+    dev = torch.device("cuda", 0)
+    engs = [engine, HipEngine(embeddername="yamnet_k2", modelname="model_general_v3"),
+            HipEngine(embeddername="yamnet_k2", modelname="model_general_v3")]
+    streams = [torch.cuda.Stream(dev) for _ in engs]
+    sizes = [1024, 1024, 1024, 678]
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    parts = [(torch.randn(HOP * (n - 1) + 15600, generator=gen) * 0.1).to(dev) for n in sizes]
+    ref = []
+    for x, n in zip(parts, sizes):
+        out = torch.empty((n, 13), device=dev)
+        engine.launch([x], HOP, STEP, False, True, out=out)
+        torch.cuda.synchronize()
+        ref.append(out)
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    ring = [[torch.empty((1024, 13), device=dev) for _ in range(4)] for _ in engs]
+    for k in range(240):
+        j, b = k % 3, k % 4
+        out = ring[j][(k // 3) % 4][:sizes[b]]
+        with torch.cuda.stream(streams[j]):
+            engs[j].launch([parts[b]], HOP, STEP, False, True, out=out)
+            bad += (out != ref[b]).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
