@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 EMBEDDER_BLOB_FLOATS = 3_217_344
 EMBEDDING_SIZE = 1024
 MEL_BANDS = 64
@@ -50,8 +50,10 @@ PROTOTYPES = {
     "bd_num_windows": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "bd_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
     "bd_resample_length": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
-    "bd_resample_taps": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32),
+    "bd_resample_taps": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "bd_set_resample_quality": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bd_debug_fir_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "bd_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                               C.c_void_p]),
     "bd_resample_s16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

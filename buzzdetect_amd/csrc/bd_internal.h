@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/buzzdetect_hip.h"
 
 namespace bd {
@@ -87,6 +89,29 @@ struct SepLayer {
 // taps / shift of the depthwise that feeds L's pointwise convolution, for the arithmetic mode L runs in
 inline const float* dw_w_of(const SepLayer& L) { return L.pw_mode != 0 ? L.dw_w16 : L.dw_w; }
 inline const float* dw_b_of(const SepLayer& L) { return L.pw_mode != 0 ? L.dw_b16 : L.dw_b; }
+
+// The soxr_hq-class resampler as a matrix-core product (resample.hip): geometry of one rate ratio.  P = 32 NB outputs and D
+// input samples make one period (P down = D up, D a multiple of 8); output (m, b, n) = sum_e x[m D + boff[b] + e] G_b[e][n].
+struct FirPlan {
+    int up, down, P, D, NB;
+    int kq, mt;                // k-steps of 16 per wave (four waves split K), 32-row tiles per workgroup
+    int contiguous;            // one phase block: the rows overlap and the span is staged once
+    int RS;                    // LDS row stride of the Toeplitz view in 16-byte chunks (odd)
+    unsigned skew_magic;       // contiguous staging skips one chunk every D / 8: floor(q / (D / 8)) = umulhi(q, skew_magic); 0 = none
+    int a_bytes, lds_bytes;    // one f16 half of the staged signal / the workgroup's dynamic LDS
+    float unscale[2];          // 2^-(filter scale + input scale) for 16-bit / float PCM
+    const void* gfrag;         // device [NB][4 kq][hi, lo][64 lanes][8] f16: B fragments of v_mfma_f32_32x32x16_f16
+    const int* koff;           // device [4 kq]: LDS byte offset of a k-step within a row
+    const int* boff;           // device [NB]: first input sample of a phase block relative to its period (multiple of 8)
+};
+struct FirPlanHost {
+    FirPlan plan;
+    std::vector<uint16_t> gfrag;
+    std::vector<int> koff, boff;
+};
+bool fir_plan_build(int up, int down, const double* taps, int half, FirPlanHost* out);
+void launch_fir_mfma(const void* in, bool s16, int64_t n_in, int channels, const FirPlan& plan, float* out, int64_t n_out,
+                     hipStream_t stream);
 
 // ---- launchers (each enqueues exactly one kernel on `stream`) ----
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,

@@ -80,13 +80,17 @@ struct bd_engine {
     // resampler: the filters of every (up, down) pair used so far, kept on the device until bd_destroy (nothing is
     // freed or re-uploaded on a rate change: hipFree would synchronise the device under the caller's streams)
     struct Taps {
-        int up, down, half;
-        float* dev;
+        int up, down, quality, half;
+        float* dev;                   // the taps as float32 (the vector kernels), then, 16-byte aligned, the matrix-core plan's
+                                      // fragment-ordered filter and its two index tables (bd::FirPlan points into this block)
         std::vector<float> host;      // source of the asynchronous upload; must outlive it
+        bool has_plan;                // the ratio fits fir_mfma_kernel (resample.hip)
+        bd::FirPlanHost fir;
         hipStream_t upload_stream;    // a launch on any OTHER stream first waits for `uploaded`
         hipEvent_t uploaded;
     };
     std::vector<Taps> taps;
+    int resample_quality = BD_RESAMPLE_HQ;
     // profiling
     bool profiling = false;
     std::vector<Event2> pending;
@@ -169,11 +173,17 @@ int geometry(int64_t n, int32_t hop, int32_t step, Geometry* g) {
     return BD_OK;
 }
 
-// ---- resampler design: scipy.signal.resample_poly's default filter, restated ----
-//   half = 10 * max(up, down); h = firwin(2 half + 1, 1 / max(up, down), window = ('kaiser', 5.0)) * up
+// ---- resampler design (restated in oracle/resample_oracle.py, tests/test_resample.py holds the two together) ----
+//   quality BD_RESAMPLE_HQ (default): the filter CLASS of libsoxr's HQ recipe, which is what the reference's
+//     librosa.resample(...) runs (src/stream/worker.py:128, res_type soxr_hq): linear phase, pass band to
+//     1 - 0.05 / TO_3dB(rej) = 0.9136 of the lower Nyquist (rej = 20 bits * 6.02 dB), stop band from that Nyquist on,
+//     as one Kaiser-windowed sinc at the up-sampled rate: -6 dB point midway between the band edges, design attenuation
+//     125 dB, beta = 0.1102 (A - 8.7), N = (A - 7.95) / (2.285 dw) + 1 taps (569 for 48 -> 16 kHz);
+//   quality BD_RESAMPLE_SCIPY: rounds 1-3's filter, scipy.signal.resample_poly's default:
+//     half = 10 * max(up, down); h = firwin(2 half + 1, 1 / max(up, down), window = ('kaiser', 5.0)) * up
 double bessel_i0(double x) {
     double sum = 1.0, term = 1.0;
-    for (int k = 1; k < 64; ++k) {
+    for (int k = 1; k < 256; ++k) {
         term *= (x / (2.0 * k)) * (x / (2.0 * k));
         sum += term;
         if (term < 1e-18 * sum) break;
@@ -192,27 +202,45 @@ void rational_ratio(int32_t rate_in, int32_t rate_out, int* up, int* down) {
     *down = rate_in / a;
 }
 
-std::vector<float> design_taps(int up, int down, int* half_out) {
-    const int max_rate = up > down ? up : down;
-    const int half = 10 * max_rate;
+// unity-DC-gain Kaiser-windowed sinc of 2 half + 1 taps, cutoff (-6 dB) as a fraction of Nyquist, times `gain`
+std::vector<double> kaiser_lowpass(int half, double cutoff, double beta, double gain) {
     const int n = 2 * half + 1;
-    const double cutoff = 1.0 / max_rate;          // as a fraction of Nyquist
-    const double beta = 5.0;
     std::vector<double> h(n);
     double sum = 0.0;
+    const double i0b = bessel_i0(beta);
     for (int i = 0; i < n; ++i) {
         const double m = i - half;
         const double x = cutoff * m;
         const double sinc = m == 0 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
-        const double r = 2.0 * i / (n - 1) - 1.0;
-        const double w = bessel_i0(beta * std::sqrt(1.0 - r * r)) / bessel_i0(beta);
+        const double r = half > 0 ? m / half : 0.0;
+        const double w = bessel_i0(beta * std::sqrt(r * r < 1.0 ? 1.0 - r * r : 0.0)) / i0b;
         h[i] = cutoff * sinc * w;
         sum += h[i];
     }
-    std::vector<float> out(n);
-    for (int i = 0; i < n; ++i) out[i] = (float)(h[i] / sum * up);
+    for (int i = 0; i < n; ++i) h[i] = h[i] / sum * gain;
+    return h;
+}
+
+std::vector<double> design_taps(int up, int down, int quality, int* half_out) {
+    const int max_rate = up > down ? up : down;
+    if (quality == BD_RESAMPLE_SCIPY) {
+        const int half = 10 * max_rate;
+        *half_out = half;
+        return kaiser_lowpass(half, 1.0 / max_rate, 5.0, (double)up);
+    }
+    if (max_rate == 1) {                           // equal rates: a copy
+        *half_out = 0;
+        return std::vector<double>(1, 1.0);
+    }
+    const double rej = 20.0 * 20.0 * std::log10(2.0);                       // libsoxr HQ: 20-bit precision
+    const double to_3db = (1.6e-6 * rej - 7.5e-4) * rej + 0.646;
+    const double fp = (1.0 - 0.05 / to_3db) / max_rate, fs = 1.0 / max_rate;   // fractions of the up-sampled Nyquist
+    const double att = 125.0;
+    const double beta = 0.1102 * (att - 8.7);
+    const int n = (int)std::ceil((att - 7.95) / (2.285 * M_PI * (fs - fp))) + 1;
+    const int half = n / 2;
     *half_out = half;
-    return out;
+    return kaiser_lowpass(half, 0.5 * (fp + fs), beta, (double)up);
 }
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
@@ -603,20 +631,54 @@ int64_t bd_resample_length(int64_t n_in, int32_t rate_in, int32_t rate_out) {
     return (n_in * up + down - 1) / down;          // ceil(n_in * up / down), as resample_poly
 }
 
-int bd_resample_taps(int32_t rate_in, int32_t rate_out, float* taps_host, int64_t capacity, int32_t* up, int32_t* down,
-                     int32_t* half) {
+int bd_resample_taps(int32_t rate_in, int32_t rate_out, int32_t quality, float* taps_host, int64_t capacity, int32_t* up,
+                     int32_t* down, int32_t* half) {
     if (rate_in <= 0 || rate_out <= 0 || !up || !down || !half) return fail(BD_EINVAL, "bd_resample_taps: bad argument");
+    if (quality != BD_RESAMPLE_SCIPY && quality != BD_RESAMPLE_HQ) return fail(BD_EINVAL, "bd_resample_taps: unknown quality");
     int u, d, hl;
     rational_ratio(rate_in, rate_out, &u, &d);
-    const std::vector<float> t = design_taps(u, d, &hl);
+    if (u > 4096 || d > 4096) return fail(BD_EINVAL, "bd_resample_taps: rate ratio does not reduce to <= 4096");
+    const std::vector<double> t = design_taps(u, d, quality, &hl);
     *up = u;
     *down = d;
     *half = hl;
     if (taps_host) {
         if (capacity < (int64_t)t.size()) return fail(BD_EINVAL, "bd_resample_taps: buffer too small");
-        std::memcpy(taps_host, t.data(), t.size() * sizeof(float));
+        for (size_t i = 0; i < t.size(); ++i) taps_host[i] = (float)t[i];
     }
     return (int)t.size();
+}
+
+int bd_debug_fir_plan(int32_t rate_in, int32_t rate_out, int32_t* geometry, int32_t* boff, int64_t boff_capacity,
+                      uint16_t* gfrag, int64_t gfrag_capacity) {
+    if (rate_in <= 0 || rate_out <= 0 || !geometry) return fail(BD_EINVAL, "bd_debug_fir_plan: bad argument");
+    int up, down, half;
+    rational_ratio(rate_in, rate_out, &up, &down);
+    if (up > 4096 || down > 4096) return fail(BD_EINVAL, "bd_debug_fir_plan: rate ratio does not reduce to <= 4096");
+    if (up == 1 && down == 1) return 0;
+    const std::vector<double> hd = design_taps(up, down, BD_RESAMPLE_HQ, &half);
+    bd::FirPlanHost f;
+    if (!bd::fir_plan_build(up, down, hd.data(), half, &f)) return 0;
+    const bd::FirPlan& p = f.plan;
+    const int32_t g[12] = {p.up, p.down, p.P, p.D, p.NB, p.kq, p.mt, p.contiguous, p.RS, p.a_bytes, p.lds_bytes, half};
+    std::memcpy(geometry, g, sizeof(g));
+    std::memcpy(geometry + 12, p.unscale, sizeof(p.unscale));
+    if (boff) {
+        if (boff_capacity < (int64_t)f.boff.size()) return fail(BD_EINVAL, "bd_debug_fir_plan: boff buffer too small");
+        std::memcpy(boff, f.boff.data(), f.boff.size() * sizeof(int));
+    }
+    if (gfrag) {
+        if (gfrag_capacity < (int64_t)f.gfrag.size()) return fail(BD_EINVAL, "bd_debug_fir_plan: gfrag buffer too small");
+        std::memcpy(gfrag, f.gfrag.data(), f.gfrag.size() * sizeof(uint16_t));
+    }
+    return 1;
+}
+
+int bd_set_resample_quality(bd_handle h, int32_t quality) {
+    if (!h) return fail(BD_EINVAL, "bd_set_resample_quality: null handle");
+    if (quality != BD_RESAMPLE_SCIPY && quality != BD_RESAMPLE_HQ) return fail(BD_EINVAL, "bd_set_resample_quality: unknown quality");
+    h->resample_quality = quality;
+    return BD_OK;
 }
 
 static int resample_any(bd_handle h, const void* in_dev, bool s16, int64_t n_in, int32_t channels, int32_t rate_in,
@@ -628,21 +690,43 @@ static int resample_any(bd_handle h, const void* in_dev, bool s16, int64_t n_in,
     rational_ratio(rate_in, rate_out, &up, &down);
     if (up > 4096 || down > 4096) return fail(BD_EINVAL, "bd_resample: rate ratio does not reduce to <= 4096");
     BD_HIP(hipSetDevice(h->device));
+    const int quality = h->resample_quality;
     const bd_engine::Taps* filt = nullptr;
     if (up != 1 || down != 1) {                            // (up = down = 1: no filter, the kernel only converts)
         for (const auto& t : h->taps)
-            if (t.up == up && t.down == down) filt = &t;
+            if (t.up == up && t.down == down && t.quality == quality) filt = &t;
         if (!filt) {                                       // first use of this ratio: design, upload in stream order
             if (h->taps.size() >= 64) return fail(BD_EINVAL, "bd_resample: more than 64 distinct rate ratios on one engine");
             if (h->taps.capacity() < 64) h->taps.reserve(64);      // entries never move: uploads read from them
             bd_engine::Taps t;
             t.up = up;
             t.down = down;
-            t.host = design_taps(up, down, &t.half);
+            t.quality = quality;
+            const std::vector<double> hd = design_taps(up, down, quality, &t.half);
+            // rounds 1-3's filter keeps its kernels (decimate_kernel / resample_kernel: bit for bit what it was); the long
+            // filter runs on the matrix cores where the ratio fits
+            t.has_plan = quality == BD_RESAMPLE_HQ && bd::fir_plan_build(up, down, hd.data(), t.half, &t.fir);
+            const size_t n_taps = (hd.size() + 3) / 4 * 4;
+            const size_t n_g = t.has_plan ? t.fir.gfrag.size() / 2 : 0;             // in floats
+            const size_t n_k = t.has_plan ? (t.fir.koff.size() + 3) / 4 * 4 : 0;
+            const size_t n_b = t.has_plan ? (t.fir.boff.size() + 3) / 4 * 4 : 0;
+            t.host.assign(n_taps + n_g + n_k + n_b, 0.0f);
+            for (size_t i = 0; i < hd.size(); ++i) t.host[i] = (float)hd[i];
+            if (t.has_plan) {
+                std::memcpy(t.host.data() + n_taps, t.fir.gfrag.data(), t.fir.gfrag.size() * sizeof(uint16_t));
+                std::memcpy(t.host.data() + n_taps + n_g, t.fir.koff.data(), t.fir.koff.size() * sizeof(int));
+                std::memcpy(t.host.data() + n_taps + n_g + n_k, t.fir.boff.data(), t.fir.boff.size() * sizeof(int));
+                std::vector<uint16_t>().swap(t.fir.gfrag);
+            }
             t.dev = nullptr;
             t.upload_stream = (hipStream_t)stream;
             t.uploaded = nullptr;
             BD_HIP(hipMalloc(&t.dev, t.host.size() * sizeof(float)));
+            if (t.has_plan) {
+                t.fir.plan.gfrag = t.dev + n_taps;
+                t.fir.plan.koff = reinterpret_cast<const int*>(t.dev + n_taps + n_g);
+                t.fir.plan.boff = reinterpret_cast<const int*>(t.dev + n_taps + n_g + n_k);
+            }
             if (hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming) != hipSuccess) {
                 (void)hipFree(t.dev);
                 return fail(BD_EHIP, "bd_resample: hipEventCreate failed");
@@ -658,8 +742,11 @@ static int resample_any(bd_handle h, const void* in_dev, bool s16, int64_t n_in,
         }
     }
     const int64_t n_out = (n_in * up + down - 1) / down;
-    bd::launch_resample(in_dev, s16, n_in, channels, filt ? filt->dev : nullptr, filt ? filt->half : 0, up, down, out_dev, n_out,
-                        (hipStream_t)stream);
+    if (filt && filt->has_plan)
+        bd::launch_fir_mfma(in_dev, s16, n_in, channels, filt->fir.plan, out_dev, n_out, (hipStream_t)stream);
+    else
+        bd::launch_resample(in_dev, s16, n_in, channels, filt ? filt->dev : nullptr, filt ? filt->half : 0, up, down, out_dev,
+                            n_out, (hipStream_t)stream);
     BD_HIP(hipGetLastError());
     return BD_OK;
 }

@@ -336,6 +336,16 @@ class HipEngine:
         return t
 
     # ------------------------------------------------------------------ streamer stage
+    RESAMPLE_QUALITIES = {"scipy": 0, "hq": 1}
+
+    def set_resample_quality(self, quality: str) -> None:
+        """"hq" (default): the soxr_hq filter class librosa.resample runs in the reference (src/stream/worker.py:128);
+        "scipy": rounds 1-3's scipy.signal.resample_poly default (61 taps for 48 -> 16 kHz)."""
+        if quality not in self.RESAMPLE_QUALITIES:
+            raise ValueError(f"quality must be one of {sorted(self.RESAMPLE_QUALITIES)}")
+        with self._lock:
+            _lib.check(self._lib.bd_set_resample_quality(self._handle, self.RESAMPLE_QUALITIES[quality]))
+
     def resample(self, samples, rate_in: int, rate_out: int = SAMPLE_RATE) -> torch.Tensor:
         """[n] or [n, channels] float32 — or int16 PCM, scaled by 1/32768 — at ``rate_in`` -> mono float32 [m] at
         ``rate_out`` on the device (np.mean(axis=1) + librosa.resample of src/stream/worker.py:116-128 as one kernel)."""

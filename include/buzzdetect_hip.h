@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 2
+#define BD_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define BD_API __attribute__((visibility("default")))
@@ -118,15 +118,31 @@ BD_API int64_t bd_workspace_bytes(bd_handle h, int64_t n_samples, int32_t hop_sa
 BD_API int bd_frontend(bd_handle h, const float* pcm_dev, int64_t n_samples, int32_t hop_samples,
                 float* logmel_dev, void* stream);
 
-/* Streamer stage (src/stream/worker.py:116-128): mean over channels, then rational resample rate_in ->
-   rate_out with a Kaiser(5.0)-windowed-sinc polyphase filter of 20*max(up,down)+1 taps (up/down = the
-   reduced rate ratio).  in_dev is [n_in][channels] interleaved f32; out_dev gets bd_resample_length()
-   samples.  The reference resamples with soxr_hq (librosa default): a different low-pass, NOT reproduced
-   bit for bit - see DESIGN.md.  bd_resample_taps returns the tap count and (optionally) the taps, so that
-   a host restatement can use the identical filter. */
+/* Streamer stage (src/stream/worker.py:116-128): mean over channels (float32, as np.mean computes it), then rational
+   resample rate_in -> rate_out (up/down = the reduced rate ratio): y[j] = sum_i mono[i] h[j down - i up + half].
+   The reference calls librosa.resample with its default res_type soxr_hq.  quality selects the low-pass h:
+     BD_RESAMPLE_HQ (default)  the filter class of libsoxr's HQ recipe - linear phase, flat (< 1e-4 dB) to 0.9136 of the lower
+                               Nyquist, >= 120 dB from that Nyquist on, unity gain, no net delay, ceil(n up / down) outputs -
+                               as one Kaiser-windowed sinc (569 taps for 48 -> 16 kHz); integer decimations and every ratio
+                               whose band fits four waves' registers run on the matrix cores (resample.hip), the rest on the
+                               vector kernel.  libsoxr's source is absent from the reference checkout and it realises the
+                               response as a cascade: same class, not the same bits ("parity unpinned").
+     BD_RESAMPLE_SCIPY         rounds 1-3's filter: scipy.signal.resample_poly's default, Kaiser(5.0) windowed sinc of
+                               20*max(up,down)+1 taps (about -30 dB one kHz into the stop band: NOT the reference's class).
+   in_dev is [n_in][channels] interleaved; out_dev gets bd_resample_length() samples.  bd_resample_taps returns the tap count
+   and (optionally) the float32 taps, so that a host restatement can use the identical filter. */
+#define BD_RESAMPLE_SCIPY 0
+#define BD_RESAMPLE_HQ    1
 BD_API int64_t bd_resample_length(int64_t n_in, int32_t rate_in, int32_t rate_out);
-BD_API int bd_resample_taps(int32_t rate_in, int32_t rate_out, float* taps_host, int64_t capacity, int32_t* up,
-                            int32_t* down, int32_t* half);
+BD_API int bd_resample_taps(int32_t rate_in, int32_t rate_out, int32_t quality, float* taps_host, int64_t capacity,
+                            int32_t* up, int32_t* down, int32_t* half);
+BD_API int bd_set_resample_quality(bd_handle h, int32_t quality);
+/* Test hook (host only): the matrix-core plan of a rate ratio at BD_RESAMPLE_HQ (resample.hip).  Returns 1 and fills
+   geometry[14] = {up, down, P, D, NB, kq, mt, contiguous, RS, a_bytes, lds_bytes, half, bits of unscale_s16, bits of
+   unscale_f32}, boff[NB] and gfrag[NB][4 kq][2][64][8] (f16 bits) when the ratio runs on fir_mfma_kernel, 0 when it runs on
+   the vector kernel.  tests/test_resample.py multiplies the fragments out on the CPU against the oracle's filter. */
+BD_API int bd_debug_fir_plan(int32_t rate_in, int32_t rate_out, int32_t* geometry, int32_t* boff, int64_t boff_capacity,
+                             uint16_t* gfrag, int64_t gfrag_capacity);
 BD_API int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels, int32_t rate_in,
                        int32_t rate_out, float* out_dev, void* stream);
 /* the same from 16-bit PCM (value / 32768, libsndfile's float convention): half the PCIe bytes; with

@@ -9,10 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from buzzdetect_amd.engine import HipEngine  # noqa: E402
 
 eng = HipEngine()
+quality = sys.argv[1] if len(sys.argv) > 1 else "hq"
+eng.set_resample_quality(quality)
+print(f"quality {quality}")
 n16 = 15360 * 1024
 gen = torch.Generator(device="cuda").manual_seed(3)
 for name, rate, ch, dtype in (("48 kHz stereo s16", 48000, 2, torch.int16), ("32 kHz mono s16", 32000, 1, torch.int16),
-                              ("96 kHz stereo s16", 96000, 2, torch.int16), ("44.1 kHz stereo f32", 44100, 2, torch.float32),
+                              ("48 kHz mono f32", 48000, 1, torch.float32), ("96 kHz stereo s16", 96000, 2, torch.int16),
+                              ("44.1 kHz stereo f32", 44100, 2, torch.float32), ("24 kHz mono s16", 24000, 1, torch.int16),
                               ("16 kHz mono s16 (convert)", 16000, 1, torch.int16)):
     n = n16 * rate // 16000
     x = torch.randn((n, ch), generator=gen, device="cuda") * 0.2
