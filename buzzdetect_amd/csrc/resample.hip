@@ -77,47 +77,56 @@ template <> struct FirIn<float> {
     static __device__ __forceinline__ float one(float v) { return __builtin_amdgcn_fmed3f(v * 64.0f, -65504.0f, 65504.0f); }
 };
 
-// eight consecutive frames starting at frame i0 (a multiple of 8) -> eight staged values
-template <typename T>
-__device__ __forceinline__ void fir_load8(const T* __restrict__ in, long long i0, long long n_in, int channels, float (&v)[8]) {
-    if (i0 >= 0 && i0 + 8 <= n_in && channels <= 2) {
-        if constexpr (sizeof(T) == 2) {
-            if (channels == 1) {
-                const uint4 q = *reinterpret_cast<const uint4*>(in + i0);
-                const unsigned w[4] = {q.x, q.y, q.z, q.w};
+// Eight consecutive frames starting at frame i0 (a multiple of 8) -> the eight staged values.
+// Interior chunks of mono / stereo input, in two steps so that a thread has several chunks' loads in flight before it
+// converts the first (nothing between the loads: no branch, no register copy the compiler would have to wait for):
+// fir_fetch issues the 16-byte loads, fir_convert turns the raw words into values.
+template <typename T, int CH> struct FirRaw {
+    uint4 r[sizeof(T) * CH / 2];
+};
+
+template <typename T, int CH>
+__device__ __forceinline__ FirRaw<T, CH> fir_fetch(const T* __restrict__ in, long long i0) {
+    FirRaw<T, CH> raw;
+    const uint4* src = reinterpret_cast<const uint4*>(in + CH * i0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] = (float)(short)(w[e] & 0xffffu);
-                    v[2 * e + 1] = (float)((int)w[e] >> 16);
-                }
-            } else {
-                const uint4 q0 = reinterpret_cast<const uint4*>(in + 2 * i0)[0];
-                const uint4 q1 = reinterpret_cast<const uint4*>(in + 2 * i0)[1];
-                const unsigned w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    for (int e = 0; e < (int)(sizeof(T) * CH / 2); ++e) raw.r[e] = src[e];
+    return raw;
+}
+
+template <typename T, int CH>
+__device__ __forceinline__ void fir_convert(const FirRaw<T, CH>& raw, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2 && CH == 1) {
+        const unsigned w[4] = {raw.r[0].x, raw.r[0].y, raw.r[0].z, raw.r[0].w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e)      // (l / 32768 + r / 32768) / 2 * 32768 = (l + r) / 2, exact in float32
-                    v[e] = (float)((int)(short)(w[e] & 0xffffu) + ((int)w[e] >> 16)) * 0.5f;
-            }
-        } else {
-            if (channels == 1) {
-                const float4 a = reinterpret_cast<const float4*>(in + i0)[0];
-                const float4 b = reinterpret_cast<const float4*>(in + i0)[1];
-                const float w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = FirIn<float>::one(w[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {    // float32 mean as the reference computes it, then the exact scale
-                    const float4 a = reinterpret_cast<const float4*>(in + 2 * i0)[e];
-                    v[2 * e] = FirIn<float>::one((a.x + a.y) * 0.5f);
-                    v[2 * e + 1] = FirIn<float>::one((a.z + a.w) * 0.5f);
-                }
-            }
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = (float)(short)(w[e] & 0xffffu);
+            v[2 * e + 1] = (float)((int)w[e] >> 16);
         }
-        return;
+    } else if constexpr (sizeof(T) == 2) {
+        const unsigned w[8] = {raw.r[0].x, raw.r[0].y, raw.r[0].z, raw.r[0].w, raw.r[1].x, raw.r[1].y, raw.r[1].z, raw.r[1].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)              // (l / 32768 + r / 32768) / 2 * 32768 = (l + r) / 2, exact in float32
+            v[e] = (float)((int)(short)(w[e] & 0xffffu) + ((int)w[e] >> 16)) * 0.5f;
+    } else if constexpr (CH == 1) {
+        const unsigned w[8] = {raw.r[0].x, raw.r[0].y, raw.r[0].z, raw.r[0].w, raw.r[1].x, raw.r[1].y, raw.r[1].z, raw.r[1].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = FirIn<float>::one(__uint_as_float(w[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {            // float32 mean as the reference computes it, then the exact scale
+            const uint4 a = raw.r[e];
+            v[2 * e] = FirIn<float>::one((__uint_as_float(a.x) + __uint_as_float(a.y)) * 0.5f);
+            v[2 * e + 1] = FirIn<float>::one((__uint_as_float(a.z) + __uint_as_float(a.w)) * 0.5f);
+        }
     }
+}
+
+// the signal's edges (samples outside it are zero) and inputs of three or more channels: one sample at a time
+template <typename T>
+__device__ __forceinline__ void fir_slow8(const T* __restrict__ in, long long i0, long long n_in, int channels, float (&v)[8]) {
 #pragma unroll 1
-    for (int e = 0; e < 8; ++e) {               // the signal's edges and the many-channel case: one sample at a time
+    for (int e = 0; e < 8; ++e) {
         const long long i = i0 + e;
         float m = 0.0f;
         if (i >= 0 && i < n_in) {
@@ -138,6 +147,76 @@ __device__ __forceinline__ void fir_load8(const T* __restrict__ in, long long i0
             }
         }
         v[e] = m;
+    }
+}
+
+__device__ __forceinline__ void fir_put8(char* a_hi, char* a_lo, int phys, const float (&v)[8]) {
+    f16x4 h0, l0, h1, l1;
+    fir_split(v[0], v[1], v[2], v[3], h0, l0);
+    fir_split(v[4], v[5], v[6], v[7], h1, l1);
+    f16x8 hv, lv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hv[e] = h0[e]; hv[4 + e] = h1[e];
+        lv[e] = l0[e]; lv[4 + e] = l1[e];
+    }
+    *reinterpret_cast<f16x8*>(a_hi + 16 * phys) = hv;
+    *reinterpret_cast<f16x8*>(a_lo + 16 * phys) = lv;
+}
+
+// The staged signal of a workgroup: chunk q -> its first frame and its place in LDS; channel mean -> (hi, lo) f16 halves.
+// CH = 1 / 2: the wave's groups of interior chunks take the two-step path above; CH = 0: everything one sample at a time.
+template <typename T, int CH, int ROWS, int CPR>
+__device__ __forceinline__ void fir_stage(const T* __restrict__ in, long long n_in, int channels, const FirPlan& p, long long base,
+                                          char* a_hi, char* a_lo, int tid) {
+    const int total = p.contiguous ? (ROWS - 1) * (p.D >> 3) + CPR : ROWS * CPR;
+    constexpr int GROUP = 4;                                // chunks whose loads a thread has in flight together
+    for (int q0 = tid; q0 < total; q0 += GROUP * kFirThreads) {
+        long long i0[GROUP];
+        int phys[GROUP];
+        bool interior = true;
+#pragma unroll
+        for (int gi = 0; gi < GROUP; ++gi) {
+            const int q = q0 + gi * kFirThreads;
+            if (p.contiguous) {
+                i0[gi] = base + 8LL * q;
+                phys[gi] = q + (p.skew_magic ? (int)__umulhi((unsigned)q, p.skew_magic) : 0);
+            } else {
+                const int row = q / CPR, c = q - row * CPR;
+                i0[gi] = base + (long long)row * p.D + 8LL * c;
+                phys[gi] = row * p.RS + c;
+            }
+            if (q >= total) {                               // past the span: load the group's first chunk again, store nothing
+                i0[gi] = i0[0];
+                phys[gi] = -1;
+            }
+            interior = interior && i0[gi] >= 0 && i0[gi] + 8 <= n_in;
+        }
+        if (CH != 0 && __all(interior)) {
+            if constexpr (CH != 0) {
+                FirRaw<T, (CH ? CH : 1)> raw[GROUP];
+#pragma unroll
+                for (int gi = 0; gi < GROUP; ++gi) raw[gi] = fir_fetch<T, (CH ? CH : 1)>(in, i0[gi]);
+                // every load of the group is issued before the first value is converted (left alone, the scheduler sinks
+                // each chunk's loads to its conversion: one exposed memory round trip per chunk instead of per group)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int gi = 0; gi < GROUP; ++gi) {
+                    float v[8];
+                    fir_convert<T, (CH ? CH : 1)>(raw[gi], v);
+                    if (phys[gi] >= 0) fir_put8(a_hi, a_lo, phys[gi], v);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int gi = 0; gi < GROUP; ++gi) {
+                if (q0 + gi * kFirThreads >= total) break;
+                float v[8];
+                fir_slow8(in, i0[gi], n_in, channels, v);
+                fir_put8(a_hi, a_lo, phys[gi], v);
+            }
+        }
     }
 }
 
@@ -170,44 +249,9 @@ __global__ __launch_bounds__(kFirThreads, 2) void fir_mfma_kernel(const T* __res
     char* const a_hi = smem;
     char* const a_lo = smem + p.a_bytes;
     const long long base = m0 * p.D + p.boff[pb];
-    if (p.contiguous) {
-        const int nch = (ROWS - 1) * (p.D >> 3) + 2 * KSTOT;
-        for (int q = tid; q < nch; q += kFirThreads) {
-            float v[8];
-            fir_load8(in, base + 8LL * q, n_in, channels, v);
-            f16x4 h0, l0, h1, l1;
-            fir_split(v[0], v[1], v[2], v[3], h0, l0);
-            fir_split(v[4], v[5], v[6], v[7], h1, l1);
-            const int phys = q + (p.skew_magic ? (int)__umulhi((unsigned)q, p.skew_magic) : 0);
-            f16x8 hv, lv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hv[e] = h0[e]; hv[4 + e] = h1[e];
-                lv[e] = l0[e]; lv[4 + e] = l1[e];
-            }
-            *reinterpret_cast<f16x8*>(a_hi + 16 * phys) = hv;
-            *reinterpret_cast<f16x8*>(a_lo + 16 * phys) = lv;
-        }
-    } else {
-        constexpr int CPR = 2 * KSTOT;                      // chunks per row
-        for (int q = tid; q < ROWS * CPR; q += kFirThreads) {
-            const int row = q / CPR, c = q - row * CPR;
-            float v[8];
-            fir_load8(in, base + (long long)row * p.D + 8LL * c, n_in, channels, v);
-            f16x4 h0, l0, h1, l1;
-            fir_split(v[0], v[1], v[2], v[3], h0, l0);
-            fir_split(v[4], v[5], v[6], v[7], h1, l1);
-            const int phys = row * p.RS + c;
-            f16x8 hv, lv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hv[e] = h0[e]; hv[4 + e] = h1[e];
-                lv[e] = l0[e]; lv[4 + e] = l1[e];
-            }
-            *reinterpret_cast<f16x8*>(a_hi + 16 * phys) = hv;
-            *reinterpret_cast<f16x8*>(a_lo + 16 * phys) = lv;
-        }
-    }
+    if (channels == 1) fir_stage<T, 1, ROWS, 2 * KSTOT>(in, n_in, channels, p, base, a_hi, a_lo, tid);
+    else if (channels == 2) fir_stage<T, 2, ROWS, 2 * KSTOT>(in, n_in, channels, p, base, a_hi, a_lo, tid);
+    else fir_stage<T, 0, ROWS, 2 * KSTOT>(in, n_in, channels, p, base, a_hi, a_lo, tid);
     __syncthreads();
 
     // ---- the product: this wave's k-steps over every row tile ----
