@@ -26,6 +26,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# throughput of the architecture on synthetic data: random-init weights in the reference layout ("data" in the JSON line says
+# so); the product refuses to run without real weights unless asked (buzzdetect_amd/weights.py)
+os.environ.setdefault("BUZZDETECT_SYNTHETIC_WEIGHTS", "1")
 
 SAMPLE_RATE = 16000
 WINDOWS_PER_BATCH = 1024

@@ -5,6 +5,8 @@ The reference sets ``patch_hop_seconds = framehop_s`` on the loaded model (embed
 hop ``int(hop_s * 16000)`` (features.py:99) and the patch step ``round(100 * hop_s)``
 (features.py:70-71) are then derived independently, which is what the engine does.
 """
+import os
+
 from src.inference.embedding import BaseEmbedder
 
 
@@ -18,12 +20,19 @@ class EmbedderYamnet(BaseEmbedder):
 
     engine_embedder = "yamnet"
 
+    def variables_candidates(self):
+        """The reference loads yamnet.keras beside this file (embedder.py:25-31); the engine reads the TensorBundle of the
+        same weights the checkout keeps there, variables/variables.data-00000-of-00001."""
+        from buzzdetect_amd import weights
+        return weights.plugin_variables(os.path.dirname(os.path.realpath(__file__)), self.engine_embedder)
+
     def attach(self, engine):
         self.model = engine
 
     def initialize(self):
         from buzzdetect_amd.engine import HipEngine
-        self.model = HipEngine(embeddername=self.engine_embedder, modelname=None)
+        self.model = HipEngine(embeddername=self.engine_embedder, modelname=None,
+                               variables_candidates=self.variables_candidates())
 
     def embed(self, audio):
         """1-D float32 audio at 16 kHz -> [n_windows, 1024] embeddings."""

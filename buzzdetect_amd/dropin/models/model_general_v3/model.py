@@ -16,7 +16,9 @@ class ModelGeneralV3(BaseModel):
         engine_embedder = getattr(self.embedder, "engine_embedder", None)
         if engine_embedder is None:
             raise RuntimeError(f"embedder plugin '{self.embeddername}' is not backed by the HIP engine")
-        self.model = HipEngine(embeddername=engine_embedder, modelname=self.modelname)
+        # the embedder's weights come from beside the EMBEDDER plugin, where the reference's embedder.initialize() loads them
+        self.model = HipEngine(embeddername=engine_embedder, modelname=self.modelname,
+                               variables_candidates=self.embedder.variables_candidates())
         self.embedder.attach(self.model)   # one set of weights serves embed() and predict()
 
     def predict(self, audiosamples):

@@ -158,15 +158,27 @@ class HipEngine:
 
     def __init__(self, embeddername: str = "yamnet_k2", modelname: Optional[str] = "model_general_v3",
                  device: Optional[int] = None, embedder_variables: Optional[str] = None,
-                 embedder_blob: Optional[np.ndarray] = None):
+                 embedder_blob: Optional[np.ndarray] = None, variables_candidates=None,
+                 synthetic_weights: Optional[bool] = None):
+        """``embedder_blob`` / ``embedder_variables``: the weights / an explicit ``variables.data-00000-of-00001``;
+        else ``variables_candidates`` (the embedder plugin passes the places beside itself where the reference keeps its
+        SavedModel; default: ``embedders/<name>`` under the working directory and under the packaged overlay), then
+        ``$BUZZDETECT_YAMNET_VARIABLES``; ``synthetic_weights`` (or ``BUZZDETECT_SYNTHETIC_WEIGHTS=1``) opts in to seeded
+        stand-ins with a warning.  No source: ``FileNotFoundError`` (``weights.load_embedder_blob``)."""
         self._handle = C.c_void_p()
         self._lib = _lib.load()
+        # the weights first (host only): a missing model fails the same way with or without a GPU in the box
+        if embedder_blob is None:
+            if variables_candidates is None:
+                variables_candidates = weights.default_candidates(embeddername)
+            blob = weights.load_embedder_blob(embedder_variables, variables_candidates, synthetic_weights)
+        else:
+            blob = embedder_blob
         if not torch.cuda.is_available():
             raise RuntimeError("buzzdetect_amd: no HIP device visible to PyTorch; this engine has no CPU path")
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
 
-        blob = weights.load_embedder_blob(embedder_variables) if embedder_blob is None else embedder_blob
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         mel = np.ascontiguousarray(weights.load_mel(embeddername), dtype=np.float32)
         w = _lib.bd_weights()

@@ -10,12 +10,18 @@ separable layers (``embedders/yamnet/yamnet.py:77-93``) depthwise kernel
 The C-ABI (``include/buzzdetect_hip.h``) takes that blob unchanged and folds the
 BatchNorms itself, so a user who owns the real file can hand it straight in.
 
-That file is NOT part of the reference checkout (``.MISSING_LARGE_BLOBS``), so
-``synthetic_embedder_blob`` provides seeded stand-ins in the same layout.
+That file is NOT part of the reference checkout (``.MISSING_LARGE_BLOBS``).  ``load_embedder_blob`` looks for it
+where the reference loads its SavedModel - next to the embedder plugin (``embedders/yamnet_k2/embedder.py:14-24``:
+``models/yamnet_wholehop`` / ``models/yamnet_halfhop``; ``embedders/yamnet/embedder.py:25-31``: beside ``embedder.py``) -
+then in ``BUZZDETECT_YAMNET_VARIABLES``, and FAILS when there is none, as the reference does when its model directory is
+missing.  ``synthetic_embedder_blob`` (seeded stand-ins in the same layout) is used only on an explicit opt-in -
+``synthetic=True`` or ``BUZZDETECT_SYNTHETIC_WEIGHTS=1``, which the tests, ``bench.py`` and ``smoke()`` set - and says
+so with a WARNING on logger ``buzzdetect``: result files written with it are noise in the reference's format.
 """
 from __future__ import annotations
 
 import json
+import logging
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -96,16 +102,94 @@ def synthetic_embedder_blob(seed: int = SYNTHETIC_SEED) -> np.ndarray:
     return blob
 
 
-def load_embedder_blob(path: Optional[str]) -> np.ndarray:
-    """A real ``variables.data-00000-of-00001`` if the user has one, else synthetic."""
-    if path is None:
-        path = os.environ.get("BUZZDETECT_YAMNET_VARIABLES")
+VARIABLES_DATA = "variables.data-00000-of-00001"
+VARIABLES_ENV = "BUZZDETECT_YAMNET_VARIABLES"
+SYNTHETIC_ENV = "BUZZDETECT_SYNTHETIC_WEIGHTS"
+PACKAGED_OVERLAY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
+_log = logging.getLogger("buzzdetect")
+
+
+def plugin_variables(plugin_dir: str, engine_embedder: str, framehop_prop=None) -> List[str]:
+    """Where the embedder weights sit relative to an embedder plugin's directory, in the reference's own layout.
+
+    ``yamnet_k2`` (embedders/yamnet_k2/embedder.py:14-24): ``models/yamnet_wholehop`` for framehop_prop 1,
+    ``models/yamnet_halfhop`` for 0.5 (the two SavedModels hold the same variables; without a hop both are tried);
+    ``yamnet`` (embedders/yamnet/embedder.py:25-31 loads ``yamnet.keras`` beside the plugin, an HDF5 archive this
+    package cannot read without h5py): the TensorBundle of the same weights the checkout keeps beside it,
+    ``variables/variables.data-00000-of-00001``."""
+    if engine_embedder == "yamnet_k2":
+        subs = {1: ("yamnet_wholehop",), 0.5: ("yamnet_halfhop",)}.get(framehop_prop, ("yamnet_wholehop", "yamnet_halfhop"))
+        return [os.path.join(plugin_dir, "models", sub, "variables", VARIABLES_DATA) for sub in subs]
+    return [os.path.join(plugin_dir, "variables", VARIABLES_DATA)]
+
+
+def default_candidates(engine_embedder: str, framehop_prop=None) -> List[str]:
+    """Plugin directories a bare ``HipEngine()`` / ``analyze()`` looks in: ``embedders/<name>`` under the working directory
+    (how buzzdetect resolves plugins, src/config.py:23), then the overlay shipped inside this package."""
+    out: List[str] = []
+    for root in (os.getcwd(), PACKAGED_OVERLAY):
+        for c in plugin_variables(os.path.join(root, "embedders", engine_embedder), engine_embedder, framehop_prop):
+            if c not in out:
+                out.append(c)
+    return out
+
+
+def read_variables(path: str) -> np.ndarray:
+    """The embedder blob from a ``variables.data-00000-of-00001``.  With its ``variables.index`` beside it every tensor is
+    looked up by name and checked (shape, float32) and the blob is assembled in the order the C ABI expects, whatever order
+    the file keeps; without one the file must BE that layout."""
+    index_path = os.path.join(os.path.dirname(path), "variables.index")
+    if os.path.exists(index_path):
+        from . import artifacts
+        index = artifacts.read_bundle_index(index_path)
+        blob = np.empty(EMBEDDER_BLOB_FLOATS, dtype=np.float32)
+        for name, shape, off in expected_table():
+            key = name + "/.ATTRIBUTES/VARIABLE_VALUE"
+            entry = index.get(key) or index.get(name)
+            if entry is None:
+                raise ValueError(f"{index_path}: no tensor {name}")
+            if tuple(entry.shape) != tuple(shape) or entry.dtype != 1:
+                raise ValueError(f"{index_path}: {name} is {entry.shape} dtype {entry.dtype}, expected float32 {shape}")
+            blob[off:off + entry.count] = artifacts.read_bundle_tensor(path, entry).reshape(-1)
+        return blob
+    raw = np.fromfile(path, dtype="<f4", count=EMBEDDER_BLOB_FLOATS)
+    if raw.size != EMBEDDER_BLOB_FLOATS:
+        raise ValueError(f"{path}: expected at least {EMBEDDER_BLOB_FLOATS * 4} bytes of f32 payload")
+    return raw.astype(np.float32)
+
+
+def synthetic_allowed(synthetic: Optional[bool] = None) -> bool:
+    if synthetic is not None:
+        return bool(synthetic)
+    return os.environ.get(SYNTHETIC_ENV, "").strip().lower() in ("1", "true", "yes")
+
+
+def load_embedder_blob(path: Optional[str] = None, candidates=(), synthetic: Optional[bool] = None) -> np.ndarray:
+    """The embedder weights, in this order: ``path`` (must exist); the first of ``candidates`` that exists (the plugin's
+    own directory, ``plugin_variables``); ``$BUZZDETECT_YAMNET_VARIABLES``; seeded synthetic weights ONLY when opted in
+    (``synthetic=True`` or ``BUZZDETECT_SYNTHETIC_WEIGHTS=1``), with a WARNING.  Otherwise ``FileNotFoundError`` naming
+    every place looked at - never a silent fallback."""
     if path:
-        raw = np.fromfile(path, dtype="<f4", count=EMBEDDER_BLOB_FLOATS)
-        if raw.size != EMBEDDER_BLOB_FLOATS:
-            raise ValueError(f"{path}: expected at least {EMBEDDER_BLOB_FLOATS * 4} bytes of f32 payload")
-        return raw.astype(np.float32)
-    return synthetic_embedder_blob()
+        return read_variables(path)
+    tried = []
+    for c in candidates:
+        tried.append(c)
+        if os.path.exists(c):
+            _log.info(f"embedder weights: {c}")
+            return read_variables(c)
+    env = os.environ.get(VARIABLES_ENV)
+    if env:
+        _log.info(f"embedder weights: {env} (${VARIABLES_ENV})")
+        return read_variables(env)
+    if synthetic_allowed(synthetic):
+        _log.warning("SYNTHETIC embedder weights (seeded random stand-ins, seed %d): no %s was found and synthetic weights "
+                     "were asked for (synthetic=True or %s=1).  Results are NOT YAMNet's - fit for tests and throughput "
+                     "measurements only.", SYNTHETIC_SEED, VARIABLES_DATA, SYNTHETIC_ENV)
+        return synthetic_embedder_blob()
+    raise FileNotFoundError(
+        "YAMNet embedder weights not found.  Looked for " + ", ".join(tried or ["(no plugin directory given)"]) +
+        f"; ${VARIABLES_ENV} is not set.  Put the checkout's {VARIABLES_DATA} there (the reference loads its SavedModel from "
+        f"the same directory), point ${VARIABLES_ENV} at it, or opt in to seeded synthetic weights with {SYNTHETIC_ENV}=1.")
 
 
 def split_blob(blob: np.ndarray) -> Dict[str, np.ndarray]:

@@ -3,6 +3,7 @@
 bd_predict_batch over 5 chunks (1040 windows)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("BUZZDETECT_SYNTHETIC_WEIGHTS", "1")      # developer tool: timing on the seeded stand-in weights
 import torch
 from buzzdetect_amd.engine import HipEngine
 

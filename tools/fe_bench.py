@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("BUZZDETECT_SYNTHETIC_WEIGHTS", "1")      # developer tool: timing on the seeded stand-in weights
 from buzzdetect_amd.engine import HipEngine  # noqa: E402
 from oracle import yamnet_oracle as O  # noqa: E402
 from buzzdetect_amd import weights as W  # noqa: E402

@@ -43,6 +43,7 @@ def read_int(path):
 def child(seconds):
     import torch
     sys.path.insert(0, ROOT)
+    os.environ.setdefault("BUZZDETECT_SYNTHETIC_WEIGHTS", "1")      # developer tool: timing on the seeded stand-in weights
     from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
     hw = hwmon_of(0)
     eng = HipEngine(device=0)

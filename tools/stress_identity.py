@@ -9,6 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("BUZZDETECT_SYNTHETIC_WEIGHTS", "1")      # developer tool: timing on the seeded stand-in weights
 from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
 
 n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 3
