@@ -1836,9 +1836,20 @@ __global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8
     if (li + 1 < nl) {                        // this tile's rows of the next layer's input: written and visible to this CU
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // L1 only (workgroup scope): the buffer read next was last read two layers ago.  NOT `buffer_inv sc1`: the agent-scope
-        // form also drops this XCD's L2 contents - issued by 12 waves of 32 drifting workgroups it cost the run a third of its
-        // speed (layers 2-4 of a run 58-68 us each instead of 41-44; 1.389 vs 1.496 M windows/s on one stream).
+        // What this hand-off relies on (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+        //  * producer and consumer of every byte are THIS workgroup, i.e. one CU: no other CU ever reads or writes the tile's
+        //    rows, so none of the inter-workgroup rules (agent-scope release / acquire, `sc1`) is needed - those exist because
+        //    a CU's vector L1 is never refreshed by ANOTHER CU's stores and the XCDs' L2s are not coherent with each other;
+        //  * the vector L1 is write-through: once a wave's `s_waitcnt vmcnt(0)` has returned, its stores have left the CU for
+        //    this XCD's L2, which is where this CU's L1 misses (and the producers' LDS-DMA loads) are served from; the
+        //    workgroup barrier makes that true for all twelve waves before any of them requests the next layer's slabs;
+        //  * what CAN be stale is this CU's own L1: it may still hold lines of the buffer read next from when the workgroup
+        //    read it two layers ago.  `buffer_inv sc0` (workgroup scope) invalidates exactly that L1 and nothing else.  The
+        //    guide's table is explicit that `sc0` is NOT an acquire for data written by other CUs - there is none here.
+        // NOT `buffer_inv sc1`: the agent-scope form also drops this XCD's L2 contents - issued by 12 waves of 32 drifting
+        // workgroups it cost the run a third of its speed (layers 2-4 of a run 58-68 us each instead of 41-44; 1.389 vs 1.496 M
+        // windows/s on one stream).  The under-load check (tests/test_gpu_parity.py, tools/stress_identity.py: every batch of a
+        // three-stream run against its idle-GPU bits, one counter per stream, with a negative control) covers it.
         asm volatile("buffer_inv sc0" ::: "memory");
     }
     }   // layers of the run

@@ -52,22 +52,63 @@ class _VerdictPool:
         self._next = 0
 
     def take(self):
+        # ``give_back`` runs from ``LaunchVerdict.__del__``, i.e. whenever the garbage collector pleases - also in the
+        # middle of this function, on this thread, when an allocation below triggers a collection that finalises a verdict
+        # caught in a reference cycle.  So ``give_back`` takes no lock (``deque.append`` is atomic), and this lock only
+        # keeps two takers from claiming the same idle pair.
+        word = event = None
         with self._lock:
             if self._idle and self._idle[0][1].query():
                 word, event = self._idle.popleft()
-            else:
-                if not self._blocks or self._next == self.BLOCK:
-                    self._blocks.append(torch.zeros(self.BLOCK, dtype=torch.int32, pin_memory=True))
-                    self._next = 0
+            elif self._blocks and self._next < self.BLOCK:
                 word = self._blocks[-1][self._next:self._next + 1]
                 self._next += 1
-                event = torch.cuda.Event()
+        if word is None:                       # a new block of pinned words: allocated outside the lock
+            block = torch.zeros(self.BLOCK, dtype=torch.int32, pin_memory=True)
+            with self._lock:
+                self._blocks.append(block)
+                self._next = 1
+            word = block[0:1]
+        if event is None:
+            event = torch.cuda.Event()
         word[0] = 0
         return word, event
 
     def give_back(self, word: torch.Tensor, event: "torch.cuda.Event") -> None:
-        with self._lock:
-            self._idle.append((word, event))
+        self._idle.append((word, event))       # lock-free on purpose (see take)
+
+
+class _EventPool:
+    """Recycled HIP events for results that carry no range verdict (exact-f32 mode, embeddings of the f32 path ...): the
+    same reason as above - a fresh event per result makes the runtime grow its signal pool mid-run."""
+
+    def __init__(self):
+        from collections import deque
+        self._idle: "deque" = deque()
+
+    def take(self) -> "torch.cuda.Event":
+        try:
+            event = self._idle.popleft()       # atomic; an event is only given back by the one result that owned it
+        except IndexError:
+            return torch.cuda.Event()
+        if event.query():
+            return event
+        self._idle.append(event)               # still pending behind somebody's stream: leave it, make a new one
+        return torch.cuda.Event()
+
+    def give_back(self, event: "torch.cuda.Event") -> None:
+        self._idle.append(event)
+
+
+_event_pools: dict = {}
+
+
+def _events_of(device_index: int) -> _EventPool:
+    with _verdict_pools_lock:
+        pool = _event_pools.get(device_index)
+        if pool is None:
+            pool = _event_pools[device_index] = _EventPool()
+        return pool
 
 
 _verdict_pools: dict = {}                  # device index -> pool (an event belongs to the device it was first recorded on)
@@ -122,9 +163,18 @@ class DeviceResult:
         self._redo = redo
         self._verdict = verdict
         self._lock = threading.Lock()
+        self._done = None
         if verdict is None:                   # results that never pass through the f16 path (mode f32, resample ...)
-            self._done = torch.cuda.Event()
+            self._events = _events_of(stream.device_index)
+            self._done = self._events.take()
             self._done.record(stream)
+
+    def __del__(self):
+        try:
+            if self._done is not None:
+                self._events.give_back(self._done)
+        except Exception:                      # interpreter shutdown
+            pass
 
     @property
     def shape(self) -> Tuple[int, ...]:

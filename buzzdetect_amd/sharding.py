@@ -157,7 +157,9 @@ class RoundGatherer:
     A rank that cannot deliver a recording it owns (unreadable file, a failure in its pipeline) still has to take part in
     that round's collective, or every other rank blocks in it forever: ``submit_failed`` contributes the block with its
     status row set (the ``ROW_ALIGN`` rows appended to every block; row 0, column 0: 0 = rows valid, 1 = not delivered);
-    ``dst`` does not pass such a recording on and lists it in ``failed``."""
+    ``dst`` does not pass such a recording on and lists it in ``failed``.  The same goes for ``on_file`` itself: if it
+    raises on ``dst``, the recording is listed in ``failed`` (reason in ``sink_errors``), every later round is still
+    gathered, and ``finish`` re-raises after the last one - no rank is ever left waiting in a collective."""
 
     def __init__(self, rows_per_file: Sequence[int], n_cols: int, on_file, device="cpu", dst: int = 0, group=None):
         self.rows_per_file = [int(r) for r in rows_per_file]
@@ -171,6 +173,7 @@ class RoundGatherer:
         self.submitted = set()                # recordings of this rank handed in so far (either way)
         self.failed: List[int] = []           # on dst: recordings some rank could not deliver
         self.failed_local = {}                # recording -> reason, on the rank that owns it
+        self.sink_errors = {}                 # on dst: recording -> exception its ``on_file`` raised
 
     def round_rows(self, g: int) -> int:
         files = range(g * self.world, min((g + 1) * self.world, self.n_files))
@@ -216,6 +219,12 @@ class RoundGatherer:
                 else:
                     block[: rows.shape[0]] = rows.to(self.device)
             out, _ = gather_round(block, n + ROW_ALIGN, dst=self.dst, group=self.group)
+            # The round's collective is done: the round is consumed whatever happens to its rows now.  If ``on_file``
+            # (rank 0's CSV write) raises - disk full, permissions - the recording is listed as not delivered with the
+            # reason, the pump goes on issuing the later rounds (the other ranks are already on their way into them and
+            # would otherwise block until the process-group timeout), and ``finish`` re-raises the first such error
+            # AFTER the last round.
+            self._next += 1
             if self.rank == self.dst:
                 host = out.cpu()
                 for r in range(self.world):
@@ -224,8 +233,11 @@ class RoundGatherer:
                         if float(host[r, n, 0]) != 0.0:
                             self.failed.append(f)
                         else:
-                            self.on_file(f, host[r, : self.rows_per_file[f]].numpy())
-            self._next += 1
+                            try:
+                                self.on_file(f, host[r, : self.rows_per_file[f]].numpy())
+                            except Exception as exc:      # noqa: BLE001 - kept, re-raised by finish()
+                                self.failed.append(f)
+                                self.sink_errors[f] = exc
 
     def finish(self) -> List[int]:
         """Every local recording has been submitted (``submit`` or ``submit_failed``): run the remaining rounds (a rank
@@ -234,4 +246,8 @@ class RoundGatherer:
         self._pump()
         if self._next != self.n_rounds:
             raise RuntimeError(f"rank {self.rank}: rounds {self._next}..{self.n_rounds - 1} never became ready")
+        if self.sink_errors:
+            first = min(self.sink_errors)
+            raise RuntimeError(f"rank {self.rank}: writing recording {first} failed ({len(self.sink_errors)} recording(s) in "
+                               f"all, every round was still gathered): {self.sink_errors[first]!r}") from self.sink_errors[first]
         return list(self.failed)

@@ -784,10 +784,13 @@ def test_persistent_kernels_at_grid_boundaries(engine, windows):
 
 
 def test_three_streams_under_load_give_the_idle_gpu_bits(engine):
-    """The fused kernels hand data from layer to layer through global memory inside one launch (layers 8-11) and overlay
-    LDS tiles: an ordering mistake there would only show under load.  240 batches on three analyzer streams (an engine each, as
-    bench.py and the pipeline run them), every batch compared on the device with the logits it gave on an idle GPU.
-    (tools/stress_identity.py is the long form: 69 480 batches, no difference.)"""
+    """The fused kernels overlay LDS tiles and (bd_set_fusion separable = 6) hand data from layer to layer through global
+    memory inside one launch: an ordering mistake there would only show under load.  240 batches on three analyzer streams
+    (an engine each, as bench.py and the pipeline run them), every batch compared on the device with the logits it gave on
+    an idle GPU.  One mismatch counter PER STREAM (a shared one would be a non-atomic read-modify-write from three
+    streams: a count could be lost), every side stream ordered behind the set-up on the current stream, and a negative
+    control: with one reference row corrupted the counters must add up to exactly the batches that use it.
+    (tools/stress_identity.py is the long form.)"""
     import torch
     from buzzdetect_amd.engine import HipEngine
     dev = torch.device("cuda", 0)
@@ -803,13 +806,27 @@ def test_three_streams_under_load_give_the_idle_gpu_bits(engine):
         engine.launch([x], HOP, STEP, False, True, out=out)
         torch.cuda.synchronize()
         ref.append(out)
-    bad = torch.zeros(1, dtype=torch.int64, device=dev)
     ring = [[torch.empty((1024, 13), device=dev) for _ in range(4)] for _ in engs]
-    for k in range(240):
-        j, b = k % 3, k % 4
-        out = ring[j][(k // 3) % 4][:sizes[b]]
-        with torch.cuda.stream(streams[j]):
-            engs[j].launch([parts[b]], HOP, STEP, False, True, out=out)
-            bad += (out != ref[b]).any().to(torch.int64)
-    torch.cuda.synchronize()
-    assert int(bad.item()) == 0
+
+    def run(reference):
+        bad = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in engs]     # one counter per stream
+        torch.cuda.synchronize()
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        for k in range(240):
+            j, b = k % 3, k % 4
+            out = ring[j][(k // 3) % 4][:sizes[b]]
+            with torch.cuda.stream(streams[j]):
+                engs[j].launch([parts[b]], HOP, STEP, False, True, out=out)
+                bad[j] += (out != reference[b]).any().to(torch.int64)
+        torch.cuda.synchronize()
+        return sum(int(c.item()) for c in bad)
+
+    try:
+        assert run(ref) == 0
+        broken = [r.clone() for r in ref]
+        broken[3][677, 12] += 1.0                      # the last row of the 678-window batch: batches k % 4 == 3
+        assert run(broken) == 60
+    finally:
+        for e in engs[1:]:
+            e.close()

@@ -1,7 +1,9 @@
 """Stress check: the headline loop on N analyzer streams for a while, EVERY batch's logits compared on the device with the
-logits the same batch gave on an idle GPU (bit for bit).  The fused kernels hand data from layer to layer through global
-memory inside one launch (layers 8-11) and overlay LDS tiles; this looks for an ordering mistake that only shows under load.
-GPU box.    python tools/stress_identity.py [streams=3] [seconds=30]"""
+logits the same batch gave on an idle GPU (bit for bit).  The fused kernels overlay LDS tiles and keep tiles resident across
+layers inside one launch; this looks for an ordering mistake that only shows under load.  One mismatch counter per stream
+(a shared one is a non-atomic read-modify-write from several streams and can lose a count), side streams ordered behind
+the set-up, and a negative control first: one reference row corrupted must be reported for exactly the batches that use it.
+GPU box.    python tools/stress_identity.py [streams=3] [seconds=30] [separable fusion code, default 1]"""
 import os
 import sys
 import time
@@ -14,8 +16,13 @@ from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
 
 n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
+separable = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda", 0)
 engs = [HipEngine(device=0) for _ in range(n_streams)]
+if separable != 1:
+    from buzzdetect_amd import _lib
+    for e in engs:
+        _lib.check(e._lib.bd_set_fusion(e._handle, 3, separable))
 streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
 hop, step = hop_samples(0.96), patch_step(0.96)
 N = 57_600_000
@@ -32,23 +39,42 @@ for f in range(3):
         engs[0].launch([files[f][a:e]], hop, step, False, True, out=out)
         torch.cuda.synchronize()
         ref[(f, b)] = out
-bad = torch.zeros(1, dtype=torch.int64, device=dev)
 ring = [[torch.empty((1024, 13), device=dev) for _ in range(4)] for _ in range(n_streams)]
-k = 0
-batches = 0
-t0 = time.perf_counter()
-while time.perf_counter() - t0 < seconds:
-    for r in range(30):
-        for b, (a, e) in enumerate(edges):
-            j = k % n_streams
-            out = ring[j][(k // n_streams) % 4][:sizes[b]]
-            with torch.cuda.stream(streams[j]):
-                engs[j].launch([files[r % 3][a:e]], hop, step, False, True, out=out)
-                bad += (out != ref[(r % 3, b)]).any().to(torch.int64)
-            k += 1
-            batches += 1
+
+
+def run(reference, seconds, rounds=30):
+    bad = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_streams)]     # one counter per stream
     torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"{batches} batches on {n_streams} streams in {dt:.1f} s ({batches * 937.5 / dt / 1e6:.2f} M windows/s incl. the comparisons): "
-      f"{int(bad.item())} batches differ from their idle-GPU result")
-sys.exit(1 if int(bad.item()) else 0)
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+    k = batches = 0
+    t0 = time.perf_counter()
+    while True:
+        for r in range(rounds):
+            for b, (a, e) in enumerate(edges):
+                j = k % n_streams
+                out = ring[j][(k // n_streams) % 4][:sizes[b]]
+                with torch.cuda.stream(streams[j]):
+                    engs[j].launch([files[r % 3][a:e]], hop, step, False, True, out=out)
+                    bad[j] += (out != reference[(r % 3, b)]).any().to(torch.int64)
+                k += 1
+                batches += 1
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 >= seconds:
+            break
+    return batches, sum(int(c.item()) for c in bad), time.perf_counter() - t0
+
+
+# negative control: one element of one reference wrong -> exactly the batches of (file 1, batch 2) are reported
+broken = dict(ref)
+broken[(1, 2)] = ref[(1, 2)].clone()
+broken[(1, 2)][500, 7] += 1.0
+n, wrong, _ = run(broken, 0.0, rounds=30)
+expect = n // 12
+print(f"negative control: {wrong} of {n} batches reported, {expect} expected")
+if wrong != expect:
+    sys.exit(2)
+batches, wrong, dt = run(ref, seconds)
+print(f"{batches} batches on {n_streams} streams in {dt:.1f} s ({batches * 937.5 / dt / 1e6:.2f} M windows/s incl. the comparisons), "
+      f"separable fusion {separable}: {wrong} batches differ from their idle-GPU result")
+sys.exit(1 if wrong else 0)
