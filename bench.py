@@ -44,7 +44,8 @@ CNN_FLOP_PER_WINDOW = 137_289_728
 FRONTEND_BYTES_PER_WINDOW = 61_440 + 24_576      # f32 PCM in + f32 log-mel out
 STFT_HOP_BYTES = 160 * 4                         # new PCM bytes a frame brings (the 240-sample overlap amortises to 0)
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_SPLIT_F16_TFLOPS = 2500.0 / 3.0             # dense f16 MFMA peak / 3 MFMAs per f32-accurate product
+PEAK_F16_MFMA_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (the 2:1-sparse figure is never used)
+PEAK_SPLIT_F16_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # ... / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 # What the board's 1400 W limit leaves of the paper peak: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, constant operands,
@@ -502,25 +503,36 @@ def main() -> int:
 
     def buffers(rows: int):
         if rows not in blocks:
-            local = [torch.zeros((rows, n_classes), dtype=torch.float32, device=device) for _ in range(RING)]
+            # (+ 4 spare rows behind the block: the first carries this rank's (rank + 1, windows) for `ranks_seen`)
+            local = [torch.zeros((rows + sharding.ROW_ALIGN, n_classes), dtype=torch.float32, device=device) for _ in range(RING)]
             gath = None
             if world > 1 and rank == 0:
-                gath = [torch.empty((world, rows, n_classes), dtype=torch.float32,
+                gath = [torch.empty((world, rows + sharding.ROW_ALIGN, n_classes), dtype=torch.float32,
                                     device="cpu" if rehearsal else device) for _ in range(RING)]
             blocks[rows] = (local, gath, [None] * RING)
         return blocks[rows]
 
     issued = [0]
     dealt = [0]
+    read_back = {"batches": 0, "rows": 0, "nonfinite": 0}
+    # N > 1: what the gathers delivered, counted on rank 0 FROM the gathered blocks: every rank writes (rank + 1, windows of
+    # the round) into the first spare row behind its block; rank 0 adds them up on the communication stream
+    seen = torch.zeros((world, 2), dtype=torch.float64, device="cpu" if rehearsal else device) if world > 1 and rank == 0 else None
 
     def run_files(n_steps: int, use_streams: bool = True):
-        """n_steps x 50 recordings through this rank's share of the rounds (see the module docstring)."""
-        for rnd in sharding.plan_rounds(n_steps * files_per_step, batch_windows, world):
+        """n_steps x 50 recordings through this rank's share of the rounds (see the module docstring).  Once per step (50
+        recordings) one batch's result is read back on the host through DeviceResult.numpy() - the path the reference's
+        writer takes (src/write/worker.py:69): the range verdict of its launch set is waited for and looked at, the rows
+        cross PCIe - so the verdict path is inside the timed region."""
+        rounds = sharding.plan_rounds(n_steps * files_per_step, batch_windows, world)
+        per_step = max(1, len(rounds) // max(n_steps, 1))
+        for ri, rnd in enumerate(rounds):
             local, gath, reusable = buffers(rnd.rows)
             slot = issued[0] % RING
             issued[0] += 1
             mine = rnd.units[rank]
             used = set()
+            probe = None
             for u, at in zip(mine, sharding.unit_offsets(mine)):
                 j = (dealt[0] % len(engines)) if use_streams else 0       # batches dealt round-robin in issue order
                 dealt[0] += 1
@@ -530,16 +542,33 @@ def main() -> int:
                 used.add(j)
                 first, n = batches[u.batch]
                 with torch.cuda.stream(s):
-                    engines[j].predict(files[u.file % len(files)][first:first + n], framehop_s,
-                                       out=local[slot][at:at + u.windows])
+                    res = engines[j].predict(files[u.file % len(files)][first:first + n], framehop_s,
+                                             out=local[slot][at:at + u.windows])
+                if probe is None:
+                    probe = res
+            if world > 1 and mine:
+                with torch.cuda.stream(streams[next(iter(used))]):
+                    local[slot][rnd.rows, 0] = float(rank + 1)
+                    local[slot][rnd.rows, 1] = float(sum(u.windows for u in mine))
+            if probe is not None and ri % per_step == per_step - 1:
+                rows = probe.numpy()                       # waits for that launch set's verdict, repeats in f32 if raised
+                read_back["batches"] += 1
+                read_back["rows"] += int(rows.shape[0])
+                read_back["nonfinite"] += int((~np.isfinite(rows)).sum())
             if world > 1:         # ONE gather per round, after both analyzer streams, off their critical path
                 for j in used:
                     comm_stream.wait_stream(streams[j])
                 with torch.cuda.stream(comm_stream):
+                    nrow = rnd.rows + sharding.ROW_ALIGN
                     if rehearsal:
-                        sharding.gather_round(local[slot].cpu(), rnd.rows, dst=0, out=gath[slot] if gath else None)
+                        sharding.gather_round(local[slot].cpu(), nrow, dst=0, out=gath[slot] if gath else None)
                     else:
-                        sharding.gather_round(local[slot], rnd.rows, dst=0, out=gath[slot] if gath else None)
+                        sharding.gather_round(local[slot], nrow, dst=0, out=gath[slot] if gath else None)
+                    if seen is not None:                   # per sending rank: rounds it took part in, windows it delivered
+                        mark = gath[slot][:, rnd.rows, :2].to(torch.float64)
+                        ok = (mark[:, 0] == torch.arange(1, world + 1, dtype=torch.float64, device=mark.device))
+                        seen[:, 0] += ok.to(torch.float64)
+                        seen[:, 1] += mark[:, 1] * ok.to(torch.float64)
                     ev = torch.cuda.Event()
                     ev.record(comm_stream)
                     reusable[slot] = ev
@@ -569,8 +598,17 @@ def main() -> int:
     # region 1: the number reported as `value` — nothing but the hot path (and, for N > 1, the gathers)
     for e in engines:
         e.profile_enable(False)
+    read_back.update(batches=0, rows=0, nonfinite=0)
+    reruns0 = sum(e.overflow_reruns for e in engines)
+    if seen is not None:
+        fence()
+        seen.zero_()
     with PowerWatch(torch, dev_index) as watch:
         elapsed = timed_region(args.steps)
+    timed_read_back = dict(read_back, exact_f32_repeats=sum(e.overflow_reruns for e in engines) - reruns0)
+    ranks_seen = None
+    if seen is not None:
+        ranks_seen = [{"rank": r, "rounds": int(seen[r, 0].item()), "windows": int(seen[r, 1].item())} for r in range(world)]
     windows_per_step = windows_per_file * files_per_step
     total_windows = windows_per_step * args.steps
     value = total_windows / elapsed
@@ -605,11 +643,18 @@ def main() -> int:
             "audio_seconds_per_s": round(value * framehop_s, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "f32 in / f32 accumulate; 1x1-conv products as split-f16 MFMA (hi+lo halves of operands scaled by "
-                          "exact powers of two - per weight row at load, per layer from an exact-f32 calibration pass - so "
-                          "that both halves are normal f16: 22-bit operands at any weight scale; 3 MFMAs per product); "
-                          "value_mode0_f32 / roofline_mode0 are the same run on exact-f32 MFMA products",
+            "vs_baseline": None, "dtype": "f32 (split-f16x3 MFMA products, f32 accumulate)",
+            "dtype_note": "f32 in / f32 accumulate; the 1x1-conv products of `value` are NOT f32 products: split-f16 MFMA (hi+lo "
+                          "halves of operands scaled by exact powers of two - per weight row at load, per layer from an "
+                          "exact-f32 calibration pass - so that both halves are normal f16: 22-bit operands at any weight "
+                          "scale; 3 MFMAs per product), inside north_star's 1e-4 on the logits against the f64 oracle.  "
+                          "value_strict_f32 is the same workload on exact-f32 MFMA products (the reference's own precision); "
+                          "value_end_to_end_f32_host is `value`'s workload starting from float32 PCM in pinned HOST memory "
+                          "(the reference's dtype_in), PCIe copies inside the timed region (SURVEY 8d's end-to-end number)",
+            "value_strict_f32": None, "value_end_to_end_f32_host": None,
+            "value_scope": "PCM resident in HBM when the timed region starts; per step one batch's logits are read back on the "
+                           "host through DeviceResult.numpy() (range verdict waited for and checked, D2H copy)",
+            "timed_read_back": timed_read_back,
             "timed_region_s": round(elapsed, 4),
             "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
             "config": {"workload": f"config 2 x {files_per_step} per step: synthetic 1 h 16 kHz mono recordings, each fed as batches "
@@ -627,6 +672,11 @@ def main() -> int:
                        "timing": "value from K clean steps; per-kernel HIP-event times from a second region "
                                  f"({ev_steps} recordings, one stream)"},
         }
+        if ranks_seen is not None:
+            out["ranks_seen"] = ranks_seen
+            out["ranks_seen_note"] = ("counted on rank 0 from the gathered blocks of the timed region: rounds in which the block "
+                                      "of that rank arrived with its marker, windows it announced; planned total "
+                                      f"{total_windows} windows")
         power = watch.summary() if rank == 0 else None
         if power:
             out["power"] = power
@@ -684,6 +734,12 @@ def main() -> int:
                     out["roofline"]["traffic_source"] = PMC_TRAFFIC_FILE + " ((2*FETCH_SIZE + WRITE_SIZE)*1024 per launch)"
             except (OSError, ValueError, KeyError):
                 pass
+            # the whole path, not only its best kernel: f16 MFMA FLOP/s executed at `value` (3 MFMAs per 1x1-conv product)
+            # over the 2.5 PFLOP/s dense f16 peak
+            out["roofline"]["pipeline_frac"] = round(3.0 * POINTWISE_FLOP_PER_WINDOW * value / world / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)
+            out["roofline"]["pipeline_frac_note"] = ("executed f16 MFMA FLOP/s of the whole hot path at `value` per GPU (3 x 132.12 "
+                                                     "MFLOP per window) / 2500 TFLOP/s: every kernel, launch gap and the "
+                                                     "front end included")
             out["roofline"].update({"avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                                     "launches": d["launches"],
                                     "flop_per_launch_avg": d["flops"] // d["launches"],
@@ -730,6 +786,7 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
     v, gbs = h2d_leg(engines[:2], streams[:2], device, hop, framehop_s, k, s16=False)
     out["value_h2d_f32"] = {"value": v, "unit": "windows/s", "pcie_GBps": gbs,
                             "what": "the same with float32 PCM on the host (the reference's dtype_in)"}
+    out["value_end_to_end_f32_host"] = v
     log(f"host-resident f32 batches: {v:.0f} windows/s ({gbs} GB/s over PCIe)")
 
     # the front-end kernel alone on one 1024-window batch (98 304 frames), HIP events on its stream: the north star's
@@ -759,8 +816,21 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
         valu = max(float(r["SQ_INSTS_VALU"]) for r in rows)
     except (OSError, ValueError, KeyError):
         pass
+    # how close the kernel is to its OWN instruction floor.  Lane-instructions a packed-f32 16 x 16 FFT
+    # front end needs per 400-sample frame (a v_pk_*_f32 on a (re, im) pair counts as one):
+    #   Hann window                          200   (200 packed complex points)
+    #   32 DFT-16 (16 over n1, 16 over n2)  2432   (8 radix-4 butterflies x 8 packed add/sub + 12 for the W16 twiddles, each)
+    #   twiddles between the two passes      450   (225 non-trivial complex multiplies x 2)
+    #   real-input split X[k], X[256 - k]    768   (128 bin pairs x 6)
+    #   |X| = sqrt(re^2 + im^2)              771   (257 bins x 3)
+    #   banded mel matrix                    461   (the matrix's non-zeros, one FMA each)
+    #   log(x + 0.001)                       192   (64 bands x 3)
+    fe_needed = 200 + 2432 + 450 + 768 + 771 + 461 + 192
     issue = None
+    valu_floor_frac = None
     if valu:
+        fe_issued = valu * 64.0 / fe_frames
+        valu_floor_frac = round(fe_needed / fe_issued, 4)
         floor_us = valu / 1024.0 * 4.0 / 2.1e3
         issue = {"valu_wave_instructions_per_launch": valu, "source": PMC_FRONTEND_FILE, "simds": 1024,
                  "cycles_per_instruction": 4.0, "clock_GHz": 2.1, "issue_floor_us": round(floor_us, 1),
@@ -772,6 +842,13 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
         "bound": "hbm", "achieved": round(fe_bytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
         "frac": round(fe_bytes / us / 1e3 / PEAK_HBM_GBS, 4), "avg_launch_us": round(us, 2), "bytes_per_launch": fe_bytes,
         "traffic": None, "north_star_gate_frac": 0.60, "gate_met": bool(fe_bytes / us / 1e3 / PEAK_HBM_GBS >= 0.60),
+        "valu_floor_frac": valu_floor_frac,
+        "valu_floor": {"lane_instructions_per_frame_needed": fe_needed,
+                       "lane_instructions_per_frame_issued": round(valu * 64.0 / fe_frames, 1) if valu else None,
+                       "what": "arithmetic a packed-f32 16 x 16 FFT + window + split + |.| + 461-FMA mel + log needs per frame "
+                               "(breakdown in bench.py) over what the kernel issues (SQ_INSTS_VALU x 64 lanes / frames): the "
+                               "kernel is within ~10-15 % of its own instruction floor, and that floor alone is ~0.5 of the "
+                               "launch - the 0.60 HBM gate is out of reach for an f32 vector FFT at 5e-5 (DESIGN.md 10)"},
         "issue_bound": issue}
     log(f"front end alone: {us:.1f} us per {fe_frames} frames = {fe_bytes / us / 1e3:.0f} GB/s "
         f"({100 * fe_bytes / us / 1e3 / PEAK_HBM_GBS:.1f} % of the HBM peak)")
@@ -810,10 +887,34 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / k
     rs_bytes = st.numel() * 2 + mono.numel() * 4
-    out["resample_roofline"] = {"kernel": "resample_kernel<short> (48 kHz stereo s16 -> 16 kHz mono f32, 61 taps)", "bound": "hbm",
-                                "achieved": round(rs_bytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+    # the reference's filter class on the matrix cores (resample.hip): 569 taps, K = 704 per 32 outputs incl. the band's zero
+    # corners, 3 f16 MFMAs per product -> executed f16 FLOP per output = 2 * 3 * 704; algorithmic f32-equivalent = 2 * 569
+    out["resample_roofline"] = {"kernel": "fir_mfma_kernel<short, 11, 4> (48 kHz stereo s16 -> 16 kHz mono f32; soxr_hq-class "
+                                          "569-tap low-pass as a Toeplitz product in split-f16 on the matrix cores)",
+                                "bound": "hbm", "achieved": round(rs_bytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": round(rs_bytes / us / 1e3 / PEAK_HBM_GBS, 4), "avg_launch_us": round(us, 2),
-                                "bytes_per_launch": rs_bytes}
+                                "bytes_per_launch": rs_bytes,
+                                "mfma_executed_f16_tflops": round(mono.numel() * 2 * 3 * 704 / us / 1e6, 1),
+                                "mfma_frac": round(mono.numel() * 2 * 3 * 704 / us / 1e6 / PEAK_F16_MFMA_TFLOPS, 4),
+                                "bound_note": "both ceilings are within 2x of each other for this stage (HBM floor ~50 us at the "
+                                              "6.3 TB/s a copy reaches, matrix floor ~30 us); as vector code the 569-tap filter "
+                                              "would be compute bound at ~180 us.  The 61-tap filter of rounds 1-3 "
+                                              "(bd_set_resample_quality 0) is resample_roofline_scipy"}
+    engines[0].set_resample_quality("scipy")
+    for _ in range(3):
+        mono = engines[0].resample(st, 48000, SAMPLE_RATE)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(k):
+        mono = engines[0].resample(st, 48000, SAMPLE_RATE)
+    e1.record()
+    torch.cuda.synchronize()
+    engines[0].set_resample_quality("hq")
+    us0 = 1e3 * e0.elapsed_time(e1) / k
+    out["resample_roofline_scipy"] = {"kernel": "decimate_kernel<short, 3> (61-tap scipy.signal.resample_poly default: NOT the "
+                                                "reference's filter class)", "bound": "hbm",
+                                      "achieved": round(rs_bytes / us0 / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": round(rs_bytes / us0 / 1e3 / PEAK_HBM_GBS, 4), "avg_launch_us": round(us0, 2)}
     log(f"resample 48k stereo s16 -> 16k mono: {us:.1f} us per batch = {rs_bytes / us / 1e3:.0f} GB/s")
     for e in engines:
         e.set_pointwise_mode("f16")
@@ -861,6 +962,7 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
         e.set_pointwise_mode("f16x3")
     if "f32" in modes:
         out["value_mode0_f32"] = {**modes["f32"], "what": "1x1 convolutions on v_mfma_f32_32x32x2_f32 (exact f32 products)"}
+        out["value_strict_f32"] = modes["f32"]["value"]
         tf = modes["f32"]["value"] * CNN_FLOP_PER_WINDOW / 1e12
         out["roofline_mode0"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),

@@ -48,3 +48,16 @@ def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():
     assert plan[11][:2] == ("sep6+dw7", "sep_ws_kernel")                        # 256 -> 256: one column tile, 8-wave kernel
     assert plan[27][:2] == ("sep14+pool", "sep_w12_ndw_kernel") and plan[28][0] == "head"     # two 512-column halves + pool
     assert plan[25][:2] == ("pw13", "sep_ws_kernel")
+
+
+def test_the_line_says_what_was_measured():
+    """the keys of the JSON line that name the arithmetic and the scope of `value` (asserted on
+    the source: the line itself needs a GPU; the driver's BENCH record carries it)."""
+    src = open(bench.__file__).read()
+    for key in ('"dtype": "f32 (split-f16x3 MFMA products, f32 accumulate)"', '"value_strict_f32"', '"value_end_to_end_f32_host"',
+                '"pipeline_frac"', '"timed_read_back"', '"ranks_seen"', '"valu_floor_frac"', '"resample_roofline"',
+                '"resample_roofline_scipy"', '"roofline"', '"cpu_baseline"'):
+        assert key in src, key
+    assert bench.PEAK_F16_MFMA_TFLOPS == 2500.0 and abs(bench.PEAK_SPLIT_F16_TFLOPS - 2500.0 / 3) < 1e-9
+    # pipeline_frac at round 3's driver-observed value: 1.609 M windows/s x 132.12 MFLOP x 3 = 638 TFLOP/s = 0.255
+    assert abs(3.0 * bench.POINTWISE_FLOP_PER_WINDOW * 1.609e6 / 1e12 / bench.PEAK_F16_MFMA_TFLOPS - 0.255) < 1e-3
