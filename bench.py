@@ -600,9 +600,10 @@ def main() -> int:
         e.profile_enable(False)
     read_back.update(batches=0, rows=0, nonfinite=0)
     reruns0 = sum(e.overflow_reruns for e in engines)
-    if seen is not None:
-        fence()
-        seen.zero_()
+    if world > 1:
+        fence()                    # (every rank: fence() holds a collective) the warm-up's gathers are done ...
+        if seen is not None:
+            seen.zero_()           # ... so the count below is the timed region's alone
     with PowerWatch(torch, dev_index) as watch:
         elapsed = timed_region(args.steps)
     timed_read_back = dict(read_back, exact_f32_repeats=sum(e.overflow_reruns for e in engines) - reruns0)

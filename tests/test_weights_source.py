@@ -141,11 +141,14 @@ def test_engine_runs_on_the_weights_beside_the_plugin(no_sources, tmp_path, monk
     x = (0.1 * np.random.default_rng(3).standard_normal(15360 * 3)).astype(np.float32)
     got = model.predict(x).numpy()
     ref_eng = HipEngine(embedder_blob=blob)
-    syn_eng = HipEngine(synthetic_weights=True)
+    here = HipEngine(synthetic_weights=True)          # the opt-in is a LAST resort: in this working directory the bundle still wins
+    syn_eng = HipEngine(embedder_blob=W.synthetic_embedder_blob())
     try:
         assert np.array_equal(got, ref_eng.predict(x, 0.96).numpy())
+        assert np.array_equal(got, here.predict(x, 0.96).numpy())
         assert np.abs(got - syn_eng.predict(x, 0.96).numpy()).max() > 1e-3
     finally:
         ref_eng.close()
         syn_eng.close()
+        here.close()
         model.model.close()
