@@ -164,72 +164,123 @@ __device__ __forceinline__ void fir_put8(char* a_hi, char* a_lo, int phys, const
     *reinterpret_cast<f16x8*>(a_lo + 16 * phys) = lv;
 }
 
-// The staged signal of a workgroup: chunk q -> its first frame and its place in LDS; channel mean -> (hi, lo) f16 halves.
-// CH = 1 / 2: the wave's groups of interior chunks take the two-step path above; CH = 0: everything one sample at a time.
-template <typename T, int CH, int ROWS, int CPR>
-__device__ __forceinline__ void fir_stage(const T* __restrict__ in, long long n_in, int channels, const FirPlan& p, long long base,
-                                          char* a_hi, char* a_lo, int tid) {
-    const int total = p.contiguous ? (ROWS - 1) * (p.D >> 3) + CPR : ROWS * CPR;
-    constexpr int GROUP = 4;                                // chunks whose loads a thread has in flight together
-    for (int q0 = tid; q0 < total; q0 += GROUP * kFirThreads) {
-        long long i0[GROUP];
-        int phys[GROUP];
-        bool interior = true;
-#pragma unroll
-        for (int gi = 0; gi < GROUP; ++gi) {
-            const int q = q0 + gi * kFirThreads;
-            if (p.contiguous) {
-                i0[gi] = base + 8LL * q;
-                phys[gi] = q + (p.skew_magic ? (int)__umulhi((unsigned)q, p.skew_magic) : 0);
-            } else {
-                const int row = q / CPR, c = q - row * CPR;
-                i0[gi] = base + (long long)row * p.D + 8LL * c;
-                phys[gi] = row * p.RS + c;
-            }
-            if (q >= total) {                               // past the span: load the group's first chunk again, store nothing
-                i0[gi] = i0[0];
-                phys[gi] = -1;
-            }
-            interior = interior && i0[gi] >= 0 && i0[gi] + 8 <= n_in;
-        }
-        if (CH != 0 && __all(interior)) {
-            if constexpr (CH != 0) {
-                FirRaw<T, (CH ? CH : 1)> raw[GROUP];
-#pragma unroll
-                for (int gi = 0; gi < GROUP; ++gi) raw[gi] = fir_fetch<T, (CH ? CH : 1)>(in, i0[gi]);
-                // every load of the group is issued before the first value is converted (left alone, the scheduler sinks
-                // each chunk's loads to its conversion: one exposed memory round trip per chunk instead of per group)
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int gi = 0; gi < GROUP; ++gi) {
-                    float v[8];
-                    fir_convert<T, (CH ? CH : 1)>(raw[gi], v);
-                    if (phys[gi] >= 0) fir_put8(a_hi, a_lo, phys[gi], v);
-                }
-            }
-        } else {
-#pragma unroll 1
-            for (int gi = 0; gi < GROUP; ++gi) {
-                if (q0 + gi * kFirThreads >= total) break;
-                float v[8];
-                fir_slow8(in, i0[gi], n_in, channels, v);
-                fir_put8(a_hi, a_lo, phys[gi], v);
-            }
-        }
+// The staged signal of a workgroup: chunk q (eight samples) -> its first frame and its place in LDS.
+template <int CPR>
+__device__ __forceinline__ void fir_chunk_at(const FirPlan& p, long long base, int q, long long& i0, int& phys) {
+    if (p.contiguous) {
+        i0 = base + 8LL * q;
+        phys = q + (p.skew_magic ? (int)__umulhi((unsigned)q, p.skew_magic) : 0);
+    } else {
+        const int row = q / CPR, c = q - row * CPR;
+        i0 = base + (long long)row * p.D + 8LL * c;
+        phys = row * p.RS + c;
     }
 }
 
-template <typename T, int KQ, int MT>
-__global__ __launch_bounds__(kFirThreads, 2) void fir_mfma_kernel(const T* __restrict__ in, long long n_in, int channels,
-                                                                  const FirPlan p, float* __restrict__ out, long long n_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// Staging in two halves so that the NEXT chunk's loads fly while this chunk is multiplied: `fetch` issues the loads of a
+// thread's first kDepth chunks of the span (interior ones; 16 bytes each, raw, into registers: nothing waits for them),
+// `commit` - a whole MFMA phase later - converts them, splits them into (hi, lo) f16 halves and writes LDS, then takes
+// whatever is left (edges of the signal one sample at a time, spans longer than kDepth x 256 chunks in groups of four
+// loads).  Without it a workgroup has bytes in flight only while it stages, a third of its time, and the stage runs at the
+// rate "bytes in flight / memory latency" allows: 2.8 TB/s where a copy reaches 6.3.
+template <typename T, int CH, int BUDGET>               // BUDGET: VGPRs the raw samples may occupy beside the filter and the accumulators
+struct FirPrefetch {
+    static constexpr int kQuads = CH ? (int)(sizeof(T) * CH / 2) : 1;       // 16-byte loads per chunk
+    static constexpr int kFit = (BUDGET < 56 ? BUDGET : 56) / (4 * kQuads);
+    static constexpr int kDepth = CH == 0 ? 0 : (kFit > 7 ? 7 : kFit < 0 ? 0 : kFit);
+    FirRaw<T, (CH ? CH : 1)> raw[kDepth ? kDepth : 1];
+    unsigned fast = 0;                                     // bit i: raw[i] holds the thread's i-th chunk
+
+    template <int CPR>
+    __device__ __forceinline__ void fetch(const T* __restrict__ in, long long n_in, const FirPlan& p, long long base, int total, int tid) {
+        fast = 0;
+        if constexpr (CH != 0) {
+#pragma unroll
+            for (int it = 0; it < kDepth; ++it) {
+                const int q = tid + it * kFirThreads;
+                long long i0;
+                int phys;
+                fir_chunk_at<CPR>(p, base, q, i0, phys);
+                if (q < total && i0 >= 0 && i0 + 8 <= n_in) {
+                    raw[it] = fir_fetch<T, (CH ? CH : 1)>(in, i0);
+                    fast |= 1u << it;
+                }
+            }
+        }
+    }
+
+    template <int CPR>
+    __device__ __forceinline__ void commit(const T* __restrict__ in, long long n_in, int channels, const FirPlan& p, long long base,
+                                           int total, char* a_hi, char* a_lo, int tid) {
+#pragma unroll
+        for (int it = 0; it < kDepth; ++it) {
+            const int q = tid + it * kFirThreads;
+            if (q < total) {
+                long long i0;
+                int phys;
+                fir_chunk_at<CPR>(p, base, q, i0, phys);
+                float v[8];
+                if (fast >> it & 1u) {
+                    if constexpr (CH != 0) fir_convert<T, (CH ? CH : 1)>(raw[it], v);
+                } else {
+                    fir_slow8(in, i0, n_in, channels, v);
+                }
+                fir_put8(a_hi, a_lo, phys, v);
+            }
+        }
+        constexpr int GROUP = kQuads <= 2 ? 4 : 2;          // the rest of a long span: a few chunks' loads in flight together
+        for (int q0 = tid + kDepth * kFirThreads; q0 < total; q0 += GROUP * kFirThreads) {
+            long long i0[GROUP];
+            int phys[GROUP];
+            bool interior = true;
+#pragma unroll
+            for (int gi = 0; gi < GROUP; ++gi) {
+                const int q = q0 + gi * kFirThreads;
+                fir_chunk_at<CPR>(p, base, q, i0[gi], phys[gi]);
+                if (q >= total) {                           // past the span: load the group's first chunk again, store nothing
+                    i0[gi] = i0[0];
+                    phys[gi] = -1;
+                }
+                interior = interior && i0[gi] >= 0 && i0[gi] + 8 <= n_in;
+            }
+            if (CH != 0 && __all(interior)) {
+                if constexpr (CH != 0) {
+                    FirRaw<T, (CH ? CH : 1)> r4[GROUP];
+#pragma unroll
+                    for (int gi = 0; gi < GROUP; ++gi) r4[gi] = fir_fetch<T, (CH ? CH : 1)>(in, i0[gi]);
+                    // every load of the group is issued before the first value is converted (left alone, the scheduler
+                    // sinks each chunk's loads to its conversion: one exposed memory round trip per chunk)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int gi = 0; gi < GROUP; ++gi) {
+                        float v[8];
+                        fir_convert<T, (CH ? CH : 1)>(r4[gi], v);
+                        if (phys[gi] >= 0) fir_put8(a_hi, a_lo, phys[gi], v);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int gi = 0; gi < GROUP; ++gi) {
+                    if (q0 + gi * kFirThreads >= total) break;
+                    float v[8];
+                    fir_slow8(in, i0[gi], n_in, channels, v);
+                    fir_put8(a_hi, a_lo, phys[gi], v);
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int KQ, int MT, int CH>
+__device__ __forceinline__ void fir_body(const T* __restrict__ in, long long n_in, int channels, const FirPlan& p,
+                                         float* __restrict__ out, long long n_out, long long n_chunks, char* smem) {
     constexpr int ROWS = 32 * MT;
     constexpr int KSTOT = kFirWaves * KQ;
+    constexpr int CPR = 2 * KSTOT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pb = blockIdx.y;
-    const long long m0 = (long long)blockIdx.x * ROWS;
 
     // this wave's share of the filter: k-steps [wave KQ, wave KQ + KQ) of phase block pb, fragment order
     f16x8 bh[KQ], bl[KQ];
@@ -245,14 +296,20 @@ __global__ __launch_bounds__(kFirThreads, 2) void fir_mfma_kernel(const T* __res
 #pragma unroll
     for (int i = 0; i < KQ; ++i) koff[i] = p.koff[wave * KQ + i];
 
-    // ---- stage: channel mean -> (hi, lo) f16 halves in LDS ----
     char* const a_hi = smem;
     char* const a_lo = smem + p.a_bytes;
-    const long long base = m0 * p.D + p.boff[pb];
-    if (channels == 1) fir_stage<T, 1, ROWS, 2 * KSTOT>(in, n_in, channels, p, base, a_hi, a_lo, tid);
-    else if (channels == 2) fir_stage<T, 2, ROWS, 2 * KSTOT>(in, n_in, channels, p, base, a_hi, a_lo, tid);
-    else fir_stage<T, 0, ROWS, 2 * KSTOT>(in, n_in, channels, p, base, a_hi, a_lo, tid);
+    const float unscale = p.unscale[sizeof(T) == 2 ? 0 : 1];
+    const int total = p.contiguous ? (ROWS - 1) * (p.D >> 3) + CPR : ROWS * CPR;
+    const long long boff = p.boff[pb];
+    FirPrefetch<T, CH, 220 - 8 * KQ - 16 * MT - 28> pf;   // 256 registers at two waves per SIMD: filter, accumulators, ~50 others
+    if ((long long)blockIdx.x < n_chunks) pf.template fetch<CPR>(in, n_in, p, (long long)blockIdx.x * ROWS * p.D + boff, total, tid);
+    // persistent: the workgroup keeps its share of the filter in registers and walks chunks of ROWS periods
+    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const long long m0 = chunk * ROWS;
+    // ---- stage: channel mean -> (hi, lo) f16 halves in LDS; then the next chunk's loads are put in flight ----
+    pf.template commit<CPR>(in, n_in, channels, p, m0 * p.D + boff, total, a_hi, a_lo, tid);
     __syncthreads();
+    if (chunk + gridDim.x < n_chunks) pf.template fetch<CPR>(in, n_in, p, (m0 + (long long)gridDim.x * ROWS) * p.D + boff, total, tid);
 
     // ---- the product: this wave's k-steps over every row tile ----
     f32x16 acc[MT];
@@ -285,7 +342,6 @@ __global__ __launch_bounds__(kFirThreads, 2) void fir_mfma_kernel(const T* __res
             red[((wave * MT + t) * 4 + g) * 64 + lane] =
                 make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
     __syncthreads();
-    const float unscale = p.unscale[sizeof(T) == 2 ? 0 : 1];
     const int g = wave;                                    // this wave sums register quad g of every tile
     const int col = lane & 31;
 #pragma unroll
@@ -305,6 +361,16 @@ __global__ __launch_bounds__(kFirThreads, 2) void fir_mfma_kernel(const T* __res
             if (j < n_out) out[j] = sv[e] * unscale;
         }
     }
+    __syncthreads();                                       // the partial tiles are read: the next chunk may be staged over them
+    }   // chunks
+}
+
+template <typename T, int KQ, int MT, int CH>     // CH: 1 = mono, 2 = stereo, 0 = any number of channels (one sample at a time)
+__global__ __launch_bounds__(kFirThreads, 2) void fir_mfma_kernel(const T* __restrict__ in, long long n_in, int channels,
+                                                                  const FirPlan p, float* __restrict__ out, long long n_out,
+                                                                  long long n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    fir_body<T, KQ, MT, CH>(in, n_in, channels, p, out, n_out, n_chunks, smem);
 }
 
 long long ceil_div(long long a, long long b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); }
@@ -428,18 +494,39 @@ void launch_fir_mfma(const void* in, bool s16, int64_t n_in, int channels, const
     if (n_out <= 0) return;
     const int rows = 32 * p.mt;
     const int64_t periods = (n_out + p.P - 1) / p.P;
-    const dim3 grid((unsigned)((periods + rows - 1) / rows), (unsigned)p.NB);
-#define BD_FIR_LAUNCH(T, KQ, MT)                                                                                  \
+    const int64_t n_chunks = (periods + rows - 1) / rows;
+    // persistent workgroups: as many as are resident together (two or three per CU by LDS and registers), each walks
+    // chunks grid.x apart with its share of the filter in registers
+    int cus = 256;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int per_cu = p.lds_bytes <= 40 * 1024 ? 3 : p.lds_bytes <= 80 * 1024 ? 2 : 1;
+    int64_t gx = (int64_t)cus * per_cu / p.NB;             // (rounded down: one workgroup too many per CU is a whole extra round)
+    if (gx > n_chunks) gx = n_chunks;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)p.NB);
+#define BD_FIR_LAUNCH_CH(T, KQ, MT, CH)                                                                           \
     do {                                                                                                          \
         static std::once_flag once_[16];                                                                          \
         int dev_ = 0;                                                                                             \
         (void)hipGetDevice(&dev_);                                                                                \
         std::call_once(once_[dev_ & 15], [] {                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_mfma_kernel<T, KQ, MT>),                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_mfma_kernel<T, KQ, MT, CH>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
         });                                                                                                       \
-        hipLaunchKernelGGL((fir_mfma_kernel<T, KQ, MT>), grid, dim3(kFirThreads), (size_t)p.lds_bytes, stream,    \
-                           static_cast<const T*>(in), (long long)n_in, channels, p, out, (long long)n_out);       \
+        hipLaunchKernelGGL((fir_mfma_kernel<T, KQ, MT, CH>), grid, dim3(kFirThreads), (size_t)p.lds_bytes, stream, \
+                           static_cast<const T*>(in), (long long)n_in, channels, p, out, (long long)n_out,        \
+                           (long long)n_chunks);                                                                  \
+    } while (0)
+#define BD_FIR_LAUNCH(T, KQ, MT)                                                                                  \
+    do {                                                                                                          \
+        if (channels == 1) BD_FIR_LAUNCH_CH(T, KQ, MT, 1);                                                        \
+        else if (channels == 2) BD_FIR_LAUNCH_CH(T, KQ, MT, 2);                                                   \
+        else BD_FIR_LAUNCH_CH(T, KQ, MT, 0);                                                                      \
     } while (0)
 #define BD_FIR_BY_KQ(T)                                                                                           \
     switch (p.kq * 8 + p.mt) {                                                                                    \
@@ -459,6 +546,7 @@ void launch_fir_mfma(const void* in, bool s16, int64_t n_in, int channels, const
     if (s16) { BD_FIR_BY_KQ(short) } else { BD_FIR_BY_KQ(float) }
 #undef BD_FIR_BY_KQ
 #undef BD_FIR_LAUNCH
+#undef BD_FIR_LAUNCH_CH
 }
 
 }  // namespace bd

@@ -11,6 +11,7 @@ from buzzdetect_amd.engine import HipEngine  # noqa: E402
 
 eng = HipEngine()
 quality = sys.argv[1] if len(sys.argv) > 1 else "hq"
+only = int(sys.argv[2]) if len(sys.argv) > 2 else None          # one input rate only (profiling runs)
 eng.set_resample_quality(quality)
 print(f"quality {quality}")
 n16 = 15360 * 1024
@@ -19,6 +20,8 @@ for name, rate, ch, dtype in (("48 kHz stereo s16", 48000, 2, torch.int16), ("32
                               ("48 kHz mono f32", 48000, 1, torch.float32), ("96 kHz stereo s16", 96000, 2, torch.int16),
                               ("44.1 kHz stereo f32", 44100, 2, torch.float32), ("24 kHz mono s16", 24000, 1, torch.int16),
                               ("16 kHz mono s16 (convert)", 16000, 1, torch.int16)):
+    if only is not None and (rate != only or ch != 2):
+        continue
     n = n16 * rate // 16000
     x = torch.randn((n, ch), generator=gen, device="cuda") * 0.2
     x = (x * 32768).clamp(-32768, 32767).to(torch.int16) if dtype == torch.int16 else x
