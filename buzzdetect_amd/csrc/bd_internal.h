@@ -132,6 +132,8 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 void launch_scale_copy(const float* src, float* dst, int64_t n, float factor, hipStream_t stream);
 bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
                             hipStream_t stream);
+bool launch_sep_f32(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream);   // sepf32.hip
+bool sep_f32_ok(const SepLayer& L, int windows);
 int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     bool band_tiles, hipStream_t stream, bool twelve_waves = true);

@@ -897,6 +897,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         const bool fuse_stem3 = fuse_stem && e->fuse_stem3 && (stop_stage < 0 || stop_stage >= 4);
         bool skip_dw3 = false;
         int skip_dw_layer = -1;      // loop index of a layer whose depthwise the previous kernel already applied
+        bool f32_layers = false;     // exact-f32 mode: every separable layer as one kernel (sepf32.hip)
         if (fuse_stem3 && e->fuse_stem4) {
             {
                 Scope sc(e, stream, 5);      // timed in the slot of pointwise 3 (slots 1-4 stay empty)
@@ -918,10 +919,21 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             first_layer = 1;
             skip_dw3 = true;
         } else {
+            // exact-f32 mode with fused separable layers (sepf32.hip): layer 2's output (98 304 floats per window) needs the
+            // larger buffer, so conv1 writes the smaller one and the two swap roles for the pass
+            bool f32_fused = mode == 0 && e->fuse_sep && !calibrating && stop_stage < 0;
+            for (int l = 0; l < 13 && f32_fused; ++l) f32_fused = bd::sep_f32_ok(sep[l], gw);
+            f32_layers = f32_fused;
+            if (f32_fused) {
+                float* t = buf_a;
+                buf_a = buf_b;
+                buf_b = t;
+            }
             {
                 Scope sc(e, stream, 1);
                 bd::launch_conv1(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, buf_a, stream);
             }
+            last = buf_a;
             last_floats = (int64_t)gw * 48 * 32 * 32;
             stopped = stop_stage == 0;
         }
@@ -986,6 +998,18 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 last = buf_a;
                 last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
                 if (stop_stage == 2 * l + 2) stopped = true;
+                continue;
+            }
+            // exact-f32 mode: depthwise + 1x1 convolution of the layer as one kernel, the depthwise output never leaves the CU
+            // (the calibration pass and the stage taps keep one kernel per op: they look at the depthwise output)
+            if (f32_layers && bd::launch_sep_f32(buf_a, buf_b, gw, L, stream)) {
+                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_sep_f32(buf_a, buf_b, gw, L, stream);
+                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                float* t = buf_a;
+                buf_a = buf_b;
+                buf_b = t;
+                last = buf_a;
+                last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
                 continue;
             }
             if (!(skip_dw3 && l == 1) && skip_dw_layer != l) {
