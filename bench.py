@@ -964,6 +964,26 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
     if "f32" in modes:
         out["value_mode0_f32"] = {**modes["f32"], "what": "1x1 convolutions on v_mfma_f32_32x32x2_f32 (exact f32 products)"}
         out["value_strict_f32"] = modes["f32"]["value"]
+        # the same mode with every separable layer as one kernel (bd_set_fusion separable = 6, sepf32.hip): bit-identical rows,
+        # the depthwise output never in HBM; selectable, not the default (it loses a few % on three streams)
+        for e in engines:
+            e.set_pointwise_mode("f32")
+            e.set_fusion(True, 6)
+        got6 = engines[0].predict(x, framehop_s).numpy()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                engines[i % len(engines)].predict(x, framehop_s)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t0
+        for e in engines:
+            e.set_fusion(True, True)
+            e.set_pointwise_mode("f16x3")
+        out["value_mode0_f32_fused"] = {"value": round(k * WINDOWS_PER_BATCH / sec, 1), "unit": "windows/s",
+                                        "max_abs_dlogit_vs_default_mode": float(np.abs(got6 - ref).max()),
+                                        "what": "exact-f32 mode, separable layers fused per layer (bd_set_fusion separable = 6)"}
+        log(f"pointwise mode f32, fused per layer: {out['value_mode0_f32_fused']['value']:.0f} windows/s")
         tf = modes["f32"]["value"] * CNN_FLOP_PER_WINDOW / 1e12
         out["roofline_mode0"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),

@@ -55,6 +55,7 @@ struct bd_engine {
     unsigned* d_range_flag = nullptr; // sticky: an activation exceeded the f16 range in mode 1 / 2 (bd_range_flag)
     bool fuse_stem = true;            // layers 1-2 and the depthwise of layer 3 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
+    bool fuse_f32 = false;            // exact-f32 mode: a separable layer as one kernel (bd_set_fusion separable = 6; sepf32.hip)
     bool fuse_stem3 = true;           // (always equal to fuse_stem: the layers 1-2 only kernel is gone)
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
@@ -921,7 +922,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         } else {
             // exact-f32 mode with fused separable layers (sepf32.hip): layer 2's output (98 304 floats per window) needs the
             // larger buffer, so conv1 writes the smaller one and the two swap roles for the pass
-            bool f32_fused = mode == 0 && e->fuse_sep && !calibrating && stop_stage < 0;
+            bool f32_fused = mode == 0 && e->fuse_f32 && !calibrating && stop_stage < 0;
             for (int l = 0; l < 13 && f32_fused; ++l) f32_fused = bd::sep_f32_ok(sep[l], gw);
             f32_layers = f32_fused;
             if (f32_fused) {
@@ -1297,9 +1298,11 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
-    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 9 &&
-        separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 9 or 12");
+    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 6 &&
+        separable != 9 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 9 or 12");
+    h->fuse_f32 = separable == 6;            // exact-f32 mode: one kernel per separable layer (sepf32.hip); the f16 modes as 1
+    if (separable == 6) separable = 1;
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_stem4 = stem >= 3;

@@ -336,7 +336,7 @@ class HipEngine:
         """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, False = off) and fused
         depthwise+pointwise kernels (True = default path, 2 = the same with layer 4 as band tiles of the generic kernel,
         3 = the same with one launch per layer for layers 8-11 instead of one for the four, 4 / 5 = the same with layer 12 /
-        layer 14 on the 8-wave kernel, 9 / 12 = plain fused layers on
+        layer 14 on the 8-wave kernel, 6 = as True and the exact-f32 mode fused per layer too, 9 / 12 = plain fused layers on
         the 8-wave / 12-wave kernel, False = one kernel per op)."""
         stem_code = 3 if stem is True else int(stem)
         with self._lock:

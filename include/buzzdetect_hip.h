@@ -257,7 +257,10 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    hook).  3: as 1 with one launch per layer for layers 8-11 (test hook).  4: as 1 with layer 12 on the
                    8-wave kernel (256-column tiles) instead of the 12-wave one (test hook).  5: as 1 with layer 14 + pool on the
                    8-wave kernel (four 256-column tiles on all CUs: faster alone, slower in a full pipeline) instead of the
-                   12-wave one (two 512-column halves; test hook).  9 / 12: plain fused layers
+                   12-wave one (two 512-column halves; test hook).  6: as 1, and in the exact-f32 mode (bd_set_pointwise_mode
+                   0, which otherwise runs one kernel per op whatever this setting) every separable layer is one kernel that
+                   keeps the depthwise output in LDS (sepf32.hip: 23 % less board power and 5 % faster on one stream, 3 %
+                   slower on three - DESIGN.md 4.6 - hence not the default).  9 / 12: plain fused layers
                    on the 8-wave kernel only / with the 12-wave kernel for 512 -> 512 channels (test hook).
    Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);

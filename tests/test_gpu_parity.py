@@ -785,10 +785,11 @@ def test_persistent_kernels_at_grid_boundaries(engine, windows):
 
 @pytest.mark.parametrize("windows", [1, 3, 37, 300, 678, 1024])
 def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
-    """Exact-f32 mode (bd_set_pointwise_mode 0) with the separable layers fused (sepf32.hip: depthwise into an LDS tile, 1x1
-    convolution on v_mfma_f32_32x32x2_f32 from it, the depthwise output never in HBM) against the same mode as one kernel per
-    op (depthwise_kernel + pointwise_kernel): the same chains of IEEE operations, so logits AND embeddings agree bit for bit;
-    whole hop and half hop, partial tiles of every layer (windows x positions is not a multiple of the 64 .. 512-row tiles)."""
+    """Exact-f32 mode (bd_set_pointwise_mode 0) with the separable layers fused (bd_set_fusion separable = 6, sepf32.hip:
+    depthwise into an LDS tile, 1x1 convolution on v_mfma_f32_32x32x2_f32 from it, the depthwise output never in HBM) against
+    the same mode as one kernel per op (depthwise_kernel + pointwise_kernel, the mode's default): the same chains of IEEE
+    operations, so logits AND embeddings agree bit for bit; whole hop and half hop, partial tiles of every layer (windows x
+    positions is not a multiple of the 96 .. 512-row tiles)."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f32")
     try:
@@ -796,7 +797,9 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
         ref = engine.predict(x, 0.96).numpy()
         ref_emb = engine.embed(x, 0.96).numpy()
         ref_half = engine.predict(x[: HOP * 40], 0.48).numpy()
-        engine.set_fusion(True, True)
+        engine.set_fusion(True, True)                    # the default setting leaves this mode at one kernel per op
+        assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)
+        engine.set_fusion(True, 6)
         assert ref.shape == (windows, 13)
         assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)
         assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb)

@@ -1,5 +1,6 @@
-"""Board power and shader clock while one arithmetic mode runs for a few seconds on three streams (hwmon, as bench.py).
-GPU box.    python tools/mode_clock.py [f32|f16x3|f16] [seconds=3]"""
+"""Board power and shader clock while one arithmetic mode runs for a few seconds on three streams (hwmon, as bench.py); with a
+third argument, exact-f32 layers fused (bd_set_fusion separable = 6) and one kernel per op (the mode's default) alternate in the same process, three rounds.
+GPU box.    python tools/mode_clock.py [f32|f16x3|f16] [seconds=3] [ab]"""
 import os
 import sys
 import time
@@ -22,14 +23,28 @@ x = (torch.randn(15360 * 1023 + 15600, generator=torch.Generator().manual_seed(1
 for e in engs:
     e.predict(x, 0.96)
 torch.cuda.synchronize()
-n = 0
-with bench.PowerWatch(torch, 0) as watch:
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(30):
-            with torch.cuda.stream(streams[n % 3]):
-                engs[n % 3].predict(x, 0.96)
-            n += 1
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-print(f"mode {mode}: {n * 1024 / dt / 1e6:.3f} M windows/s on three streams; {watch.summary()}")
+
+
+def run(label):
+    n = 0
+    with bench.PowerWatch(torch, 0) as watch:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(30):
+                with torch.cuda.stream(streams[n % 3]):
+                    engs[n % 3].predict(x, 0.96)
+                n += 1
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    w = watch.summary() or {}
+    print(f"mode {mode} {label}: {n * 1024 / dt / 1e6:.3f} M windows/s on three streams; {w.get('avg_W')} W, {w.get('sclk_MHz_avg')} MHz")
+
+
+if len(sys.argv) > 3:
+    for rnd in range(3):
+        for fused in (True, False):
+            for e in engs:
+                e.set_fusion(True, 6 if fused else True)
+            run("fused" if fused else "one kernel per op")
+else:
+    run("")

@@ -1,5 +1,5 @@
 """Per-launch times of one arithmetic mode of the 1x1 convolutions (engine marker events), one 1024-window batch repeated.
-GPU box.    python tools/mode_slots.py [f32|f16x3|f16] [repeats=20]"""
+GPU box.    python tools/mode_slots.py [f32|f16x3|f16] [repeats=20] [bd_set_fusion separable code]"""
 import os
 import sys
 
@@ -13,6 +13,8 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 eng = HipEngine(device=0)
 eng.set_pointwise_mode(mode)
+if len(sys.argv) > 3:                      # e.g. 6: the exact-f32 mode fused per layer
+    eng.set_fusion(True, int(sys.argv[3]))
 x = (torch.randn(15360 * 1023 + 15600, generator=torch.Generator().manual_seed(1)) * 0.1).cuda()
 for _ in range(3):
     eng.predict(x, 0.96)
