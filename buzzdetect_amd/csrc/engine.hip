@@ -919,6 +919,20 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             last_floats = (int64_t)gw * 24 * 16 * 64;
             first_layer = 1;
             skip_dw3 = true;
+        } else if (mode == 0 && e->fuse_stem && e->fuse_stem3 && e->fuse_stem4 && !calibrating && stop_stage < 0) {
+            // exact-f32 mode: layers 1-3 as one kernel on v_mfma_f32_32x32x2_f32 (sepf32.hip), bit-identical to the five
+            // kernels it replaces (the calibration pass and the stage taps keep one kernel per op)
+            {
+                Scope sc(e, stream, 5);
+                bd::launch_stem_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+                BD_REPEAT_EXTRA(5)
+                    bd::launch_stem_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+            }
+            last = buf_a;
+            last_floats = (int64_t)gw * 24 * 16 * 128;
+            first_layer = 2;
+            f32_layers = mode == 0 && e->fuse_f32;
+            for (int l = 2; l < 13 && f32_layers; ++l) f32_layers = bd::sep_f32_ok(sep[l], gw);
         } else {
             // exact-f32 mode with fused separable layers (sepf32.hip): layer 2's output (98 304 floats per window) needs the
             // larger buffer, so conv1 writes the smaller one and the two swap roles for the pass
