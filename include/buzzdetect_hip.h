@@ -247,6 +247,7 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    writes only the depthwise output (the 402 MB layer-2 tensor never reaches HBM); profile slot 4;
    stem == 3       (default) ... and layer 3's pointwise convolution: layers 1-3 are one kernel that
                    reads log-mel patches and writes the [24][16][128] layer-3 output; profile slot 5;
+                   (in the exact-f32 mode stem != 0 selects the same fusion on v_mfma_f32_32x32x2_f32, sepf32.hip);
    separable != 0  stride-1 layers 4, 6, 8-12, 14: depthwise computed inside the pointwise GEMM, timed
                    in the layer's pointwise slot.  With 1 (default) layers 4, 6 and 12 also apply the NEXT
                    layer's stride-2 depthwise in their epilogue, so depthwise 5, 7 and 13 have no launch of
@@ -259,7 +260,7 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    8-wave kernel (four 256-column tiles on all CUs: faster alone, slower in a full pipeline) instead of the
                    12-wave one (two 512-column halves; test hook).  6: as 1, and in the exact-f32 mode (bd_set_pointwise_mode
                    0, which otherwise runs one kernel per op whatever this setting) every separable layer is one kernel that
-                   keeps the depthwise output in LDS (sepf32.hip: 23 % less board power and 5 % faster on one stream, 3 %
+                   keeps the depthwise output in LDS (sepf32.hip: 16-23 % less board power and 5 % faster on one stream, 1.5-3 %
                    slower on three - DESIGN.md 4.6 - hence not the default).  9 / 12: plain fused layers
                    on the 8-wave kernel only / with the 12-wave kernel for 512 -> 512 channels (test hook).
    Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
