@@ -499,10 +499,15 @@ void launch_fir_mfma(const void* in, bool s16, int64_t n_in, int channels, const
     // chunks grid.x apart with its share of the filter in registers
     int cus = 256;
     {
+        static int cus_of[16] = {0};                       // per device, asked once (racing first calls write the same value)
         int dev = 0;
         (void)hipGetDevice(&dev);
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        int& c = cus_of[dev & 15];
+        if (c == 0) {
+            int v = 0;
+            c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        }
+        cus = c;
     }
     const int per_cu = p.lds_bytes <= 40 * 1024 ? 3 : p.lds_bytes <= 80 * 1024 ? 2 : 1;
     int64_t gx = (int64_t)cus * per_cu / p.NB;             // (rounded down: one workgroup too many per CU is a whole extra round)

@@ -307,3 +307,36 @@ def test_config5_chain_s16_stereo_48k_in_both_f16_modes(weights_bundle):
         assert eng.overflow_reruns == 0
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate_in,channels", [(48000, 2), (44100, 1)])
+def test_an_hour_of_input_is_indexed_in_64_bits(engine, rate_in, channels):
+    """One hour of 16-bit PCM in ONE call (172.8 M frames of 48 kHz stereo: 691 MB, 57.6 M outputs; sample indices beyond 2^27,
+    byte offsets beyond 2^29): slices of the output - the start, the end, three places in between - against the oracle run
+    on the matching piece of the input with the filter's reach on either side."""
+    import torch
+    n = rate_in * 3600
+    gen = torch.Generator(device="cuda").manual_seed(rate_in)
+    q = torch.randint(-20000, 20000, (n, channels), generator=gen, device="cuda", dtype=torch.int32).to(torch.int16)
+    if channels == 1:
+        q = q[:, 0].contiguous()
+    got = engine.resample(q, rate_in)
+    up, down = RO.ratio(rate_in, 16000)
+    _, half = RO.taps(up, down)
+    n_out = -(-n * up // down)
+    assert got.shape[0] == n_out
+    reach = half // up + 2                                   # input samples either side of an output's centre
+    block = 160 * 20                                         # outputs checked per place: whole periods of either ratio
+    for j0 in (0, (n_out // 3) // block * block, (n_out // 2) // block * block, (5 * n_out // 6) // block * block, n_out - block):
+        j1 = min(j0 + block, n_out)
+        i0 = max(0, j0 * down // up - reach)
+        i0 -= i0 % down                                      # keep the piece's phase: i0 a multiple of `down` = whole outputs
+        i1 = min(n, j1 * down // up + reach + down)
+        piece = q[i0:i1].cpu().numpy().astype(np.float32) / 32768.0
+        ref = RO.resample(piece, rate_in)
+        off = i0 * up // down                                # output index of the piece's first output
+        a, b = j0 - off, j1 - off
+        assert np.abs(got[j0:j1].cpu().numpy() - ref[a:b]).max() < 5e-6, (j0, j1)
+    del q, got
+    torch.cuda.empty_cache()
