@@ -899,6 +899,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         bool skip_dw3 = false;
         int skip_dw_layer = -1;      // loop index of a layer whose depthwise the previous kernel already applied
         bool f32_layers = false;     // exact-f32 mode: every separable layer as one kernel (sepf32.hip)
+        bool f32_l4 = false;         // exact-f32 mode: layer 4 + the depthwise of layer 5 as one kernel behind the f32 stem
         if (fuse_stem3 && e->fuse_stem4) {
             {
                 Scope sc(e, stream, 5);      // timed in the slot of pointwise 3 (slots 1-4 stay empty)
@@ -931,6 +932,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             last = buf_a;
             last_floats = (int64_t)gw * 24 * 16 * 128;
             first_layer = 2;
+            f32_l4 = e->fuse_sep && e->fuse_next_dw;
             f32_layers = mode == 0 && e->fuse_f32;
             for (int l = 2; l < 13 && f32_layers; ++l) f32_layers = bd::sep_f32_ok(sep[l], gw);
         } else {
@@ -987,6 +989,16 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * L.cout;
                 continue;
             }
+            // exact-f32 mode, behind the f32 stem: layer 4 and layer 5's stride-2 depthwise as one kernel (bit-identical to the
+            // three it replaces); layer 5 then starts at its 1x1 convolution
+            if (f32_l4 && l == 2 && bd::launch_l4_f32(buf_a, buf_b, gw, L, sep[3], stream)) {
+                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_l4_f32(buf_a, buf_b, gw, L, sep[3], stream);
+                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                skip_dw_layer = 3;
+                last = buf_b;
+                last_floats = (int64_t)gw * 12 * 8 * 128;
+                continue;
+            }
             if (e->fuse_sep && e->fuse_run && mode != 0 && e->sep_variant <= 1 && stop_stage < 0 && skip_dw_layer != l) {
                 const int ran = bd::launch_separable_run(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
                 if (ran > 0) {
@@ -1017,7 +1029,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // exact-f32 mode: depthwise + 1x1 convolution of the layer as one kernel, the depthwise output never leaves the CU
             // (the calibration pass and the stage taps keep one kernel per op: they look at the depthwise output)
-            if (f32_layers && bd::launch_sep_f32(buf_a, buf_b, gw, L, stream)) {
+            if (f32_layers && skip_dw_layer != l && bd::launch_sep_f32(buf_a, buf_b, gw, L, stream)) {
                 BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_sep_f32(buf_a, buf_b, gw, L, stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 float* t = buf_a;

@@ -797,8 +797,13 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
         ref = engine.predict(x, 0.96).numpy()
         ref_emb = engine.embed(x, 0.96).numpy()
         ref_half = engine.predict(x[: HOP * 40], 0.48).numpy()
-        engine.set_fusion(True, True)                    # the default setting leaves this mode at one kernel per op
-        assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)
+        # the default: layers 1-3 as stem3_f32_kernel, layer 4 + depthwise 5 as l4_f32_kernel, the rest one kernel per op;
+        # 9 = the stem alone; 6 = layers 4-14 as one kernel each
+        for code in (True, 9):
+            engine.set_fusion(True, code)
+            assert np.array_equal(engine.predict(x, 0.96).numpy(), ref), code
+            assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), code
+            assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half), code
         engine.set_fusion(True, 6)
         assert ref.shape == (windows, 13)
         assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)

@@ -1,6 +1,7 @@
 """Board power and shader clock while one arithmetic mode runs for a few seconds on three streams (hwmon, as bench.py); with a
-third argument, exact-f32 layers fused (bd_set_fusion separable = 6) and one kernel per op (the mode's default) alternate in the same process, three rounds.
-GPU box.    python tools/mode_clock.py [f32|f16x3|f16] [seconds=3] [ab]"""
+third argument, two fusion layouts alternate in the same process, three rounds: `ab` = exact-f32 layers 4-14 fused (bd_set_fusion
+separable = 6) against the default; a number = that separable code against the default (9: exact-f32 without the layer-4 kernel).
+GPU box.    python tools/mode_clock.py [f32|f16x3|f16] [seconds=3] [ab|code]"""
 import os
 import sys
 import time
@@ -41,10 +42,11 @@ def run(label):
 
 
 if len(sys.argv) > 3:
+    other = 6 if sys.argv[3] == "ab" else int(sys.argv[3])
     for rnd in range(3):
-        for fused in (True, False):
+        for code in (other, 1):
             for e in engs:
-                e.set_fusion(True, 6 if fused else True)
-            run("fused" if fused else "one kernel per op")
+                e.set_fusion(True, code)
+            run(f"separable fusion {code}")
 else:
     run("")
