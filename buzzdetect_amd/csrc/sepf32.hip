@@ -286,42 +286,64 @@ __global__ __launch_bounds__(256, 3) void stem3_f32_kernel(const float* __restri
 }
 
 // Layer 4 (128 -> 128 on the 24 x 16 map) + the stride-2 depthwise of layer 5 in exact f32 as ONE kernel, in the manner of
-// the stem: a workgroup owns two output rows of depthwise 5 in one window; they need five layer-4 rows (one is shared with
-// the neighbouring workgroup and computed twice; 80 positions, padded to three 32-row matrix tiles) and seven input rows.
-// The 128 input channels go through in four chunks of 32 so that three workgroups fit a CU (42 KB of LDS each):
-//   per chunk   input band [7][18][32] (zero halo columns, zero rows outside the map) -> LDS
-//               depthwise 4 of the 80 positions -> f32 A tile [96][32] (16-byte chunks XORed with (row >> 1) & 7)
-//               v_mfma_f32_32x32x2_f32, weights as the A operand (lane = position in the accumulators), k ascending
+// the stem: a tile is two output rows of depthwise 5 in one window; they need five layer-4 rows (one is shared with the
+// neighbouring tile and computed twice; 80 positions, padded to three 32-row matrix tiles) and seven input rows.
+// Persistent workgroups (two per CU, 67 KB of LDS each) walk the 6 x windows tiles.  The 128 input channels go through in
+// four chunks of 32, software-pipelined with ONE barrier per chunk (two band buffers, two A buffers):
+//   chunk k     v_mfma_f32_32x32x2_f32 on A buffer k & 1, weights as the A operand (lane = position in the accumulators),
+//               k ascending; then depthwise 4 of chunk k + 1: band buffer -> f32 A tile [96][32] (16-byte chunks XORed with
+//               (row >> 1) & 7); the band [7][18][32] of chunk k + 2 (zero halo columns, zero rows outside the map) is in
+//               flight from HBM into registers meanwhile - for the last two chunks that is the NEXT tile's first band
 //   then        bias + ReLU -> f32 tile P[80][132] (rows past the map are depthwise 5's zero padding), depthwise 5 on P -> HBM
-// The chain of IEEE operations per element is that of depthwise_kernel, pointwise_kernel, depthwise_kernel: bit-identical
-// to the three kernels it replaces (316 us per 1024 windows), whose two intermediate tensors (201 MB each) never exist.
-__global__ __launch_bounds__(256, 3) void l4_f32_kernel(const float* __restrict__ X, const float* __restrict__ dw4_w,
+// Both depthwise layers' taps sit in LDS for the life of the workgroup.  The chain of IEEE operations per element is that
+// of depthwise_kernel, pointwise_kernel, depthwise_kernel: bit-identical to the three kernels it replaces (316 us per 1024
+// windows -> 227 us), whose two intermediate tensors (201 MB each) never exist.  The matrix pipe is busy 55 % of the time
+// (1.5 x the layer's MFMAs: 96 rows for 64 new positions): what is left is the phases of a tile that no other wave covers
+// at two waves per SIMD.
+__global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict__ X, const float* __restrict__ dw4_w,
                                                         const float* __restrict__ dw4_b, const float* __restrict__ W4,
                                                         const float* __restrict__ pw4_b, const float* __restrict__ dw5_w,
                                                         const float* __restrict__ dw5_b, float* __restrict__ out, int windows) {
     constexpr int H = 24, W = 16, C = 128, R4 = 5, NPOS = R4 * W;   // 80 positions
     constexpr int KC = 32, PW = C + 4;
-    constexpr int OFF_BAND = 0;                                     // [7][18][32] f32
-    constexpr int OFF_A = 7 * 18 * KC * 4;                          // 16128: [96][32] f32
+    constexpr int BAND_BYTES = 7 * 18 * KC * 4, A_BYTES = 96 * KC * 4;   // 16128, 12288; two of each (chunk k + 1 is prepared
+    constexpr int OFF_BAND = 0, OFF_A = 2 * BAND_BYTES;                  // while chunk k is multiplied)
     constexpr int P_BYTES = NPOS * PW * 4;                          // 42240, aliases from 0 after the product
-    constexpr int LDS_BYTES = P_BYTES > OFF_A + 96 * KC * 4 ? P_BYTES : OFF_A + 96 * KC * 4;
+    constexpr int LDS_BYTES = P_BYTES > OFF_A + 2 * A_BYTES ? P_BYTES : OFF_A + 2 * A_BYTES;
     constexpr int OFF_TAPS = LDS_BYTES;                             // both depthwise layers' taps and shifts: [10][128] f32 each
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 2 * 10 * C * 4];
-    float (*s_x)[18][KC] = reinterpret_cast<float (*)[18][KC]>(smem + OFF_BAND);
-    char* const s_a = smem + OFF_A;
     float* const P = reinterpret_cast<float*>(smem);
     float* const s_t4 = reinterpret_cast<float*>(smem + OFF_TAPS);  // rows 0 .. 8 the taps, row 9 the shift
     float* const s_t5 = s_t4 + 10 * C;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 10 * C / 4; i += 256) {
-        reinterpret_cast<float4*>(s_t4)[i] = i < 9 * C / 4 ? reinterpret_cast<const float4*>(dw4_w)[i] : reinterpret_cast<const float4*>(dw4_b)[i - 9 * C / 4];
-        reinterpret_cast<float4*>(s_t5)[i] = i < 9 * C / 4 ? reinterpret_cast<const float4*>(dw5_w)[i] : reinterpret_cast<const float4*>(dw5_b)[i - 9 * C / 4];
-    }
-    // workgroups go to the XCDs round-robin by ID: the six bands of a window share input rows, so they go to ONE XCD (one L2)
-    int win, ob;                                        // depthwise-5 rows 2 ob, 2 ob + 1
     {
-        const int id = blockIdx.x, full = (windows >> 3) * 48;
+        // 320 float4 per table: every thread one, the first wave a second one; every load first, then the LDS writes
+        auto src4 = [&](int i) { return i < 9 * C / 4 ? reinterpret_cast<const float4*>(dw4_w)[i] : reinterpret_cast<const float4*>(dw4_b)[i - 9 * C / 4]; };
+        auto src5 = [&](int i) { return i < 9 * C / 4 ? reinterpret_cast<const float4*>(dw5_w)[i] : reinterpret_cast<const float4*>(dw5_b)[i - 9 * C / 4]; };
+        const float4 t4a = src4(tid), t5a = src5(tid);
+        float4 t4b = t4a, t5b = t5a;
+        if (tid < 64) {
+            t4b = src4(tid + 256);
+            t5b = src5(tid + 256);
+        }
+        reinterpret_cast<float4*>(s_t4)[tid] = t4a;
+        reinterpret_cast<float4*>(s_t5)[tid] = t5a;
+        if (tid < 64) {
+            reinterpret_cast<float4*>(s_t4)[tid + 256] = t4b;
+            reinterpret_cast<float4*>(s_t5)[tid + 256] = t5b;
+        }
+    }
+    const int frow = lane & 31, fh = lane >> 5;
+    // this lane's layer-4 weights: output channel 32 wave + frow, k = 8 s + 4 fh .. + 3 (64 KB in all: they stay in L2 and are
+    // fetched per chunk, 16 registers instead of 64)
+    const float* const w4row = W4 + (size_t)(32 * wave + frow) * C + 4 * fh;
+    const int c4 = tid & 7, pcol = (tid >> 3) & 15, phalf = tid >> 7;     // depthwise 4: channel quad, map column, row parity
+    const int total = 6 * windows;
+    // Tile id -> (window, band).  Workgroups go to the XCDs round-robin by ID and the grid is a multiple of 8, so tile t runs
+    // on XCD t & 7: the six bands of a window share input rows and go to ONE XCD (one L2).
+    auto tile_of = [&](int id, int& win, int& ob) {
+        const int full = (windows >> 3) * 48;
         if (id < full) {
             const int idx = id >> 3;
             win = (idx / 6) * 8 + (id & 7);
@@ -330,155 +352,175 @@ __global__ __launch_bounds__(256, 3) void l4_f32_kernel(const float* __restrict_
             win = (windows >> 3) * 8 + (id - full) / 6;
             ob = (id - full) % 6;
         }
-    }
-    const int r0 = 4 * ob;                              // first layer-4 row of the tile
-    const int frow = lane & 31, fh = lane >> 5;
-    const float* const xin = X + (size_t)win * H * W * C;
-
-    // this lane's layer-4 weights: output channel 32 wave + frow, k = 8 s + 4 fh .. + 3 (64 KB in all: they stay in L2 and are
-    // fetched per chunk, 16 registers instead of 64)
-    const float* const w4row = W4 + (size_t)(32 * wave + frow) * C + 4 * fh;
-    f32x16 acc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    const int c4 = tid & 7, pcol = (tid >> 3) & 15, phalf = tid >> 7;     // depthwise 4: channel quad, map column, row parity
-    // the band of a chunk is fetched into registers one chunk ahead (in flight behind the depthwise and the product)
+    };
+    // the band of a chunk is fetched into registers ahead of its use (in flight behind the depthwise and the product; the
+    // first band of the NEXT tile behind this tile's last chunks and epilogue)
     float4 band[4];
-    auto fetch_band = [&](int kc) {
+    auto fetch_band = [&](int win, int ob, int kc) {
+        const float* const xin = X + (size_t)win * H * W * C;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u;
             const int cc = i & 7, pos = i >> 3;
             const int row = pos / 18, col = pos - row * 18;
-            const int ih = r0 - 1 + row, iw = col - 1;
+            const int ih = 4 * ob - 1 + row, iw = col - 1;
             band[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < 7 * 18 * 8 && ih >= 0 && ih < H && iw >= 0 && iw < W)
                 band[u] = *reinterpret_cast<const float4*>(xin + ((size_t)ih * W + iw) * C + kc * KC + cc * 4);
         }
     };
-    fetch_band(0);
-#pragma unroll 1
-    for (int kc = 0; kc < C / KC; ++kc) {
-        v4f w4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const v4f*>(w4row + kc * KC + 8 * q);
-        __syncthreads();                                // the previous chunk's tiles have been read
-        // ---- input rows r0 - 1 .. r0 + 5, columns -1 .. 16, channels 32 kc .. (zeros outside the map) ----
+    auto put_band = [&](int kc) {                       // registers -> band buffer kc & 1
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u;
-            if (i < 7 * 18 * 8) *reinterpret_cast<float4*>(reinterpret_cast<float*>(smem + OFF_BAND) + i * 4) = band[u];
+            if (i < 7 * 18 * 8) *reinterpret_cast<float4*>(smem + OFF_BAND + (kc & 1) * BAND_BYTES + i * 16) = band[u];
         }
-        __syncthreads();
-        if (kc + 1 < C / KC) fetch_band(kc + 1);
-        // ---- depthwise 4 (depthwise_kernel's chain: shift, then the taps in (kh, kw) order, zeros outside the map) ----
-        {
-            v4f a[3];
-            a[0] = a[1] = a[2] = *reinterpret_cast<const v4f*>(s_t4 + 9 * C + kc * KC + c4 * 4);
+    };
+    // depthwise 4 of chunk kc (depthwise_kernel's chain: shift, then the taps in (kh, kw) order, zeros outside the map):
+    // band buffer kc & 1 -> A buffer kc & 1
+    auto depthwise4 = [&](int kc) {
+        const float (*s_x)[18][KC] = reinterpret_cast<const float (*)[18][KC]>(smem + OFF_BAND + (kc & 1) * BAND_BYTES);
+        char* const s_a = smem + OFF_A + (kc & 1) * A_BYTES;
+        v4f a[3];
+        a[0] = a[1] = a[2] = *reinterpret_cast<const v4f*>(s_t4 + 9 * C + kc * KC + c4 * 4);
 #pragma unroll 1
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const v4f wt = *reinterpret_cast<const v4f*>(s_t4 + (kh * 3 + kw) * C + kc * KC + c4 * 4);
-#pragma unroll
-                    for (int it = 0; it < 3; ++it) {
-                        const int r = 2 * it + phalf;   // layer-4 row within the tile: 0, 2, 4 / 1, 3 (row 5 is a dummy)
-                        a[it] = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(&s_x[r < R4 ? r + kh : kh][pcol + kw][c4 * 4]), wt, a[it]);
-                    }
-                }
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int r = 2 * it + phalf;
-                if (r < R4) {
-                    v4f v = a[it];
-                    v.x = fmaxf(v.x, 0.0f);
-                    v.y = fmaxf(v.y, 0.0f);
-                    v.z = fmaxf(v.z, 0.0f);
-                    v.w = fmaxf(v.w, 0.0f);
-                    const int row = r * W + pcol;
-                    *reinterpret_cast<v4f*>(s_a + row * 128 + ((c4 ^ ((row >> 1) & 7)) << 4)) = v;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- [96][32] x [32][128]: wave w = output channels 32 w .., three row tiles (positions 80 .. 95 are not used) ----
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int row = i * 32 + frow;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4f a4 = *reinterpret_cast<const v4f*>(s_a + row * 128 + (((2 * q + fh) ^ ((row >> 1) & 7)) << 4));
-                const v4f ww = w4[q];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.x, a4.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.y, a4.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.z, a4.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w, a4.w, acc[i], 0, 0, 0);
-            }
-        }
-    }
-    __syncthreads();   // every wave is done with the band and the A tile: P may overwrite them
-
-    // ---- bias + ReLU -> P (transposed accumulators: lane = position 32 i + frow, registers 4 g .. 4 g + 3 = channels
-    //      32 wave + 8 g + 4 fh + (0..3)); layer-4 rows past row 23 are depthwise 5's zero padding ----
-    {
-        v4f b4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const v4f*>(pw4_b + 32 * wave + 8 * g + 4 * fh);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int pos = i * 32 + frow;
-            if (pos < NPOS) {
-                const bool live = r0 + pos / W < H;
-                float* prow = P + pos * PW + 32 * wave + 4 * fh;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    v4f v = {0.f, 0.f, 0.f, 0.f};
-                    if (live) {
-                        v.x = fmaxf(acc[i][4 * g + 0] + b4[g].x, 0.0f);
-                        v.y = fmaxf(acc[i][4 * g + 1] + b4[g].y, 0.0f);
-                        v.z = fmaxf(acc[i][4 * g + 2] + b4[g].z, 0.0f);
-                        v.w = fmaxf(acc[i][4 * g + 3] + b4[g].w, 0.0f);
-                    }
-                    *reinterpret_cast<v4f*>(prow + 8 * g) = v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- depthwise 5, stride 2 (SAME: pad 0 before, 1 after): out[o][ow][c] from P rows 2 o + kh, columns 2 ow + kw ----
-    const int c32 = tid & 31, ow = tid >> 5;            // 8 output columns x 32 channel quads; o = it
-    v4f d5[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) d5[t] = *reinterpret_cast<const v4f*>(s_t5 + t * C + c32 * 4);
-    const v4f d5b = *reinterpret_cast<const v4f*>(s_t5 + 9 * C + c32 * 4);
-    const bool right_edge = ow == 7;                    // the tap right of column 15 is the zero padding
-    float* dst = out + (((size_t)win * 12 + 2 * ob) * 8) * C;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int o = it;
-        v4f a = d5b;
-#pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int col = 2 * ow + kw;
-                v4f v = *reinterpret_cast<const v4f*>(P + ((2 * o + kh) * W + (col < W ? col : W - 1)) * PW + c32 * 4);
-                if (kw == 2) {
-                    v.x = right_edge ? 0.0f : v.x;
-                    v.y = right_edge ? 0.0f : v.y;
-                    v.z = right_edge ? 0.0f : v.z;
-                    v.w = right_edge ? 0.0f : v.w;
+                const v4f wt = *reinterpret_cast<const v4f*>(s_t4 + (kh * 3 + kw) * C + kc * KC + c4 * 4);
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int r = 2 * it + phalf;       // layer-4 row within the tile: 0, 2, 4 / 1, 3 (row 5 is a dummy)
+                    a[it] = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(&s_x[r < R4 ? r + kh : kh][pcol + kw][c4 * 4]), wt, a[it]);
                 }
-                a = __builtin_elementwise_fma(v, d5[kh * 3 + kw], a);
             }
-        a.x = fmaxf(a.x, 0.0f);
-        a.y = fmaxf(a.y, 0.0f);
-        a.z = fmaxf(a.z, 0.0f);
-        a.w = fmaxf(a.w, 0.0f);
-        *reinterpret_cast<v4f*>(dst + ((size_t)o * 8 + ow) * C + c32 * 4) = a;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int r = 2 * it + phalf;
+            if (r < R4) {
+                v4f v = a[it];
+                v.x = fmaxf(v.x, 0.0f);
+                v.y = fmaxf(v.y, 0.0f);
+                v.z = fmaxf(v.z, 0.0f);
+                v.w = fmaxf(v.w, 0.0f);
+                const int row = r * W + pcol;
+                *reinterpret_cast<v4f*>(s_a + row * 128 + ((c4 ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+        }
+    };
+    int tile = blockIdx.x, win = 0, ob = 0;
+    if (tile < total) {
+        tile_of(tile, win, ob);
+        fetch_band(win, ob, 0);
+    }
+#pragma unroll 1
+    for (; tile < total; tile += gridDim.x) {           // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...
+        const int r0 = 4 * ob;                          // first layer-4 row of the tile
+        f32x16 acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        __syncthreads();                                // the previous tile's P has been read (first tile: nothing)
+        put_band(0);
+        fetch_band(win, ob, 1);
+        __syncthreads();                                // band 0 (and, the first time, the taps) are in LDS
+        depthwise4(0);
+        int nwin = 0, nob = 0;
+        const bool more = tile + (int)gridDim.x < total;
+        if (more) tile_of(tile + gridDim.x, nwin, nob);
+#pragma unroll 1
+        for (int kc = 0; kc < C / KC; ++kc) {
+            v4f w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const v4f*>(w4row + kc * KC + 8 * q);
+            if (kc + 1 < C / KC) put_band(kc + 1);      // its buffer was last read two chunks ago
+            __syncthreads();                            // A tile kc and band kc + 1 are complete; A tile kc - 1 has been read
+            if (kc + 2 < C / KC) fetch_band(win, ob, kc + 2);
+            else if (kc + 2 == C / KC && more) fetch_band(nwin, nob, 0);      // stays in registers through the epilogue
+            // ---- [96][32] x [32][128]: wave w = output channels 32 w .., three row tiles (positions 80 .. 95 are not used) ----
+            const char* const s_a = smem + OFF_A + (kc & 1) * A_BYTES;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int row = i * 32 + frow;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4f a4 = *reinterpret_cast<const v4f*>(s_a + row * 128 + (((2 * q + fh) ^ ((row >> 1) & 7)) << 4));
+                    const v4f ww = w4[q];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.x, a4.x, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.y, a4.y, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.z, a4.z, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w, a4.w, acc[i], 0, 0, 0);
+                }
+            }
+            if (kc + 1 < C / KC) depthwise4(kc + 1);
+        }
+        __syncthreads();   // every wave is done with the band and the A tile: P may overwrite them
+
+        // ---- bias + ReLU -> P (transposed accumulators: lane = position 32 i + frow, registers 4 g .. 4 g + 3 = channels
+        //      32 wave + 8 g + 4 fh + (0..3)); layer-4 rows past row 23 are depthwise 5's zero padding ----
+        {
+            v4f b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const v4f*>(pw4_b + 32 * wave + 8 * g + 4 * fh);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pos = i * 32 + frow;
+                if (pos < NPOS) {
+                    const bool live = r0 + pos / W < H;
+                    float* prow = P + pos * PW + 32 * wave + 4 * fh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        v4f v = {0.f, 0.f, 0.f, 0.f};
+                        if (live) {
+                            v.x = fmaxf(acc[i][4 * g + 0] + b4[g].x, 0.0f);
+                            v.y = fmaxf(acc[i][4 * g + 1] + b4[g].y, 0.0f);
+                            v.z = fmaxf(acc[i][4 * g + 2] + b4[g].z, 0.0f);
+                            v.w = fmaxf(acc[i][4 * g + 3] + b4[g].w, 0.0f);
+                        }
+                        *reinterpret_cast<v4f*>(prow + 8 * g) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- depthwise 5, stride 2 (SAME: pad 0 before, 1 after): out[o][ow][c] from P rows 2 o + kh, columns 2 ow + kw ----
+        {
+            const int c32 = tid & 31, ow = tid >> 5;    // 8 output columns x 32 channel quads; o = it
+            const bool right_edge = ow == 7;            // the tap right of column 15 is the zero padding
+            float* dst = out + (((size_t)win * 12 + 2 * ob) * 8) * C;
+            v4f a[2];
+            a[0] = a[1] = *reinterpret_cast<const v4f*>(s_t5 + 9 * C + c32 * 4);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const v4f wt = *reinterpret_cast<const v4f*>(s_t5 + (kh * 3 + kw) * C + c32 * 4);
+                    const int col = 2 * ow + kw;
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        v4f v = *reinterpret_cast<const v4f*>(P + ((2 * o + kh) * W + (col < W ? col : W - 1)) * PW + c32 * 4);
+                        if (kw == 2) {
+                            v.x = right_edge ? 0.0f : v.x;
+                            v.y = right_edge ? 0.0f : v.y;
+                            v.z = right_edge ? 0.0f : v.z;
+                            v.w = right_edge ? 0.0f : v.w;
+                        }
+                        a[o] = __builtin_elementwise_fma(v, wt, a[o]);
+                    }
+                }
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                v4f v = a[o];
+                v.x = fmaxf(v.x, 0.0f);
+                v.y = fmaxf(v.y, 0.0f);
+                v.z = fmaxf(v.z, 0.0f);
+                v.w = fmaxf(v.w, 0.0f);
+                *reinterpret_cast<v4f*>(dst + ((size_t)o * 8 + ow) * C + c32 * 4) = v;
+            }
+        }
+        win = nwin;
+        ob = nob;
     }
 }
 
@@ -724,8 +766,20 @@ bool launch_l4_f32(const float* in, float* out, int windows, const SepLayer& L4,
     if (windows <= 0) return true;
     if (L4.cin != 128 || L4.cout != 128 || L4.h_in != 24 || L4.w_in != 16 || L4.stride != 1 || L5.cin != 128 || L5.stride != 2)
         return false;
-    hipLaunchKernelGGL(l4_f32_kernel, dim3(6 * windows), dim3(256), 0, stream, in, L4.dw_w, L4.dw_b, L4.pw_wt, L4.pw_b, L5.dw_w,
-                       L5.dw_b, out, windows);
+    // persistent: two workgroups per CU (67 KB of LDS each) walk the 6 x windows tiles; a multiple of 8 for the XCD mapping
+    static int cus_of[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && cus_of[dev] == 0) {
+        int v = 0;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_of[dev] = v > 0 ? v : 256;
+    }
+    const int cus = dev >= 0 && dev < 16 ? cus_of[dev] : 256;
+    int grid = 2 * cus / 8 * 8;
+    if (grid > 6 * windows) grid = (6 * windows + 7) / 8 * 8;
+    hipLaunchKernelGGL(l4_f32_kernel, dim3(grid), dim3(256), 0, stream, in, L4.dw_w, L4.dw_b, L4.pw_wt, L4.pw_b, L5.dw_w, L5.dw_b,
+                       out, windows);
     return true;
 }
 

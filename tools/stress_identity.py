@@ -3,7 +3,7 @@ logits the same batch gave on an idle GPU (bit for bit).  The fused kernels over
 layers inside one launch; this looks for an ordering mistake that only shows under load.  One mismatch counter per stream
 (a shared one is a non-atomic read-modify-write from several streams and can lose a count), side streams ordered behind
 the set-up, and a negative control first: one reference row corrupted must be reported for exactly the batches that use it.
-GPU box.    python tools/stress_identity.py [streams=3] [seconds=30] [separable fusion code, default 1]"""
+GPU box.    python tools/stress_identity.py [streams=3] [seconds=30] [separable fusion code, default 1] [f16x3|f32|f16]"""
 import os
 import sys
 import time
@@ -17,12 +17,15 @@ from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
 n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
 separable = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+mode = sys.argv[4] if len(sys.argv) > 4 else "f16x3"
 dev = torch.device("cuda", 0)
 engs = [HipEngine(device=0) for _ in range(n_streams)]
 if separable != 1:
     from buzzdetect_amd import _lib
     for e in engs:
         _lib.check(e._lib.bd_set_fusion(e._handle, 3, separable))
+for e in engs:
+    e.set_pointwise_mode(mode)
 streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
 hop, step = hop_samples(0.96), patch_step(0.96)
 N = 57_600_000
@@ -76,5 +79,5 @@ if wrong != expect:
     sys.exit(2)
 batches, wrong, dt = run(ref, seconds)
 print(f"{batches} batches on {n_streams} streams in {dt:.1f} s ({batches * 937.5 / dt / 1e6:.2f} M windows/s incl. the comparisons), "
-      f"separable fusion {separable}: {wrong} batches differ from their idle-GPU result")
+      f"mode {mode}, separable fusion {separable}: {wrong} batches differ from their idle-GPU result")
 sys.exit(1 if wrong else 0)
