@@ -1,7 +1,7 @@
 """Board power and shader clock while one arithmetic mode runs for a few seconds on three streams (hwmon, as bench.py); with a
 third argument, two fusion layouts alternate in the same process, three rounds: `ab` = exact-f32 layers 4-14 fused (bd_set_fusion
 separable = 6) against the default; a number = that separable code against the default (9: exact-f32 without the layer-4 kernel).
-GPU box.    python tools/mode_clock.py [f32|f16x3|f16] [seconds=3] [ab|code]"""
+GPU box.    python tools/mode_clock.py [f32|f16x3|f16] [seconds=3] [ab|code|-] [streams=3]"""
 import os
 import sys
 import time
@@ -16,7 +16,8 @@ from buzzdetect_amd.engine import HipEngine  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
-engs = [HipEngine(device=0) for _ in range(3)]
+NS = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+engs = [HipEngine(device=0) for _ in range(NS)]
 streams = [torch.cuda.Stream() for _ in engs]
 for e in engs:
     e.set_pointwise_mode(mode)
@@ -32,16 +33,16 @@ def run(label):
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:
             for _ in range(30):
-                with torch.cuda.stream(streams[n % 3]):
-                    engs[n % 3].predict(x, 0.96)
+                with torch.cuda.stream(streams[n % NS]):
+                    engs[n % NS].predict(x, 0.96)
                 n += 1
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     w = watch.summary() or {}
-    print(f"mode {mode} {label}: {n * 1024 / dt / 1e6:.3f} M windows/s on three streams; {w.get('avg_W')} W, {w.get('sclk_MHz_avg')} MHz")
+    print(f"mode {mode} {label}: {n * 1024 / dt / 1e6:.3f} M windows/s on {NS} streams; {w.get('avg_W')} W, {w.get('sclk_MHz_avg')} MHz")
 
 
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[3] != "-":
     other = 6 if sys.argv[3] == "ab" else int(sys.argv[3])
     for rnd in range(3):
         for code in (other, 1):
