@@ -86,6 +86,19 @@ struct SepLayer {
     unsigned* amax;      // calibration pass only: device word that takes max |depthwise output| (as float bits); else null
 };
 
+// compute units of the current device (asked once per device; racing first calls write the same value)
+inline int cu_count() {
+    static int cus_of[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& c = cus_of[dev & 63];
+    if (c == 0) {
+        int v = 0;
+        c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return c;
+}
+
 // taps / shift of the depthwise that feeds L's pointwise convolution, for the arithmetic mode L runs in
 inline const float* dw_w_of(const SepLayer& L) { return L.pw_mode != 0 ? L.dw_w16 : L.dw_w; }
 inline const float* dw_b_of(const SepLayer& L) { return L.pw_mode != 0 ? L.dw_b16 : L.dw_b; }

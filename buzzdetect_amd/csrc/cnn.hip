@@ -207,15 +207,28 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict
 // B[k = l >> 5][j = l & 31]; which k a step covers is free as long as both operands agree, so
 // lane-half h takes k = 8*s + 4*h + j for the j-th MFMA of super-step s (one b128 per operand).
 // Rows past M are loaded from row M-1 (always in bounds) and never stored.
+#ifndef BD_PW_ABLATE
+#define BD_PW_ABLATE 0      // developer builds: 1 = no global loads in the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = no stores
+#endif
 constexpr int kBK = 32;
-constexpr int kLds = kBK + 4;   // row stride in floats: 144 B = odd multiple of 16 B -> conflict-free b128
+constexpr int kLds = kBK + 4;
+// an operand fragment from LDS (developer build 2: a register value instead; by value, so that no address escapes)
+typedef float pw4 __attribute__((ext_vector_type(4)));   // native vectors: SSA values, nothing for the compiler to keep in memory
+// operand pointers that are re-pointed inside the tile loop: the address space is lost through the loop's phi nodes and the
+// loads become flat_load (counted in lgkmcnt too: every LDS wait then waits for them) unless it is spelled out
+typedef const __attribute__((address_space(1))) float* pw_gptr;
+typedef const __attribute__((address_space(1))) pw4* pw_gptr4;
+__device__ __forceinline__ pw4 pw_frag(const float* p, pw4 instead) {
+    if (BD_PW_ABLATE & 2) return instead;
+    return *reinterpret_cast<const pw4*>(p);
+}   // row stride in floats: 144 B = odd multiple of 16 B -> conflict-free b128
 
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* __restrict__ A,
                                                                   const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ C, long long M, int N,
-                                                                  int K, int tiles_n) {
+                                                                  int K, int tiles_n, long long tiles, int xcd_map) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -230,26 +243,54 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* _
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave / WGN, wc = wave % WGN;
-    // consecutive workgroups walk the n-tiles of one m-tile: they share the A rows through L2
-    const long long tile_m = blockIdx.x / tiles_n;
-    const int tile_n = blockIdx.x % tiles_n;
-    const long long m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
-
     const int lrow = tid >> 3;   // 0 .. RPP-1
     const int lc4 = tid & 7;     // float4 column within the 32-wide k slab
-
-    const float* ap[LA];
-    const float* bp[LB];
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        long long m = m0 + lrow + RPP * i;
-        m = m < M ? m : M - 1;
-        ap[i] = A + (size_t)m * K + lc4 * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) bp[i] = Wt + (size_t)(n0 + lrow + RPP * i) * K + lc4 * 4;
     const int st_off = lrow * kLds + lc4 * 4;
+    const int frow = lane & 31;
+    const int fk = (lane >> 5) * 4;
+    const int half = lane >> 5;
+    const float* const a_frag = As + (wr * WM + frow) * kLds + fk;
+    const float* const b_frag = Bs + (wc * WN + frow) * kLds + fk;
+
+    // Persistent workgroups walk tiles blockIdx.x, + gridDim.x, ... as ONE stream of K stages: the first stage of the next
+    // tile is loaded behind the last product of this one, and this tile's stores drain behind the next tile's products (a
+    // workgroup that ends on its stores holds its CU share until they retire: 14 of 124 us on a 512 -> 512 layer).
+    // Tile order: the n-tiles of one m-tile are neighbours; with xcd_map (m-tiles a multiple of 8) they sit on ONE XCD
+    // (workgroups go to the XCDs round-robin by ID and the grid is a multiple of 8), so the A rows they share come from one L2.
+#define BD_PW_ORIGIN(T_, M0_, N0_)                                                   \
+    {                                                                                \
+        long long tile_m_;                                                           \
+        int tile_n_;                                                                 \
+        if (xcd_map) {                                                               \
+            const long long idx_ = (T_) >> 3;                                        \
+            tile_n_ = (int)(idx_ % tiles_n);                                         \
+            tile_m_ = (idx_ / tiles_n) * 8 + ((T_) & 7);                             \
+        } else {                                                                     \
+            tile_m_ = (T_) / tiles_n;                                                \
+            tile_n_ = (int)((T_) % tiles_n);                                         \
+        }                                                                            \
+        M0_ = tile_m_ * BM;                                                          \
+        N0_ = tile_n_ * BN;                                                          \
+    }
+    // rows past M are loaded from row M-1 (always in bounds) and never stored
+#define BD_PW_POINT(M0_, N0_)                                                        \
+    {                                                                                \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                             \
+            long long m_ = (M0_) + lrow + RPP * i;                                   \
+            m_ = m_ < M ? m_ : M - 1;                                                \
+            ap[i] = (pw_gptr)A + (size_t)m_ * K + lc4 * 4;                           \
+        }                                                                            \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) bp[i] = (pw_gptr)Wt + (size_t)((N0_) + lrow + RPP * i) * K + lc4 * 4; \
+    }
+    pw_gptr ap[LA];
+    pw_gptr bp[LB];
+
+    long long t = blockIdx.x;
+    if (t >= tiles) return;
+    long long m0;
+    int n0;
+    BD_PW_ORIGIN(t, m0, n0)
+    BD_PW_POINT(m0, n0)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -259,32 +300,29 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float4 ra[LA], rb[LB];
+    pw4 ra[LA], rb[LB];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i]);
+    for (int i = 0; i < LA; ++i) ra[i] = *(pw_gptr4)(ap[i]);
 #pragma unroll
-    for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i]);
+    for (int i = 0; i < LB; ++i) rb[i] = *(pw_gptr4)(bp[i]);
 #pragma unroll
-    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(As + st_off + RPP * i * kLds) = ra[i];
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<pw4*>(As + st_off + RPP * i * kLds) = ra[i];
 #pragma unroll
-    for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(Bs + st_off + RPP * i * kLds) = rb[i];
+    for (int i = 0; i < LB; ++i) *reinterpret_cast<pw4*>(Bs + st_off + RPP * i * kLds) = rb[i];
     __syncthreads();
-
-    const int frow = lane & 31;
-    const int fk = (lane >> 5) * 4;
-    const float* const a_frag = As + (wr * WM + frow) * kLds + fk;
-    const float* const b_frag = Bs + (wc * WN + frow) * kLds + fk;
 
 #define BD_PW_COMPUTE(BUF)                                                                              \
     {                                                                                                   \
         const float* as_ = a_frag + (BUF) * BM * kLds;                                                  \
         const float* bs_ = b_frag + (BUF) * BN * kLds;                                                  \
         _Pragma("unroll") for (int s = 0; s < kBK / 8; ++s) {                                           \
-            float4 av[TM], bv[TN];                                                                      \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) av[i] =                                      \
-                *reinterpret_cast<const float4*>(as_ + i * 32 * kLds + s * 8);                          \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[j] =                                      \
-                *reinterpret_cast<const float4*>(bs_ + j * 32 * kLds + s * 8);                          \
+            pw4 av[TM], bv[TN];                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) av[i] = pw_frag(as_ + i * 32 * kLds + s * 8, ra[0]); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[j] = pw_frag(bs_ + j * 32 * kLds + s * 8, rb[0]); \
+            if (BD_PW_ABLATE & 4) {                                                                     \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+                    acc[i][j][s] += av[i].x * bv[j].y;                                                  \
+            } else                                                                                      \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0); \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0); \
@@ -295,41 +333,78 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* _
     }
 
     const int nk = K / kBK;
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        const int buf = kt & 1;
-        const int koff = (kt + 1) * kBK;
+    int buf = 0;
+    for (;;) {
+        const long long tn = t + gridDim.x;
+        const bool more = tn < tiles;
+        long long nm0 = 0;
+        int nn0 = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last = kt + 1 == nk;
+            const bool feed = !last || more;     // a stage follows this one: load it now, store it to LDS after the product
+            int koff = (kt + 1) * kBK;
+            if (last) {                          // ... the first stage of the next tile
+                koff = 0;
+                if (more) {
+                    BD_PW_ORIGIN(tn, nm0, nn0)
+                    BD_PW_POINT(nm0, nn0)
+                }
+            }
+            // unconditional (the very last stage of a workgroup re-reads its tile's first stage and drops it): loads under a
+            // branch make the compiler wait for them at the join, in FRONT of the product they are meant to hide behind
+            if (!(BD_PW_ABLATE & 1)) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + koff);
+                for (int i = 0; i < LA; ++i) ra[i] = *(pw_gptr4)(ap[i] + koff);
 #pragma unroll
-        for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + koff);
-        BD_PW_COMPUTE(buf)
-        float* an = As + (buf ^ 1) * BM * kLds + st_off;
-        float* bn = Bs + (buf ^ 1) * BN * kLds + st_off;
+                for (int i = 0; i < LB; ++i) rb[i] = *(pw_gptr4)(bp[i] + koff);
+            }
+            asm volatile("" ::: "memory");       // keeps the loads HERE: their only use is under `feed`, and the compiler sinks them there
+            BD_PW_COMPUTE(buf)
+            if (feed) {
+                float* an = As + (buf ^ 1) * BM * kLds + st_off;
+                float* bn = Bs + (buf ^ 1) * BN * kLds + st_off;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(an + RPP * i * kLds) = ra[i];
+                for (int i = 0; i < LA; ++i) *reinterpret_cast<pw4*>(an + RPP * i * kLds) = ra[i];
 #pragma unroll
-        for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(bn + RPP * i * kLds) = rb[i];
-        __syncthreads();
-    }
-    BD_PW_COMPUTE((nk - 1) & 1)
-#undef BD_PW_COMPUTE
-
-    // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-    const int half = lane >> 5;
+                for (int i = 0; i < LB; ++i) *reinterpret_cast<pw4*>(bn + RPP * i * kLds) = rb[i];
+                __syncthreads();
+            }
+            buf ^= 1;
+        }
+        // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).  A tile inside
+        // M stores without a branch per row: under a branch each store gets its own s_waitcnt vmcnt(0) (for the bias load),
+        // which on gfx9 also waits for the store before it - sixteen memory round trips in a row per 32 x 32 tile.
+        const bool whole = m0 + BM <= M;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * WN + j * 32 + frow;
-        const float b = bias[n];
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * WN + j * 32 + frow;
+            const float b = bias[n];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long long mb = m0 + wr * WM + i * 32 + 4 * half;
+            for (int i = 0; i < TM; ++i) {
+                const long long mb = m0 + wr * WM + i * 32 + 4 * half;
+                float* const crow = C + (size_t)mb * N + n;
+                if (whole && !(BD_PW_ABLATE & 8)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M) C[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+                    for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * N] = fmaxf(acc[i][j][r] + b, 0.0f);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long m = mb + (r & 3) + 8 * (r >> 2);
+                        if (m < M && (!(BD_PW_ABLATE & 8) || acc[i][j][r] == 12345.678f)) C[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
             }
         }
+        if (!more) break;
+        t = tn;
+        m0 = nm0;
+        n0 = nn0;
     }
+#undef BD_PW_COMPUTE
+#undef BD_PW_ORIGIN
+#undef BD_PW_POINT
 }
 
 // --------------------------------------------------------------------------- pointwise GEMM, split-f16
@@ -560,9 +635,17 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&pointwise_kernel<BM, BN, WGM, WGN>, (int)lds, lds_once);
     const int tiles_n = N / BN;
-    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
-    hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NT), lds, stream, A, Wt,
-                       bias, C, M, N, K, tiles_n);
+    const long long tiles_m = (M + BM - 1) / BM;
+    const long long tiles = tiles_m * tiles_n;
+    // persistent: as many workgroups as fit the chip at once (by LDS: 160 KB per CU; by waves: 8 per SIMD), a multiple of 8
+    int per_cu = (int)(160 * 1024 / lds);
+    if (per_cu > 2048 / NT) per_cu = 2048 / NT;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)cu_count() * per_cu / 8 * 8;
+    if (grid > tiles) grid = tiles;
+    const int xcd_map = tiles_m % 8 == 0 && grid % 8 == 0;
+    hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(NT), lds, stream, A, Wt,
+                       bias, C, M, N, K, tiles_n, tiles, xcd_map);
 }
 
 // Workgroup (or persistent tile index) -> (row tile, column tile).  Workgroups go to the 8 XCDs round-robin by ID
@@ -3011,7 +3094,28 @@ int launch_pointwise_variant(const float* A, const float* Wt, const float* bias,
                              int K, int variant, hipStream_t stream) {
     if (M <= 0) return 0;
     if (K % kBK != 0 || N % 64 != 0) return -1;
-    if (variant == 0) variant = (K == 256 && N == 256) ? 7 : 8;   // tools/gemm_sweep.py on MI355X
+    if (variant == 0) {
+        // tools/gemm_sweep.py 1024 ... f32 on MI355X (round 4, persistent kernel): the first tile of the shape's list that
+        // gives every CU a tile; 64 x 64 tiles for small batches
+        struct Opt { int variant, bm, bn; };
+        static const Opt n64[] = {{8, 64, 64}};
+        static const Opt n128_k64[] = {{1, 128, 128}, {8, 64, 64}};
+        static const Opt n128[] = {{9, 96, 128}, {8, 64, 64}};
+        static const Opt n256[] = {{7, 128, 256}, {9, 96, 128}, {8, 64, 64}};
+        static const Opt wide[] = {{9, 96, 128}, {8, 64, 64}};
+        const Opt* list = wide;
+        int count = 2;
+        if (N == 64) { list = n64; count = 1; }
+        else if (N == 128 && K <= 64) { list = n128_k64; count = 2; }
+        else if (N == 128) { list = n128; count = 2; }
+        else if (N == 256) { list = n256; count = 3; }
+        variant = 8;
+        for (int i = 0; i < count; ++i) {
+            if (N % list[i].bn) continue;
+            const long long tiles = ((M + list[i].bm - 1) / list[i].bm) * (N / list[i].bn);
+            if (tiles >= 256 || i == count - 1) { variant = list[i].variant; break; }
+        }
+    }
     switch (variant) {
         case 1: if (N % 128) return -1; launch_pw<128, 128, 2, 2>(A, Wt, bias, C, M, N, K, stream); break;
         case 2: launch_pw<128, 64, 2, 2>(A, Wt, bias, C, M, N, K, stream); break;
@@ -3021,6 +3125,8 @@ int launch_pointwise_variant(const float* A, const float* Wt, const float* bias,
         case 6: if (N % 128) return -1; launch_pw<64, 128, 1, 4>(A, Wt, bias, C, M, N, K, stream); break;
         case 7: if (N % 256) return -1; launch_pw<128, 256, 2, 4>(A, Wt, bias, C, M, N, K, stream); break;
         case 8: launch_pw<64, 64, 2, 2>(A, Wt, bias, C, M, N, K, stream); break;
+        case 9: if (N % 128) return -1; launch_pw<96, 128, 1, 4>(A, Wt, bias, C, M, N, K, stream); break;
+        case 10: launch_pw<96, 64, 1, 2>(A, Wt, bias, C, M, N, K, stream); break;
         default: return -1;
     }
     return 0;
