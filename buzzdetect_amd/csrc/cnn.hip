@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict
 #define BD_PW_ABLATE 0      // developer builds: 1 = no global loads in the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = no stores
 #endif
 constexpr int kBK = 32;
-constexpr int kLds = kBK + 4;
+constexpr int kLds = kBK + 4;   // row stride in floats: 144 B = odd multiple of 16 B -> conflict-free b128
 // an operand fragment from LDS (developer build 2: a register value instead; by value, so that no address escapes)
 typedef float pw4 __attribute__((ext_vector_type(4)));   // native vectors: SSA values, nothing for the compiler to keep in memory
 // operand pointers that are re-pointed inside the tile loop: the address space is lost through the loop's phi nodes and the
@@ -221,15 +221,23 @@ typedef const __attribute__((address_space(1))) pw4* pw_gptr4;
 __device__ __forceinline__ pw4 pw_frag(const float* p, pw4 instead) {
     if (BD_PW_ABLATE & 2) return instead;
     return *reinterpret_cast<const pw4*>(p);
-}   // row stride in floats: 144 B = odd multiple of 16 B -> conflict-free b128
+}
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* __restrict__ A,
+// With NH > 0 the kernel also applies the NEXT layer's depthwise 3x3 (stride NS, TF SAME padding) to its output, an NH x NW
+// map per window: a 96-row tile is whole windows (one 12 x 8 map, four 6 x 4 maps or sixteen 3 x 2 maps), so the tile goes
+// through LDS as f32 (bias + ReLU applied) and what reaches HBM - `C` - is the depthwise output [windows][NH / NS][NW / NS][N];
+// the 1x1 output itself never exists.  depthwise_kernel's chain (shift, the taps in (kh, kw) order, zeros outside the map).
+template <int BM, int BN, int WGM, int WGN, int NH = 0, int NW = 0, int NS = 1>
+__global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_kernel(const float* __restrict__ A,
                                                                   const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ C, long long M, int N,
-                                                                  int K, int tiles_n, long long tiles, int xcd_map) {
+                                                                  int K, int tiles_n, long long tiles, int xcd_map,
+                                                                  const float* __restrict__ ndw_w,
+                                                                  const float* __restrict__ ndw_b, int windows) {
     constexpr int NT = WGM * WGN * 64;
+    constexpr bool NDW = NH > 0;
+    static_assert(!NDW || (BM % (NH * NW) == 0 && BN == 128 && NT % 32 == 0), "whole windows per tile");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RPP = NT / 8;                  // tile rows covered by one float4-per-thread pass
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* _
             }
             asm volatile("" ::: "memory");       // keeps the loads HERE: their only use is under `feed`, and the compiler sinks them there
             BD_PW_COMPUTE(buf)
-            if (feed) {
+            if (feed && !(NDW && last)) {        // (with the depthwise epilogue the tile passes through these buffers first)
                 float* an = As + (buf ^ 1) * BM * kLds + st_off;
                 float* bn = Bs + (buf ^ 1) * BN * kLds + st_off;
 #pragma unroll
@@ -371,30 +379,96 @@ __global__ __launch_bounds__(WGM* WGN * 64) void pointwise_kernel(const float* _
             }
             buf ^= 1;
         }
-        // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).  A tile inside
-        // M stores without a branch per row: under a branch each store gets its own s_waitcnt vmcnt(0) (for the bias load),
-        // which on gfx9 also waits for the store before it - sixteen memory round trips in a row per 32 x 32 tile.
-        const bool whole = m0 + BM <= M;
+        if constexpr (NDW) {
+            constexpr int PWN = NH * NW, WPT = BM / PWN;         // positions per window, windows per tile
+            constexpr int OH = NH / NS, OW = NW / NS, OPW = OH * OW;
+            constexpr int PAD = NS == 1 ? 1 : 0;
+            constexpr int PS = BN + 4;                           // row stride of the f32 tile
+            constexpr int TASKS = WPT * OPW * (BN / 4);
+            float* const P = smem;                               // [BM][PS], over the stage buffers
+            const int c4 = tid & (BN / 4 - 1);                   // this thread's channel quad (NT is a multiple of 32)
+            pw4 tw[9];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * WN + j * 32 + frow;
-            const float b = bias[n];
+            for (int k = 0; k < 9; ++k) tw[k] = *(pw_gptr4)((pw_gptr)ndw_w + (size_t)k * N + n0 + c4 * 4);
+            const pw4 tb = *(pw_gptr4)((pw_gptr)ndw_b + n0 + c4 * 4);
+            __syncthreads();                                     // every wave has read its last fragments
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const long long mb = m0 + wr * WM + i * 32 + 4 * half;
-                float* const crow = C + (size_t)mb * N + n;
-                if (whole && !(BD_PW_ABLATE & 8)) {
+            for (int j = 0; j < TN; ++j) {
+                const float b = bias[n0 + wc * WN + j * 32 + frow];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * N] = fmaxf(acc[i][j][r] + b, 0.0f);
-                } else {
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const long long m = mb + (r & 3) + 8 * (r >> 2);
-                        if (m < M && (!(BD_PW_ABLATE & 8) || acc[i][j][r] == 12345.678f)) C[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+                        P[(wr * WM + i * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * PS + wc * WN + j * 32 + frow] = fmaxf(acc[i][j][r] + b, 0.0f);
+                        acc[i][j][r] = 0.0f;
                     }
-                }
+            }
+            __syncthreads();
+            const long long win0 = m0 / PWN;
+            const bool whole = win0 + WPT <= windows;            // (stores under a branch each wait for the one before)
+#pragma unroll 1
+            for (int u = 0; u < (TASKS + NT - 1) / NT; ++u) {
+                const int idx = tid + NT * u;
+                const int pos = idx / (BN / 4);
+                const int w = pos / OPW, o = pos % OPW, oh = o / OW, ow = o % OW;
+                pw4 a = tb;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int ih = oh * NS + kh - PAD, iw = ow * NS + kw - PAD;
+                        const bool ok = ih >= 0 && ih < NH && iw >= 0 && iw < NW && (TASKS % NT == 0 || idx < TASKS);
+                        pw4 v = *reinterpret_cast<const pw4*>(P + (ok ? (w * PWN + ih * NW + iw) : 0) * PS + c4 * 4);
+                        v.x = ok ? v.x : 0.0f;
+                        v.y = ok ? v.y : 0.0f;
+                        v.z = ok ? v.z : 0.0f;
+                        v.w = ok ? v.w : 0.0f;
+                        a = __builtin_elementwise_fma(v, tw[kh * 3 + kw], a);
+                    }
+                a.x = fmaxf(a.x, 0.0f);
+                a.y = fmaxf(a.y, 0.0f);
+                a.z = fmaxf(a.z, 0.0f);
+                a.w = fmaxf(a.w, 0.0f);
+                float* const dst = C + (((size_t)(win0 + w) * OH + oh) * OW + ow) * N + n0 + c4 * 4;
+                if (whole && TASKS % NT == 0) *reinterpret_cast<pw4*>(dst) = a;
+                else if ((TASKS % NT == 0 || idx < TASKS) && win0 + w < windows) *reinterpret_cast<pw4*>(dst) = a;
+            }
+            if (more) {                                          // the next tile's first stage, held in registers since the last product
+                __syncthreads();                                 // the tile has been read
+                float* an = As + buf * BM * kLds + st_off;
+                float* bn = Bs + buf * BN * kLds + st_off;
+#pragma unroll
+                for (int i = 0; i < LA; ++i) *reinterpret_cast<pw4*>(an + RPP * i * kLds) = ra[i];
+#pragma unroll
+                for (int i = 0; i < LB; ++i) *reinterpret_cast<pw4*>(bn + RPP * i * kLds) = rb[i];
+                __syncthreads();
+            }
+        } else {
+        // epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).  A tile inside
+            // M stores without a branch per row: under a branch each store gets its own s_waitcnt vmcnt(0) (for the bias load),
+            // which on gfx9 also waits for the store before it - sixteen memory round trips in a row per 32 x 32 tile.
+            const bool whole = m0 + BM <= M;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * WN + j * 32 + frow;
+                const float b = bias[n];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const long long mb = m0 + wr * WM + i * 32 + 4 * half;
+                    float* const crow = C + (size_t)mb * N + n;
+                    if (whole && !(BD_PW_ABLATE & 8)) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * N] = fmaxf(acc[i][j][r] + b, 0.0f);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const long long m = mb + (r & 3) + 8 * (r >> 2);
+                            if (m < M && (!(BD_PW_ABLATE & 8) || acc[i][j][r] == 12345.678f)) C[(size_t)m * N + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                }
             }
         }
         if (!more) break;
@@ -627,13 +701,14 @@ void launch_pw16(const float* A, const _Float16* Whi, const _Float16* Wlo, const
     else launch_pw16_<BM, BN, WGM, WGN, false>(A, Whi, Wlo, unscale, bias, C, M, N, K, range_flag, stream);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NH = 0, int NW = 0, int NS = 1>
 void launch_pw(const float* A, const float* Wt, const float* bias, float* C, long long M, int N, int K,
-               hipStream_t stream) {
+               hipStream_t stream, const float* ndw_w = nullptr, const float* ndw_b = nullptr, int windows = 0) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = 2u * (BM + BN) * kLds * sizeof(float);
+    static_assert(NH == 0 || lds >= (size_t)BM * (BN + 4) * sizeof(float), "the f32 tile of the depthwise epilogue fits the stage buffers");
     static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&pointwise_kernel<BM, BN, WGM, WGN>, (int)lds, lds_once);
+    allow_dynamic_lds(&pointwise_kernel<BM, BN, WGM, WGN, NH, NW, NS>, (int)lds, lds_once);
     const int tiles_n = N / BN;
     const long long tiles_m = (M + BM - 1) / BM;
     const long long tiles = tiles_m * tiles_n;
@@ -644,8 +719,8 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
     long long grid = (long long)cu_count() * per_cu / 8 * 8;
     if (grid > tiles) grid = tiles;
     const int xcd_map = tiles_m % 8 == 0 && grid % 8 == 0;
-    hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(NT), lds, stream, A, Wt,
-                       bias, C, M, N, K, tiles_n, tiles, xcd_map);
+    hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN, NH, NW, NS>), dim3((unsigned)grid), dim3(NT), lds, stream, A, Wt,
+                       bias, C, M, N, K, tiles_n, tiles, xcd_map, ndw_w, ndw_b, windows);
 }
 
 // Workgroup (or persistent tile index) -> (row tile, column tile).  Workgroups go to the 8 XCDs round-robin by ID
@@ -3130,6 +3205,29 @@ int launch_pointwise_variant(const float* A, const float* Wt, const float* bias,
         default: return -1;
     }
     return 0;
+}
+
+// Exact-f32 1x1 convolution of layer L with the depthwise of the NEXT layer applied in the kernel's epilogue (96 x 128 tiles of
+// whole windows): in = L's depthwise output [windows][h][w][cin], out = the next layer's depthwise output.  false = shape not
+// covered (the caller runs the two kernels).
+bool launch_pointwise_next_dw_f32(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& Ln,
+                                  hipStream_t stream) {
+    if (windows <= 0) return true;
+    if (L.cout % 128 != 0 || L.cin % kBK != 0 || Ln.cin != L.cout || Ln.h_in != L.h_out || Ln.w_in != L.w_out) return false;
+    const long long M = (long long)windows * L.h_out * L.w_out;
+    const int h = L.h_out, w = L.w_out, st = Ln.stride;
+#define BD_NDW_CASE(H_, W_, S_)                                                                                         \
+    if (h == H_ && w == W_ && st == S_) {                                                                               \
+        launch_pw<96, 128, 1, 4, H_, W_, S_>(in, L.pw_wt, L.pw_b, out, M, L.cout, L.cin, stream, Ln.dw_w, Ln.dw_b, windows); \
+        return true;                                                                                                    \
+    }
+    BD_NDW_CASE(12, 8, 1)
+    BD_NDW_CASE(12, 8, 2)
+    BD_NDW_CASE(6, 4, 1)
+    BD_NDW_CASE(6, 4, 2)
+    BD_NDW_CASE(3, 2, 1)
+#undef BD_NDW_CASE
+    return false;
 }
 
 // Tile choice for the split-f16 kernel, from tools/gemm_sweep.py on MI355X at 1024 windows; when the

@@ -1049,6 +1049,20 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 stopped = true;
                 break;
             }
+            // exact-f32 mode behind the f32 stem: the 1x1 convolution with the NEXT layer's depthwise in its epilogue (whole
+            // windows per 96-row tile; bit-identical to the two kernels): the 1x1 output never reaches HBM and the next
+            // layer starts at its own 1x1 convolution.  Timed in this layer's pointwise slot.
+            if (f32_l4 && l + 1 < 13 && bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream)) {
+                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream);
+                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                float* t = buf_a;                // the next layer's depthwise output is what buf_b holds from here on
+                buf_a = buf_b;
+                buf_b = t;
+                skip_dw_layer = l + 1;
+                last = buf_b;
+                last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * L.cout;
+                continue;
+            }
             {
                 Scope sc(e, stream, 3 + 2 * l);
                 bd::launch_pointwise(buf_b, buf_a, (int64_t)gw * L.h_out * L.w_out, L, stream);

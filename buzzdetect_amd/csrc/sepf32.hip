@@ -678,7 +678,10 @@ __global__ __launch_bounds__(512, 2) void sepf32_kernel(const float* __restrict_
     }
 
     // ---- 4. shift + ReLU, NHWC rows (C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+    // A tile inside M stores without a branch per row: under a branch each store gets its own s_waitcnt vmcnt(0) (for the
+    // bias load), which on gfx9 also waits for the store before it - sixteen memory round trips in a row per 32 x 32 tile.
     const int half = lane >> 5;
+    const bool whole = m0 + BM <= M;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + frow;
@@ -686,10 +689,16 @@ __global__ __launch_bounds__(512, 2) void sepf32_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const long long mb = m0 + wr * 32 * TM + i * 32 + 4 * half;
+            if (whole) {
+                float* const crow = C + (size_t)mb * Cout + n;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M) C[(size_t)m * Cout + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+                for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * Cout] = fmaxf(acc[i][j][r] + b, 0.0f);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < M) C[(size_t)m * Cout + n] = fmaxf(acc[i][j][r] + b, 0.0f);
+                }
             }
         }
     }
