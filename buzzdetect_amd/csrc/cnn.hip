@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_ker
             constexpr int PAD = NS == 1 ? 1 : 0;
             constexpr int PS = BN + 4;                           // row stride of the f32 tile
             constexpr int TASKS = WPT * OPW * (BN / 4);
-            float* const P = smem;                               // [BM][PS], over the stage buffers
+            float* const P = smem;                               // [BM + 1][PS], over the stage buffers
             const int c4 = tid & (BN / 4 - 1);                   // this thread's channel quad (NT is a multiple of 32)
             pw4 tw[9];
 #pragma unroll
@@ -403,10 +403,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_ker
                         acc[i][j][r] = 0.0f;
                     }
             }
+            if (tid < BN / 4) *reinterpret_cast<pw4*>(P + BM * PS + tid * 4) = pw4{0.0f, 0.0f, 0.0f, 0.0f};   // what a tap outside the map reads
             __syncthreads();
             const long long win0 = m0 / PWN;
             const bool whole = win0 + WPT <= windows;            // (stores under a branch each wait for the one before)
-#pragma unroll 1
+#pragma unroll 3
             for (int u = 0; u < (TASKS + NT - 1) / NT; ++u) {
                 const int idx = tid + NT * u;
                 const int pos = idx / (BN / 4);
@@ -418,11 +419,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_ker
                     for (int kw = 0; kw < 3; ++kw) {
                         const int ih = oh * NS + kh - PAD, iw = ow * NS + kw - PAD;
                         const bool ok = ih >= 0 && ih < NH && iw >= 0 && iw < NW && (TASKS % NT == 0 || idx < TASKS);
-                        pw4 v = *reinterpret_cast<const pw4*>(P + (ok ? (w * PWN + ih * NW + iw) : 0) * PS + c4 * 4);
-                        v.x = ok ? v.x : 0.0f;
-                        v.y = ok ? v.y : 0.0f;
-                        v.z = ok ? v.z : 0.0f;
-                        v.w = ok ? v.w : 0.0f;
+                        const pw4 v = *reinterpret_cast<const pw4*>(P + (ok ? (w * PWN + ih * NW + iw) : BM) * PS + c4 * 4);   // row BM: zeros
                         a = __builtin_elementwise_fma(v, tw[kh * 3 + kw], a);
                     }
                 a.x = fmaxf(a.x, 0.0f);
@@ -706,7 +703,7 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
                hipStream_t stream, const float* ndw_w = nullptr, const float* ndw_b = nullptr, int windows = 0) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = 2u * (BM + BN) * kLds * sizeof(float);
-    static_assert(NH == 0 || lds >= (size_t)BM * (BN + 4) * sizeof(float), "the f32 tile of the depthwise epilogue fits the stage buffers");
+    static_assert(NH == 0 || lds >= (size_t)(BM + 1) * (BN + 4) * sizeof(float), "the f32 tile of the depthwise epilogue (+ a row of zeros) fits the stage buffers");
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&pointwise_kernel<BM, BN, WGM, WGN, NH, NW, NS>, (int)lds, lds_once);
     const int tiles_n = N / BN;

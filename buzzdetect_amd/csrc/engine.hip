@@ -1052,7 +1052,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // exact-f32 mode behind the f32 stem: the 1x1 convolution with the NEXT layer's depthwise in its epilogue (whole
             // windows per 96-row tile; bit-identical to the two kernels): the 1x1 output never reaches HBM and the next
             // layer starts at its own 1x1 convolution.  Timed in this layer's pointwise slot.
-            if (f32_l4 && l + 1 < 13 && bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream)) {
+            if (f32_l4 && !f32_layers && l + 1 < 13 && bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream)) {
                 BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 float* t = buf_a;                // the next layer's depthwise output is what buf_b holds from here on
