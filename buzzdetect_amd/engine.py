@@ -336,8 +336,8 @@ class HipEngine:
         """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, False = off) and fused
         depthwise+pointwise kernels (True = default path, 2 = the same with layer 4 as band tiles of the generic kernel,
         3 = the same with one launch per layer for layers 8-11 instead of one for the four, 4 / 5 = the same with layer 12 /
-        layer 14 on the 8-wave kernel, 6 = as True and the exact-f32 mode fused per layer too, 9 / 12 = plain fused layers on
-        the 8-wave / 12-wave kernel, False = one kernel per op)."""
+        layer 14 on the 8-wave kernel, 6 = as True and the exact-f32 mode on sepf32.hip's per-layer kernels, 9 / 12 = plain fused layers on
+        the 8-wave / 12-wave kernel (exact-f32 mode: the f32 stem, then two kernels per layer), False = one kernel per op)."""
         stem_code = 3 if stem is True else int(stem)
         with self._lock:
             _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))

@@ -258,11 +258,15 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    hook).  3: as 1 with one launch per layer for layers 8-11 (test hook).  4: as 1 with layer 12 on the
                    8-wave kernel (256-column tiles) instead of the 12-wave one (test hook).  5: as 1 with layer 14 + pool on the
                    8-wave kernel (four 256-column tiles on all CUs: faster alone, slower in a full pipeline) instead of the
-                   12-wave one (two 512-column halves; test hook).  6: as 1, and in the exact-f32 mode (bd_set_pointwise_mode
-                   0, which otherwise runs one kernel per op whatever this setting) every separable layer is one kernel that
-                   keeps the depthwise output in LDS (sepf32.hip: 16-23 % less board power and 5 % faster on one stream, 1.5-3 %
-                   slower on three - DESIGN.md 4.6 - hence not the default).  9 / 12: plain fused layers
-                   on the 8-wave kernel only / with the 12-wave kernel for 512 -> 512 channels (test hook).
+                   12-wave one (two 512-column halves; test hook).  6: as 1, and in the exact-f32 mode every
+                   separable layer from 6 on is one kernel that keeps the depthwise output in LDS (sepf32.hip; slower on three
+                   streams than the default below - DESIGN.md 4.6).  9 / 12: plain fused layers on the 8-wave kernel only /
+                   with the 12-wave kernel for 512 -> 512 channels (test hook).
+                   The exact-f32 mode (bd_set_pointwise_mode 0) with stem == 3: layers 1-3 are one f32-MFMA kernel; with
+                   separable 1 .. 5 (default 1) layer 4 + depthwise 5 are another and every later 1x1 convolution applies the
+                   NEXT layer's depthwise in its epilogue (no stand-alone depthwise kernel is left); with 9 / 12 the layers
+                   behind the stem run depthwise_kernel + pointwise_kernel; with stem == 0 or during calibration / stage taps
+                   one kernel per op.
    Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);
 /* whi/wlo: [n][k] f16 halves of wt * scale[n] (wt[n][:] * scale[n] ~= whi[n][:] + wlo[n][:]); unscale[n] = 1 / (scale[n] *
