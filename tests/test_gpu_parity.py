@@ -286,13 +286,14 @@ def _pow2_operands(a, wt):
 
 @pytest.mark.parametrize("mode", ["f32", "f16x3"])
 @pytest.mark.parametrize("gain", [1.0, 30.0, 300.0, 2.0 ** 20, 0.01, 0.001, 2.0 ** -20])
-@pytest.mark.parametrize("m,k,n", [(1, 32, 64), (6, 1024, 1024), (130, 64, 128), (4992, 512, 512), (1000, 256, 256)])
+@pytest.mark.parametrize("m,k,n", [(1, 32, 64), (6, 1024, 1024), (130, 64, 128), (4992, 512, 512), (1000, 256, 256), (19300, 128, 512)])
 def test_pointwise_gemm_every_tile_variant(mode, m, k, n, gain):
     """Every tile shape of both GEMM kernels against an f64 product, on ragged M (tile-edge rows), at HOSTILE operand
     scales: activations times `gain`, weights divided by it, rows of the weight matrix a further factor 1..1000 apart
     (what BatchNorm folding does to real weights).  The bound is per output and relative to that output's own sum of
     |a||w| - the f32 kernel's own error class - so the split-f16 path cannot hide a lost low half behind the largest
-    output of the matrix."""
+    output of the matrix.  (19300 x 512: more tiles than the persistent exact-f32 kernel has workgroups - every workgroup
+    walks several tiles, the last row tile ragged.)"""
     import torch
     from buzzdetect_amd import _lib
     lib = _lib.load()
@@ -310,7 +311,7 @@ def test_pointwise_gemm_every_tile_variant(mode, m, k, n, gain):
     a16, whi, wlo, unscale = _pow2_operands(a, wt)
     stream = torch.cuda.current_stream().cuda_stream
     ran = 0
-    for variant in range(0, 10):
+    for variant in range(0, 11):
         c = torch.full((m, n), -1.0, device=dev)
         if mode == "f32":
             rc = lib.bd_debug_pointwise(a.data_ptr(), wt.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, variant, stream)
@@ -783,13 +784,15 @@ def test_persistent_kernels_at_grid_boundaries(engine, windows):
         engine.set_fusion(True, True)
 
 
-@pytest.mark.parametrize("windows", [1, 3, 37, 300, 678, 1024])
+@pytest.mark.parametrize("windows", [1, 3, 37, 300, 678, 1024, 1090])
 def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
-    """Exact-f32 mode (bd_set_pointwise_mode 0) with the separable layers fused (bd_set_fusion separable = 6, sepf32.hip:
-    depthwise into an LDS tile, 1x1 convolution on v_mfma_f32_32x32x2_f32 from it, the depthwise output never in HBM) against
-    the same mode as one kernel per op (depthwise_kernel + pointwise_kernel, the mode's default): the same chains of IEEE
-    operations, so logits AND embeddings agree bit for bit; whole hop and half hop, partial tiles of every layer (windows x
-    positions is not a multiple of the 96 .. 512-row tiles)."""
+    """Exact-f32 mode (bd_set_pointwise_mode 0) in its fused layouts against the same mode as one kernel per op
+    (conv1_kernel, depthwise_kernel, pointwise_kernel): the same chains of IEEE operations, so logits AND embeddings agree
+    bit for bit; whole hop and half hop, partial tiles of every layer (windows x positions is not a multiple of the 96 ..
+    512-row tiles; windows not a multiple of the 4 / 16 windows of a tile of the depthwise epilogue), two passes (1090).
+    Default: layers 1-3 as stem3_f32_kernel, layer 4 + depthwise 5 as l4_f32_kernel, every later 1x1 convolution with the
+    next layer's depthwise in its epilogue (pointwise_kernel<96, 128, 1, 4, NH, NW, NS>); 9: the stem, then two kernels per
+    layer; 6: sepf32.hip's per-layer kernels (depthwise into an LDS tile, the product from it)."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f32")
     try:
