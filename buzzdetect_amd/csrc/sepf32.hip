@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 3) void stem3_f32_kernel(const float* __restri
 //   then        bias + ReLU -> f32 tile P[80][132] (rows past the map are depthwise 5's zero padding), depthwise 5 on P -> HBM
 // Both depthwise layers' taps sit in LDS for the life of the workgroup.  The chain of IEEE operations per element is that
 // of depthwise_kernel, pointwise_kernel, depthwise_kernel: bit-identical to the three kernels it replaces (316 us per 1024
-// windows -> 227 us), whose two intermediate tensors (201 MB each) never exist.  The matrix pipe is busy 55 % of the time
+// windows -> 214 us), whose two intermediate tensors (201 MB each) never exist.  The matrix pipe is busy 55-60 % of the time
 // (1.5 x the layer's MFMAs: 96 rows for 64 new positions): what is left is the phases of a tile that no other wave covers
 // at two waves per SIMD.
 __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict__ X, const float* __restrict__ dw4_w,
@@ -355,25 +355,33 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
     };
     // the band of a chunk is fetched into registers ahead of its use (in flight behind the depthwise and the product; the
     // first band of the NEXT tile behind this tile's last chunks and epilogue)
+    // Loads WITHOUT a branch (clamped address, zeroed when stored to LDS): a load under a branch cannot be counted by the
+    // compiler, which then waits for everything in flight - these loads included - before the first use of the weights that
+    // were loaded ahead of them, i.e. in front of the matrix instructions the loads are meant to hide behind.
     float4 band[4];
+    unsigned band_ok = 0;
     auto fetch_band = [&](int win, int ob, int kc) {
         const float* const xin = X + (size_t)win * H * W * C;
+        band_ok = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u;
             const int cc = i & 7, pos = i >> 3;
             const int row = pos / 18, col = pos - row * 18;
             const int ih = 4 * ob - 1 + row, iw = col - 1;
-            band[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < 7 * 18 * 8 && ih >= 0 && ih < H && iw >= 0 && iw < W)
-                band[u] = *reinterpret_cast<const float4*>(xin + ((size_t)ih * W + iw) * C + kc * KC + cc * 4);
+            const bool ok = i < 7 * 18 * 8 && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            band_ok |= ok ? 1u << u : 0u;
+            const int ihc = ih < 0 ? 0 : ih >= H ? H - 1 : ih, iwc = iw < 0 ? 0 : iw >= W ? W - 1 : iw;
+            band[u] = *reinterpret_cast<const float4*>(xin + ((size_t)ihc * W + iwc) * C + kc * KC + cc * 4);
         }
     };
     auto put_band = [&](int kc) {                       // registers -> band buffer kc & 1
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u;
-            if (i < 7 * 18 * 8) *reinterpret_cast<float4*>(smem + OFF_BAND + (kc & 1) * BAND_BYTES + i * 16) = band[u];
+            float4 v = band[u];
+            if (!((band_ok >> u) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < 7 * 18 * 8) *reinterpret_cast<float4*>(smem + OFF_BAND + (kc & 1) * BAND_BYTES + i * 16) = v;
         }
     };
     // depthwise 4 of chunk kc (depthwise_kernel's chain: shift, then the taps in (kh, kw) order, zeros outside the map):
@@ -409,6 +417,9 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
         }
     };
     int tile = blockIdx.x, win = 0, ob = 0;
+    v4f w4[2][4];                                       // the layer's weights of this chunk and the next (from L2)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w4[0][q] = *reinterpret_cast<const v4f*>(w4row + 8 * q);
     if (tile < total) {
         tile_of(tile, win, ob);
         fetch_band(win, ob, 0);
@@ -429,15 +440,17 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
         int nwin = 0, nob = 0;
         const bool more = tile + (int)gridDim.x < total;
         if (more) tile_of(tile + gridDim.x, nwin, nob);
-#pragma unroll 1
+#pragma unroll                                   // (unrolled: which band to fetch is then known at compile time - see fetch_band)
         for (int kc = 0; kc < C / KC; ++kc) {
-            v4f w4[4];
+            // this lane's weights of the NEXT chunk (of chunk 0 again behind the last one: the next tile starts with them)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const v4f*>(w4row + kc * KC + 8 * q);
+            for (int q = 0; q < 4; ++q) w4[(kc + 1) & 1][q] = *reinterpret_cast<const v4f*>(w4row + ((kc + 1) & 3) * KC + 8 * q);
             if (kc + 1 < C / KC) put_band(kc + 1);      // its buffer was last read two chunks ago
             __syncthreads();                            // A tile kc and band kc + 1 are complete; A tile kc - 1 has been read
             if (kc + 2 < C / KC) fetch_band(win, ob, kc + 2);
-            else if (kc + 2 == C / KC && more) fetch_band(nwin, nob, 0);      // stays in registers through the epilogue
+            else if (kc + 2 == C / KC) fetch_band(more ? nwin : win, more ? nob : ob, 0);   // the next tile's first band (or a
+                                                        // dummy): stays in registers through the last chunk and the epilogue
+            asm volatile("" ::: "memory");              // issued HERE, in front of the matrix instructions, not sunk behind them
             // ---- [96][32] x [32][128]: wave w = output channels 32 w .., three row tiles (positions 80 .. 95 are not used) ----
             const char* const s_a = smem + OFF_A + (kc & 1) * A_BYTES;
 #pragma unroll
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const v4f a4 = *reinterpret_cast<const v4f*>(s_a + row * 128 + (((2 * q + fh) ^ ((row >> 1) & 7)) << 4));
-                    const v4f ww = w4[q];
+                    const v4f ww = w4[kc & 1][q];
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.x, a4.x, acc[i], 0, 0, 0);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.y, a4.y, acc[i], 0, 0, 0);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.z, a4.z, acc[i], 0, 0, 0);
