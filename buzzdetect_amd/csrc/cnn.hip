@@ -407,28 +407,78 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_ker
             __syncthreads();
             const long long win0 = m0 / PWN;
             const bool whole = win0 + WPT <= windows;            // (stores under a branch each wait for the one before)
-#pragma unroll 3
-            for (int u = 0; u < (TASKS + NT - 1) / NT; ++u) {
-                const int idx = tid + NT * u;
-                const int pos = idx / (BN / 4);
-                const int w = pos / OPW, o = pos % OPW, oh = o / OW, ow = o % OW;
-                pw4 a = tb;
+            if constexpr (NS == 1) {
+                // stride 1: a thread owns a COLUMN of a window's map (and a channel quad) and walks the input rows once - each row
+                // is tap row 0 of the output below it, 1 of its own, 2 of the one above - so an output's chain still runs
+                // in (kh, kw) order, with 3 NH LDS reads per NH outputs instead of 9 NH
+                constexpr int ITEMS = WPT * NW * (BN / 4);
+                static_assert(ITEMS % NT == 0, "whole rounds of column items");
+#pragma unroll 1
+                for (int u = 0; u < ITEMS / NT; ++u) {
+                    const int q = (tid + NT * u) / (BN / 4);
+                    const int col = q % NW, w = q / NW;
+                    pw4 o[NH];
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+                    for (int r = 0; r < NH; ++r) o[r] = tb;
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int ih = oh * NS + kh - PAD, iw = ow * NS + kw - PAD;
-                        const bool ok = ih >= 0 && ih < NH && iw >= 0 && iw < NW && (TASKS % NT == 0 || idx < TASKS);
-                        const pw4 v = *reinterpret_cast<const pw4*>(P + (ok ? (w * PWN + ih * NW + iw) : BM) * PS + c4 * 4);   // row BM: zeros
-                        a = __builtin_elementwise_fma(v, tw[kh * 3 + kw], a);
+                    for (int r = -1; r <= NH; ++r) {
+                        pw4 v[3];
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int cc = col - 1 + kw;
+                            const bool ok = r >= 0 && r < NH && cc >= 0 && cc < NW;
+                            v[kw] = *reinterpret_cast<const pw4*>(P + (ok ? w * PWN + r * NW + cc : BM) * PS + c4 * 4);    // row BM: zeros
+                        }
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            if (r + 1 < NH) o[r + 1 < NH ? r + 1 : 0] = __builtin_elementwise_fma(v[kw], tw[kw], o[r + 1 < NH ? r + 1 : 0]);
+                        }
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            if (r >= 0 && r < NH) o[r >= 0 && r < NH ? r : 0] = __builtin_elementwise_fma(v[kw], tw[3 + kw], o[r >= 0 && r < NH ? r : 0]);
+                        }
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            if (r >= 1) o[r >= 1 ? r - 1 : 0] = __builtin_elementwise_fma(v[kw], tw[6 + kw], o[r >= 1 ? r - 1 : 0]);
+                        }
                     }
-                a.x = fmaxf(a.x, 0.0f);
-                a.y = fmaxf(a.y, 0.0f);
-                a.z = fmaxf(a.z, 0.0f);
-                a.w = fmaxf(a.w, 0.0f);
-                float* const dst = C + (((size_t)(win0 + w) * OH + oh) * OW + ow) * N + n0 + c4 * 4;
-                if (whole && TASKS % NT == 0) *reinterpret_cast<pw4*>(dst) = a;
-                else if ((TASKS % NT == 0 || idx < TASKS) && win0 + w < windows) *reinterpret_cast<pw4*>(dst) = a;
+                    if (whole || win0 + w < windows) {
+                        float* const dst = C + (((size_t)(win0 + w) * OH) * OW + col) * N + n0 + c4 * 4;
+#pragma unroll
+                        for (int r = 0; r < NH; ++r) {
+                            pw4 a = o[r];
+                            a.x = fmaxf(a.x, 0.0f);
+                            a.y = fmaxf(a.y, 0.0f);
+                            a.z = fmaxf(a.z, 0.0f);
+                            a.w = fmaxf(a.w, 0.0f);
+                            *reinterpret_cast<pw4*>(dst + (size_t)r * OW * N) = a;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll 3
+                for (int u = 0; u < (TASKS + NT - 1) / NT; ++u) {
+                    const int idx = tid + NT * u;
+                    const int pos = idx / (BN / 4);
+                    const int w = pos / OPW, o = pos % OPW, oh = o / OW, ow = o % OW;
+                    pw4 a = tb;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int ih = oh * NS + kh - PAD, iw = ow * NS + kw - PAD;
+                            const bool ok = ih >= 0 && ih < NH && iw >= 0 && iw < NW && (TASKS % NT == 0 || idx < TASKS);
+                            const pw4 v = *reinterpret_cast<const pw4*>(P + (ok ? (w * PWN + ih * NW + iw) : BM) * PS + c4 * 4);   // row BM: zeros
+                            a = __builtin_elementwise_fma(v, tw[kh * 3 + kw], a);
+                        }
+                    a.x = fmaxf(a.x, 0.0f);
+                    a.y = fmaxf(a.y, 0.0f);
+                    a.z = fmaxf(a.z, 0.0f);
+                    a.w = fmaxf(a.w, 0.0f);
+                    float* const dst = C + (((size_t)(win0 + w) * OH + oh) * OW + ow) * N + n0 + c4 * 4;
+                    if (whole && TASKS % NT == 0) *reinterpret_cast<pw4*>(dst) = a;
+                    else if ((TASKS % NT == 0 || idx < TASKS) && win0 + w < windows) *reinterpret_cast<pw4*>(dst) = a;
+                }
             }
             if (more) {                                          // the next tile's first stage, held in registers since the last product
                 __syncthreads();                                 // the tile has been read
