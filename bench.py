@@ -546,8 +546,14 @@ def main() -> int:
                                              out=local[slot][at:at + u.windows])
                 if probe is None:
                     probe = res
-            if world > 1 and mine:
-                with torch.cuda.stream(streams[next(iter(used))]):
+            if world > 1:
+                # the marker row is written in EVERY round, also by a rank that has no units in it (windows = 0): a reused
+                # ring slot would otherwise hand rank 0 the marker of the slot's previous round a second time
+                mark_stream = streams[next(iter(used))] if used else streams[0]
+                if not used and reusable[slot] is not None:
+                    mark_stream.wait_event(reusable[slot])
+                used.add(streams.index(mark_stream))
+                with torch.cuda.stream(mark_stream):
                     local[slot][rnd.rows, 0] = float(rank + 1)
                     local[slot][rnd.rows, 1] = float(sum(u.windows for u in mine))
             if probe is not None and ri % per_step == per_step - 1:

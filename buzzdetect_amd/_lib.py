@@ -53,6 +53,7 @@ PROTOTYPES = {
     "bd_resample_taps": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bd_set_resample_quality": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bd_resample_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "bd_debug_fir_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "bd_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                               C.c_void_p]),

@@ -18,7 +18,7 @@ import tempfile
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libbuzzdetect_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ("engine.hip", "frontend.hip", "resample.hip", "sepf32.hip", "cnn.hip")
+SOURCES = ("engine.hip", "frontend.hip", "resample.hip", "sepf32.hip", "sepchip.hip", "cnn.hip")
 HEADERS = ("bd_internal.h", os.path.join("..", "..", "include", "buzzdetect_hip.h"))
 ARCH = "gfx950"
 

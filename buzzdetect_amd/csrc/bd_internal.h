@@ -131,6 +131,7 @@ void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* l
                    const FeTables* tables, hipStream_t stream);
 void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const float* taps, int half, int up,
                      int down, float* out, int64_t n_out, hipStream_t stream);
+bool resample_span_fits(int half, int up, int down);       // frontend.hip: can resample_kernel stage one output's span?
 void launch_patches(const float* logmel, int64_t n_windows, int patch_step, float* patches,
                     hipStream_t stream);
 void launch_conv1(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* w9x32,
@@ -153,7 +154,9 @@ bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, cons
 bool launch_l4_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
 void launch_stem_f32(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
-int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
+int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,
+                         bool on_chip = true);
+void launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream);   // sepchip.hip
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     bool band_tiles, hipStream_t stream, bool twelve_waves = true);
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,

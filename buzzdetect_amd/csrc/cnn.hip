@@ -785,6 +785,7 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)cu_count() * per_cu / 8 * 8;
     if (grid > tiles) grid = tiles;
+    if (grid < 1) grid = 1;                   // (a device with fewer than 8 resident workgroups: never a zero-sized launch)
     const int xcd_map = tiles_m % 8 == 0 && grid % 8 == 0;
     hipLaunchKernelGGL((pointwise_kernel<BM, BN, WGM, WGN, NH, NW, NS>), dim3((unsigned)grid), dim3(NT), lds, stream, A, Wt,
                        bias, C, M, N, K, tiles_n, tiles, xcd_map, ndw_w, ndw_b, windows);
@@ -3437,7 +3438,7 @@ bool launch_separable_fused(const float* in, float* out, int windows, const SepL
 // A run of stride-1 512 -> 512 layers on the 6 x 4 map (layers 8-11) as one launch of the 12-wave kernel.  Returns how many
 // layers of L[0 .. max_layers) it ran (0: none - the caller goes layer by layer); the output of an odd count is in b, of an
 // even count in a.  A layer whose successor is a stride-2 one is left to launch_separable_fused_next_dw.
-int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream) {
+int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream, bool on_chip) {
     int n = 0;
     while (n < 4 && n + 1 < max_layers) {     // n + 1 < max_layers: L[n + 1] exists
         const SepLayer& l = L[n];
@@ -3447,7 +3448,8 @@ int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int
     }
     const long long M = (long long)windows * 24;
     if (n < 2 || windows <= 0 || M >= (1LL << 31)) return 0;
-    launch_sep_w12<96>(a, b, L, n, M, stream);
+    if (on_chip) launch_separable_chip(a, (n & 1) ? b : a, windows, L, n, stream);      // sepchip.hip: only a and the result in HBM
+    else launch_sep_w12<96>(a, b, L, n, M, stream);
     return n;
 }
 

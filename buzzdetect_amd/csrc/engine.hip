@@ -60,6 +60,8 @@ struct bd_engine {
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
+    bool chip_run = true;             // ... with the tiles between its layers kept on the CU (sepchip.hip; separable = 7: the
+                                      // round-3 form that hands them over through global memory)
     bool ndw_w12 = true;              // layer 12 (+ the next layer's depthwise) on the 12-wave kernel (separable = 4: 8-wave)
     bool pool_w12 = true;             // layer 14 + pool on the 12-wave kernel, two 512-column halves (separable = 5: 8-wave, four quarters)
     int sep_variant = 0;
@@ -675,6 +677,20 @@ int bd_debug_fir_plan(int32_t rate_in, int32_t rate_out, int32_t* geometry, int3
     return 1;
 }
 
+int bd_resample_supported(int32_t rate_in, int32_t rate_out, int32_t quality) {
+    if (rate_in <= 0 || rate_out <= 0) return fail(BD_EINVAL, "bd_resample_supported: bad rate");
+    if (quality != BD_RESAMPLE_SCIPY && quality != BD_RESAMPLE_HQ) return fail(BD_EINVAL, "bd_resample_supported: unknown quality");
+    int up, down, half = 0;
+    rational_ratio(rate_in, rate_out, &up, &down);
+    if (up > 4096 || down > 4096) return 0;
+    if (up == 1 && down == 1) return 1;
+    const std::vector<double> hd = design_taps(up, down, quality, &half);
+    bd::FirPlanHost f;
+    if (quality == BD_RESAMPLE_HQ && bd::fir_plan_build(up, down, hd.data(), half, &f)) return 1;
+    if (up == 1 && (down == 2 || down == 3) && half == 10 * down) return 1;
+    return bd::resample_span_fits(half, up, down) ? 1 : 0;
+}
+
 int bd_set_resample_quality(bd_handle h, int32_t quality) {
     if (!h) return fail(BD_EINVAL, "bd_set_resample_quality: null handle");
     if (quality != BD_RESAMPLE_SCIPY && quality != BD_RESAMPLE_HQ) return fail(BD_EINVAL, "bd_set_resample_quality: unknown quality");
@@ -707,6 +723,9 @@ static int resample_any(bd_handle h, const void* in_dev, bool s16, int64_t n_in,
             // rounds 1-3's filter keeps its kernels (decimate_kernel / resample_kernel: bit for bit what it was); the long
             // filter runs on the matrix cores where the ratio fits
             t.has_plan = quality == BD_RESAMPLE_HQ && bd::fir_plan_build(up, down, hd.data(), t.half, &t.fir);
+            if (!t.has_plan && !(up == 1 && (down == 2 || down == 3) && t.half == 10 * down) &&
+                !bd::resample_span_fits(t.half, up, down))
+                return fail(BD_EINVAL, "bd_resample: the filter of this rate ratio is longer than the kernel's staged span");
             const size_t n_taps = (hd.size() + 3) / 4 * 4;
             const size_t n_g = t.has_plan ? t.fir.gfrag.size() / 2 : 0;             // in floats
             const size_t n_k = t.has_plan ? (t.fir.koff.size() + 3) / 4 * 4 : 0;
@@ -1000,7 +1019,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 continue;
             }
             if (e->fuse_sep && e->fuse_run && mode != 0 && e->sep_variant <= 1 && stop_stage < 0 && skip_dw_layer != l) {
-                const int ran = bd::launch_separable_run(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
+                const int ran = bd::launch_separable_run(buf_a, buf_b, gw, &sep[l], 13 - l, stream, e->chip_run);
                 if (ran > 0) {
                     l += ran - 1;
                     if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);      // the whole run in its last layer's slot
@@ -1029,7 +1048,11 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // exact-f32 mode: depthwise + 1x1 convolution of the layer as one kernel, the depthwise output never leaves the CU
             // (the calibration pass and the stage taps keep one kernel per op: they look at the depthwise output)
-            if (f32_layers && skip_dw_layer != l && bd::launch_sep_f32(buf_a, buf_b, gw, L, stream)) {
+            if (f32_layers && skip_dw_layer != l) {
+                // sep_f32_ok said yes for every layer before the buffers were swapped (conv1 wrote the SMALL one): falling
+                // through to depthwise_kernel + pointwise_kernel here would write 98 304 floats per window into it
+                if (!bd::launch_sep_f32(buf_a, buf_b, gw, L, stream))
+                    return fail(BD_EHIP, "exact-f32 fused layer refused a shape that sep_f32_ok accepted");
                 BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_sep_f32(buf_a, buf_b, gw, L, stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 float* t = buf_a;
@@ -1356,8 +1379,10 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
     if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 6 &&
-        separable != 9 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 9 or 12");
+        separable != 7 && separable != 9 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 7, 9 or 12");
+    h->chip_run = separable != 7;            // 7: layers 8-11 as one launch that hands its tiles over through global memory
+    if (separable == 7) separable = 1;
     h->fuse_f32 = separable == 6;            // exact-f32 mode: one kernel per separable layer (sepf32.hip); the f16 modes as 1
     if (separable == 6) separable = 1;
     h->fuse_stem = stem != 0;

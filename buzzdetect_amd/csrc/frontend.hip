@@ -720,6 +720,13 @@ void launch_resample(const void* in, bool s16, int64_t n_in, int channels, const
 #undef BD_RS_LAUNCH
 }
 
+// resample_kernel stages the input span of a tile (tile * down / up + 2 * half / up + a few samples) in s_x[kRsMaxSpan]: a
+// filter so long that even a one-output tile does not fit cannot run on it (launch_resample clamps the tile to 1 and the
+// kernel would stage past the array).  With the 569-tap-class filter that is down / up > ~43, e.g. 768 kHz -> 16 kHz.
+bool resample_span_fits(int half, int up, int down) {
+    return 2 * (int64_t)half / up + (int64_t)down / up + 4 <= kRsMaxSpan;
+}
+
 void launch_logmel(const float* pcm, int64_t n_valid, int64_t n_frames, float* logmel,
                    const FeTables* tables, hipStream_t stream) {
     if (n_frames <= 0) return;

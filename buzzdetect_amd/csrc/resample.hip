@@ -497,18 +497,7 @@ void launch_fir_mfma(const void* in, bool s16, int64_t n_in, int channels, const
     const int64_t n_chunks = (periods + rows - 1) / rows;
     // persistent workgroups: as many as are resident together (two or three per CU by LDS and registers), each walks
     // chunks grid.x apart with its share of the filter in registers
-    int cus = 256;
-    {
-        static int cus_of[16] = {0};                       // per device, asked once (racing first calls write the same value)
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        int& c = cus_of[dev & 15];
-        if (c == 0) {
-            int v = 0;
-            c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-        }
-        cus = c;
-    }
+    const int cus = cu_count();
     const int per_cu = p.lds_bytes <= 40 * 1024 ? 3 : p.lds_bytes <= 80 * 1024 ? 2 : 1;
     int64_t gx = (int64_t)cus * per_cu / p.NB;             // (rounded down: one workgroup too many per CU is a whole extra round)
     if (gx > n_chunks) gx = n_chunks;

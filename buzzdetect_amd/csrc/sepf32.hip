@@ -789,17 +789,10 @@ bool launch_l4_f32(const float* in, float* out, int windows, const SepLayer& L4,
     if (L4.cin != 128 || L4.cout != 128 || L4.h_in != 24 || L4.w_in != 16 || L4.stride != 1 || L5.cin != 128 || L5.stride != 2)
         return false;
     // persistent: two workgroups per CU (67 KB of LDS each) walk the 6 x windows tiles; a multiple of 8 for the XCD mapping
-    static int cus_of[16] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 16 && cus_of[dev] == 0) {
-        int v = 0;
-        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        cus_of[dev] = v > 0 ? v : 256;
-    }
-    const int cus = dev >= 0 && dev < 16 ? cus_of[dev] : 256;
+    const int cus = cu_count();
     int grid = 2 * cus / 8 * 8;
     if (grid > 6 * windows) grid = (6 * windows + 7) / 8 * 8;
+    if (grid < 8) grid = 8;
     hipLaunchKernelGGL(l4_f32_kernel, dim3(grid), dim3(256), 0, stream, in, L4.dw_w, L4.dw_b, L4.pw_wt, L4.pw_b, L5.dw_w, L5.dw_b,
                        out, windows);
     return true;

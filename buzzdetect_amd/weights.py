@@ -134,6 +134,9 @@ def default_candidates(engine_embedder: str, framehop_prop=None) -> List[str]:
     return out
 
 
+RAW_TAIL_MAX = 1 << 16      # bytes a data shard may carry behind the 54 tensors (the saved object graph)
+
+
 def read_variables(path: str) -> np.ndarray:
     """The embedder blob from a ``variables.data-00000-of-00001``.  With its ``variables.index`` beside it every tensor is
     looked up by name and checked (shape, float32) and the blob is assembled in the order the C ABI expects, whatever order
@@ -152,10 +155,27 @@ def read_variables(path: str) -> np.ndarray:
                 raise ValueError(f"{index_path}: {name} is {entry.shape} dtype {entry.dtype}, expected float32 {shape}")
             blob[off:off + entry.count] = artifacts.read_bundle_tensor(path, entry).reshape(-1)
         return blob
-    raw = np.fromfile(path, dtype="<f4", count=EMBEDDER_BLOB_FLOATS)
-    if raw.size != EMBEDDER_BLOB_FLOATS:
-        raise ValueError(f"{path}: expected at least {EMBEDDER_BLOB_FLOATS * 4} bytes of f32 payload")
-    return raw.astype(np.float32)
+    # No index: the file is taken to BE the blob in the C ABI's order.  That is an assumption about bytes nobody named, so it
+    # is said out loud and checked as far as the layout allows: the size is the payload plus at most a small object-graph
+    # tail (a TensorBundle data shard of this model is 12 869 376 bytes + < 64 KiB), every value is finite, and the slices
+    # that must be BatchNorm moving variances are all positive - an unrelated or re-ordered bundle fails that at once.
+    size = os.path.getsize(path)
+    need = EMBEDDER_BLOB_FLOATS * 4
+    if size < need or size > need + RAW_TAIL_MAX:
+        raise ValueError(f"{path}: {size} bytes without a variables.index beside it; a raw embedder payload is {need} bytes "
+                         f"(+ at most {RAW_TAIL_MAX} of object graph)")
+    raw = np.fromfile(path, dtype="<f4", count=EMBEDDER_BLOB_FLOATS).astype(np.float32)
+    if not np.isfinite(raw).all():
+        raise ValueError(f"{path}: non-finite values where the embedder weights should be (no variables.index to look tensors up by)")
+    for name, shape, off in expected_table():
+        if name.endswith("moving_variance"):
+            n = int(np.prod(shape))
+            if not (raw[off:off + n] > 0).all():
+                raise ValueError(f"{path}: the slice that should be {name} is not all positive - this file is not the embedder "
+                                 f"payload in blob order (put its variables.index beside it)")
+    _log.warning("embedder weights: %s has no variables.index beside it; read as the raw payload in blob order "
+                 "(size, finiteness and BatchNorm-variance slices checked)", path)
+    return raw
 
 
 def synthetic_allowed(synthetic: Optional[bool] = None) -> bool:

@@ -143,6 +143,11 @@ BD_API int bd_set_resample_quality(bd_handle h, int32_t quality);
    the vector kernel.  tests/test_resample.py multiplies the fragments out on the CPU against the oracle's filter. */
 BD_API int bd_debug_fir_plan(int32_t rate_in, int32_t rate_out, int32_t* geometry, int32_t* boff, int64_t boff_capacity,
                              uint16_t* gfrag, int64_t gfrag_capacity);
+/* Host only: 1 when bd_resample / bd_resample_s16 accept rate_in -> rate_out at `quality` (BD_RESAMPLE_*), 0 when they refuse
+   it with BD_EINVAL - the ratio does not reduce to <= 4096, or its low-pass is longer than the span the vector kernel
+   stages per tile and the matrix-core form does not fit either (HQ: down / up > ~43, e.g. 768 kHz -> 16 kHz).  The
+   reference resamples any rate (librosa.resample, src/stream/worker.py:128); such a file has to be decimated in two steps. */
+BD_API int bd_resample_supported(int32_t rate_in, int32_t rate_out, int32_t quality);
 BD_API int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t channels, int32_t rate_in,
                        int32_t rate_out, float* out_dev, void* stream);
 /* the same from 16-bit PCM (value / 32768, libsndfile's float convention): half the PCIe bytes; with
@@ -253,8 +258,10 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    layer's stride-2 depthwise in their epilogue, so depthwise 5, 7 and 13 have no launch of
                    their own, and layer 14 average-pools in its epilogue (layer 4 + depthwise 5 run a window per
                    workgroup, l4_window_kernel), and layers 8-11 (one shape, windows independent) are ONE launch
-                   in which every workgroup takes its four windows through the four layers (timed in layer 11's
-                   pointwise slot).  2: the same with layer 4 as overlapping band tiles of the generic kernel (test
+                   in which every workgroup takes its four windows through the four layers with the tiles between the
+                   layers kept on the CU - accumulators -> depthwise in registers -> LDS ring, sepchip.hip - so that only
+                   the run's input and output touch global memory (timed in layer 11's pointwise slot).  7: as 1 with the
+                   round-3 form of that launch, which hands the tiles over through global memory (test hook).  2: the same with layer 4 as overlapping band tiles of the generic kernel (test
                    hook).  3: as 1 with one launch per layer for layers 8-11 (test hook).  4: as 1 with layer 12 on the
                    8-wave kernel (256-column tiles) instead of the 12-wave one (test hook).  5: as 1 with layer 14 + pool on the
                    8-wave kernel (four 256-column tiles on all CUs: faster alone, slower in a full pipeline) instead of the

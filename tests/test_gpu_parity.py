@@ -371,7 +371,8 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
 
 @pytest.mark.parametrize("windows", [1, 4, 5, 131, 1025])
 def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, windows):
-    """Default path: every workgroup of the 12-wave kernel takes its four windows through layers 8-11 in ONE launch (each
+    """Default path: every workgroup takes its four windows through layers 8-11 in ONE launch with the tiles between the
+    layers kept on the CU (sepchip.hip: accumulators -> depthwise in registers -> LDS ring); hook 7: the round-3 form (each
     layer's output written to the other buffer and read back by the same workgroup).  Against one launch per layer
     (bd_set_fusion separable = 3): the same bits, in both f16 modes, whole and partial tiles, first and last workgroup."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=800 + windows)
@@ -381,7 +382,7 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
             engine.set_fusion(True, 3)
             ref_logits = engine.predict(x, 0.96).numpy()
             ref_emb = engine.embed(x, 0.96).numpy()
-            for hook in (4, 5):                  # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel
+            for hook in (4, 5, 7):               # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel
                 engine.set_fusion(True, hook)
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), (mode, hook)
                 assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), (mode, hook)
@@ -807,11 +808,12 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
             assert np.array_equal(engine.predict(x, 0.96).numpy(), ref), code
             assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), code
             assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half), code
-        engine.set_fusion(True, 6)
         assert ref.shape == (windows, 13)
-        assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)
-        assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb)
-        assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half)
+        for stem in (True, False, 2):              # stem 0 / 2 with 6: conv1 writes the SMALL buffer and the two swap roles
+            engine.set_fusion(stem, 6)
+            assert np.array_equal(engine.predict(x, 0.96).numpy(), ref), stem
+            assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), stem
+            assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half), stem
     finally:
         engine.set_fusion(True, True)
         engine.set_pointwise_mode("f16x3")

@@ -140,6 +140,68 @@ def test_torch_restatement_agrees_with_numpy_oracle(weights_bundle, hop, step):
     assert np.abs(t32 - ref).max() < 1e-4
 
 
+def _stft_magnitude_by_dft_matrix(wave_padded: np.ndarray, dtype) -> np.ndarray:
+    """The reference's OWN TensorFlow-free definition of |STFT| (embedders/yamnet/features.py:111-165, the `tflite_compatible`
+    branch), restated in NumPy: Hann sampled as 0.5 - 0.5 cos(2 pi t) on t = arange(0, 1, 1/400) (:115-119), each 400-sample
+    frame zero-padded to 512 on BOTH sides (56 + 56, :141-151), multiplied by the first 257 columns of the full
+    exp(+2 pi i j k / 512) matrix (:121-136, :152-153), magnitude as sqrt(re^2 + im^2) (:155-156).  The main branch
+    (features.py:42-46) pads on the right only and uses exp(-...): a circular shift and a conjugation, neither of which
+    changes a magnitude - which is why the two branches of the reference agree, and why this pins the oracle's."""
+    t = np.arange(0, 1.0, 1.0 / O.STFT_WINDOW)
+    assert t.shape == (O.STFT_WINDOW,)
+    window = (0.5 - 0.5 * np.cos(2 * np.pi * t)).astype(dtype)
+    n_frames = 1 + (wave_padded.shape[0] - O.STFT_WINDOW) // O.STFT_HOP
+    frames = wave_padded.astype(dtype)[(np.arange(n_frames) * O.STFT_HOP)[:, None] + np.arange(O.STFT_WINDOW)[None, :]]
+    frames = frames * window[None, :]
+    half_pad = (O.FFT_LENGTH - O.STFT_WINDOW) // 2
+    frames = np.pad(frames, ((0, 0), (half_pad, O.FFT_LENGTH - O.STFT_WINDOW - half_pad)))
+    jk = np.outer(np.arange(O.FFT_LENGTH), np.arange(O.FFT_LENGTH // 2 + 1))
+    dft = np.exp(2j * np.pi * jk / float(O.FFT_LENGTH))
+    re = frames @ np.real(dft).astype(dtype)
+    im = frames @ np.imag(dft).astype(dtype)
+    return np.sqrt(re * re + im * im)
+
+
+def test_front_end_matches_the_references_tf_free_stft_definition(weights_bundle):
+    """Row (c) of SURVEY 8: the VALUES of the front end have no reference-held vector, but its DEFINITION does exist in the
+    reference as plain NumPy constants + two matmuls (features.py:111-165).  The oracle's rfft-based log-mel must agree with
+    that definition to float64 round-off, and in float32 within the bound the device is held to (5e-5)."""
+    mel = weights_bundle["mel"]
+    x = O.pad_waveform(O.synthetic_audio(15360 * 3, seed=77), 15360)       # 3 windows = 288 frames
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, 5e-5)):
+        mag = _stft_magnitude_by_dft_matrix(x, dtype)
+        assert mag.shape == (288, 257)
+        ref = np.log(mag @ mel.astype(dtype) + dtype(O.LOG_OFFSET))
+        got = O.log_mel(x, mel, dtype=dtype)
+        assert got.shape == ref.shape == (288, 64)
+        assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() < tol, dtype
+    # the float32 oracle against the float64 DEFINITION (what the device's 5e-5 is measured from)
+    ref64 = np.log(_stft_magnitude_by_dft_matrix(x, np.float64) @ mel.astype(np.float64) + O.LOG_OFFSET)
+    assert np.abs(O.log_mel(x, mel, dtype=np.float32).astype(np.float64) - ref64).max() < 5e-5
+    # the window: arange(0, 1, 1/400) and 2 pi k / 400 are the same periodic Hann to float32 round-off (the oracle evaluates the graph's float32 op chain: two ulps)
+    t = np.arange(0, 1.0, 1.0 / O.STFT_WINDOW)
+    assert np.abs((0.5 - 0.5 * np.cos(2 * np.pi * t)).astype(np.float32) - O.hann_periodic(np.float32)).max() < 3e-7
+
+
+def test_torch_second_opinion_on_a_full_batch(weights_bundle):
+    """The torch-CPU restatement (F.conv2d, torch.stft) against the NumPy oracle at a full 1024-window batch in float32: two
+    independent CPU implementations of the same path agree within the gate the device is held to."""
+    torch = pytest.importorskip("torch")
+    from oracle.torch_baseline import TorchYamnet
+    b = weights_bundle
+    x = O.synthetic_audio(15360 * 1023 + 15600, seed=1024)
+    tm = TorchYamnet(b["blob"], b["mel"], b["head_kernel"], b["head_bias"], dtype=torch.float32)
+    got = tm.predict(x, 15360, 96)
+    assert got.shape == (1024, 13)
+    idx = np.r_[0:8, 500:508, 1016:1024]                      # the NumPy oracle on the first, middle and last windows
+    for w in (0, 500, 1016):
+        seg = x[w * 15360: (w + 7) * 15360 + 15600]
+        ref = O.predict(seg, b["blob"], b["mel"], b["head_kernel"], b["head_bias"], 15360, 96, np.float64)
+        assert ref.shape == (8, 13)
+        assert np.abs(got[w:w + 8] - ref).max() < 1e-4, w
+    assert np.isfinite(got).all() and idx.size == 24
+
+
 def test_same_padding_is_asymmetric_for_stride_2():
     assert O._same_pad(96, 3, 2) == (48, 0, 1)
     assert O._same_pad(64, 3, 2) == (32, 0, 1)

@@ -75,6 +75,23 @@ def test_library_designs_the_same_filter(quality):
     assert lib.bd_resample_taps(48000, 16000, 7, None, 0, C.byref(up), C.byref(down), C.byref(half)) < 0
 
 
+def test_ratios_whose_filter_outgrows_the_staged_span_are_refused_not_overrun():
+    """with the HQ filter (~189 max(up, down) taps) a ratio that does not fit the matrix kernel goes to
+    resample_kernel, which stages one tile's input span in 8192 floats of LDS; beyond down / up ~ 43 not even a one-output
+    tile fits and the kernel used to stage past the array.  Such ratios are refused (host-side predicate, no GPU needed);
+    everything the tests and the bench use stays supported."""
+    from buzzdetect_amd import _lib
+    lib = _lib.load()
+    for rate_in in (48000, 32000, 44100, 96000, 22050, 24000, 12000, 8000, 16000, 192000, 11025):
+        assert lib.bd_resample_supported(rate_in, 16000, QUALITY_CODE["hq"]) == 1, rate_in
+        assert lib.bd_resample_supported(rate_in, 16000, QUALITY_CODE["scipy"]) == 1, rate_in
+    assert lib.bd_resample_supported(768000, 16000, QUALITY_CODE["hq"]) == 0        # 48 : 1, 18 000 taps: span 18 196 > 8192
+    assert lib.bd_resample_supported(1024000, 16000, QUALITY_CODE["hq"]) == 0
+    assert lib.bd_resample_supported(768000, 16000, QUALITY_CODE["scipy"]) == 1     # the 61-tap-class filter: 960 taps
+    assert lib.bd_resample_supported(16000 * 4099, 16000, QUALITY_CODE["hq"]) == 0  # ratio does not reduce to <= 4096
+    assert lib.bd_resample_supported(0, 16000, 1) < 0 and lib.bd_resample_supported(48000, 16000, 7) < 0
+
+
 def _fir_plan(rate_in):
     from buzzdetect_amd import _lib
     lib = _lib.load()

@@ -117,6 +117,34 @@ def test_raw_payload_and_env_variable(no_sources, tmp_path, monkeypatch):
         W.load_embedder_blob(str(short))
 
 
+def test_raw_payload_without_an_index_is_checked_and_said_out_loud(no_sources, tmp_path, caplog):
+    """without variables.index the file is ASSUMED to be the blob - any 12.9 MB file used to pass.  Now: a WARNING,
+    and the file must have the payload's size (+ a small object-graph tail), finite values and positive BatchNorm variances."""
+    good = W.synthetic_embedder_blob(seed=7)
+    path = tmp_path / W.VARIABLES_DATA
+    with open(path, "wb") as f:
+        f.write(good.astype("<f4").tobytes() + b"\0" * 4096)                # payload + a tail, as a real shard has
+    with caplog.at_level(logging.WARNING, logger="buzzdetect"):
+        assert np.array_equal(W.read_variables(str(path)), good)
+    assert any("no variables.index" in r.getMessage() and r.levelno == logging.WARNING for r in caplog.records)
+    big = tmp_path / "unrelated.bin"
+    with open(big, "wb") as f:
+        f.write(good.astype("<f4").tobytes() + b"\0" * (W.RAW_TAIL_MAX + 4))
+    with pytest.raises(ValueError, match="without a variables.index"):
+        W.read_variables(str(big))
+    name, shape, off = next(t for t in W.expected_table() if t[0].endswith("moving_variance"))
+    bad = good.copy()
+    bad[off + 3] = -0.25                                                    # e.g. a re-ordered bundle: a beta where a variance belongs
+    bad.astype("<f4").tofile(tmp_path / "reordered.bin")
+    with pytest.raises(ValueError, match="moving_variance"):
+        W.read_variables(str(tmp_path / "reordered.bin"))
+    bad = good.copy()
+    bad[12345] = np.nan
+    bad.astype("<f4").tofile(tmp_path / "nan.bin")
+    with pytest.raises(ValueError, match="non-finite"):
+        W.read_variables(str(tmp_path / "nan.bin"))
+
+
 def test_index_with_a_wrong_shape_is_refused(no_sources, tmp_path):
     t = _bundle_tensors(np.zeros(W.EMBEDDER_BLOB_FLOATS, np.float32))
     key = "layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE"
