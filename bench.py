@@ -48,6 +48,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: dense f1
 PEAK_SPLIT_F16_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # ... / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC_STRICT_FILE = os.path.join("profiles", "r05_pmc_traffic_strict_f32.json")
 # What the board's 1400 W limit leaves of the paper peak: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, constant operands,
 # held for 3 s, settles at 1987 TFLOP/s (2.0 GHz, 1345 W) - tools/ubench_power.hip, profiles/r03_ubench_power.txt.  The headline
 # loop itself runs AT the limit (the `power` object of the line), so this is the ceiling its matrix work is priced against in
@@ -60,7 +61,7 @@ _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 
         (1, 512), (1, 512), (2, 1024), (1, 1024))
 
 
-def slot_plan(launches, pool_fused=True):
+def slot_plan(launches, pool_fused=True, chip=True):
     """Map the 29 profile slots to (slot name, kernel family, per-window algorithmic bytes, per-window flops)
     for the launches that actually happened (fused kernels are timed in the pointwise slot of their layer)."""
     plan = {0: ("frontend", "logmel_kernel", FRONTEND_BYTES_PER_WINDOW, 0)}
@@ -75,8 +76,8 @@ def slot_plan(launches, pool_fused=True):
         dw = ((h * w * c + ho * wo * c) * 4, 2 * 9 * ho * wo * c)
         pw = ((ho * wo * c + ho * wo * cout) * 4, 2 * ho * wo * c * cout)
         if stride == 1 and c == 512 and cout == 512 and launches[dw_slot] == 0 and launches[pw_slot] == 0 and launches[0] > 0:
-            # timed (and launched) with the last layer of its run: every layer of the run still stores its output and
-            # reads it back as the next layer's slabs
+            # timed (and launched) with the last layer of its run (round-3 form, --sep-variant 7: every layer of the run still
+            # stores its output and reads it back as the next layer's slabs; default: sepchip.hip keeps them on the CU)
             run = run or [layer, 0, 0]
             run[1] += (h * w * c + ho * wo * cout) * 4
             run[2] += dw[1] + pw[1]
@@ -120,7 +121,10 @@ def slot_plan(launches, pool_fused=True):
                     # (12-wave kernel, two 512-column halves per row tile: cnn.hip launch_separable_fused_pool)
                     plan[pw_slot] = ("sep14+pool", "sep_w12_ndw_kernel", (h * w * c + cout) * 4, dw[1] + pw[1] + ho * wo * cout)
                 elif run and fam == "sep_w12_kernel":
-                    plan[pw_slot] = (f"sep{run[0]}-{layer}", fam, run[1] + (h * w * c + ho * wo * cout) * 4, run[2] + dw[1] + pw[1])
+                    if chip:       # sepchip.hip: the tiles between the run's layers stay on the CU - its input in, its output out
+                        plan[pw_slot] = (f"sep{run[0]}-{layer}", "sep_chip_kernel", (h * w * c + ho * wo * cout) * 4, run[2] + dw[1] + pw[1])
+                    else:
+                        plan[pw_slot] = (f"sep{run[0]}-{layer}", fam, run[1] + (h * w * c + ho * wo * cout) * 4, run[2] + dw[1] + pw[1])
                     run = None
                 else:
                     plan[pw_slot] = (f"sep{layer}", fam, (h * w * c + ho * wo * cout) * 4, dw[1] + pw[1])
@@ -130,6 +134,42 @@ def slot_plan(launches, pool_fused=True):
     else:
         plan[28] = ("pool_head", "pool_head_kernel", (6 * 1024 + 13) * 4, 2 * 1024 * 13)
     return plan
+
+
+def slot_plan_f32(launches):
+    """The exact-f32 mode's default launch set (bd_set_pointwise_mode 0, bd_set_fusion 3 / 1): slot -> (name, kernel, per-window
+    algorithmic bytes, per-window flops).  Layers 1-3 are stem3_f32_kernel (slot 5), layer 4 + depthwise 5 l4_f32_kernel
+    (slot 7); from layer 5 on every 1x1 convolution is pointwise_kernel with the NEXT layer's depthwise in its epilogue
+    (timed in its own pointwise slot: depthwise-L output in, depthwise-(L+1) output out), layer 14 with the average pool."""
+    plan = {0: ("frontend", "logmel_kernel", FRONTEND_BYTES_PER_WINDOW, 0)}
+    dims = []                      # per layer 2..14: (h_in, w_in, c_in, h_out, w_out, c_out)
+    h, w, c = 48, 32, 32
+    for stride, cout in _DEF[1:]:
+        dims.append((h, w, c, h // stride, w // stride, cout))
+        h, w, c = h // stride, w // stride, cout
+    dw_fl = lambda d: 2 * 9 * d[3] * d[4] * d[2]              # noqa: E731
+    pw_fl = lambda d: 2 * d[3] * d[4] * d[2] * d[5]           # noqa: E731
+    conv1_fl = 2 * 9 * 48 * 32 * 32
+    if launches[5] > 0 and launches[1] == 0:
+        d2, d3 = dims[0], dims[1]
+        plan[5] = ("stem(1-3)", "stem3_f32_kernel", 96 * 64 * 4 + d3[3] * d3[4] * d3[5] * 4,
+                   conv1_fl + dw_fl(d2) + pw_fl(d2) + dw_fl(d3) + pw_fl(d3))
+    if launches[7] > 0 and launches[6] == 0:
+        d4, d5 = dims[2], dims[3]
+        plan[7] = ("sep4+dw5", "l4_f32_kernel", (d4[0] * d4[1] * d4[2] + d5[3] * d5[4] * d5[2]) * 4, dw_fl(d4) + pw_fl(d4) + dw_fl(d5))
+    for layer in range(5, 15):
+        d = dims[layer - 2]
+        slot = 2 * layer - 1
+        if launches[slot] == 0 or launches[slot - 1] > 0:
+            continue
+        rows_in = d[3] * d[4] * d[2] * 4
+        if layer == 14:
+            plan[slot] = ("pw14+pool", "pointwise_kernel", rows_in + d[5] * 4, pw_fl(d) + d[3] * d[4] * d[5])
+        else:
+            n = dims[layer - 1]
+            plan[slot] = (f"pw{layer}+dw{layer + 1}", "pointwise_kernel", rows_in + n[3] * n[4] * n[2] * 4, pw_fl(d) + dw_fl(n))
+    plan[28] = ("head", "pool_head_kernel", (1024 + 13) * 4, 2 * 1024 * 13)
+    return {k: v for k, v in plan.items() if launches[k] > 0}
 
 
 def log(msg: str) -> None:
@@ -376,9 +416,10 @@ def h2d_leg(engine, streams, device, hop: int, framehop_s: float, batches: int, 
     return round(rate, 1), round(batches * n * (2 if s16 else 4) / sec / 1e9, 2)
 
 
-def analyze_leg(device_index: int, hours: int, chunklength: float, framehop_prop: float, engines=None):
-    """analyze() file -> CSV over one generated 16-bit mono WAV of `hours` h on tmpfs; audio-seconds per second
-    (the reference's own rate definition, src/inference/worker.py:54-62, over the whole run)."""
+def analyze_leg(device_index: int, hours: int, chunklength: float, framehop_prop: float, engines=None, files: int = 1):
+    """analyze() files -> CSV over `files` generated 16-bit mono WAVs of `hours` h each on tmpfs, in ONE call; audio-seconds
+    per second (the reference's own rate definition, src/inference/worker.py:54-62, over the whole run) and the wall
+    seconds each stage of the feeder spent working (Report.busy)."""
     import shutil
     import tempfile
     import wave
@@ -391,26 +432,32 @@ def analyze_leg(device_index: int, hours: int, chunklength: float, framehop_prop
         os.makedirs(audio)
         hour = synthetic_audio(torch.device("cuda", device_index), FILE_SAMPLES, 4242)
         block = (hour * 32768.0).round().clamp_(-32768, 32767).to(torch.int16).cpu().numpy().astype("<i2").tobytes()
-        with wave.open(os.path.join(audio, f"synthetic_{hours}h.wav"), "wb") as w:
-            w.setnchannels(1)
-            w.setsampwidth(2)
-            w.setframerate(SAMPLE_RATE)
-            for _ in range(hours):
-                w.writeframes(block)
+        for i in range(files):
+            with wave.open(os.path.join(audio, f"synthetic_{hours}h_{i:03d}.wav"), "wb") as w:
+                w.setnchannels(1)
+                w.setsampwidth(2)
+                w.setframerate(SAMPLE_RATE)
+                for _ in range(hours):
+                    w.writeframes(block)
         del block, hour
-        secs = []
+        secs, busy = [], []
         for call in range(2):      # the first call pins its staging buffers (host allocator cold), the second is the sustained rate
             t0 = time.perf_counter()
             rep = analyze("model_general_v3", classes_out="all", framehop_prop=framehop_prop, chunklength=chunklength,
                           dir_audio=audio, dir_out=f"{out}{call}", embeddername="yamnet_k2", engines=engines, rank=0, world_size=1)
             secs.append(time.perf_counter() - t0)
-            assert rep.files_done == 1, rep
+            busy.append({k: round(v, 4) for k, v in sorted(getattr(rep, "busy", {}).items())})
+            assert rep.files_done == files, rep
+            shutil.rmtree(f"{out}{call}", ignore_errors=True)
         sec = secs[0]
-        return {"audio_s_per_s": round(rep.audio_seconds / sec, 1), "windows_per_s": round(rep.windows / sec, 1),
+        return {"files": files, "hours_each": hours, "chunklength_s": chunklength, "framehop_prop": framehop_prop,
+                "audio_s_per_s": round(rep.audio_seconds / sec, 1), "windows_per_s": round(rep.windows / sec, 1),
                 "seconds": round(sec, 3), "windows": rep.windows, "chunks": rep.chunks,
-                "pcm_GBps_s16": round(rep.audio_seconds * SAMPLE_RATE * 2 / sec / 1e9, 3),
+                "pcm_GBps_s16": round(rep.audio_seconds * SAMPLE_RATE * 2 / sec / 1e9, 3), "stage_busy_s": busy[0],
                 "second_call": {"audio_s_per_s": round(rep.audio_seconds / secs[1], 1),
-                                "windows_per_s": round(rep.windows / secs[1], 1), "seconds": round(secs[1], 3)}}
+                                "windows_per_s": round(rep.windows / secs[1], 1), "seconds": round(secs[1], 3),
+                                "pcm_GBps_s16": round(rep.audio_seconds * SAMPLE_RATE * 2 / secs[1] / 1e9, 3),
+                                "stage_busy_s": busy[1]}}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -434,6 +481,9 @@ def main() -> int:
                          "with four streams and four batches per recording every stream sees the same batch of every recording "
                          "and the streams run in lock-step (1.63 vs 1.66 M windows/s, DESIGN.md 7)")
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable layers: 9 = 8-wave kernel only, 12 = with the 12-wave kernel (no epilogue fusion; tuning)")
+    ap.add_argument("--pointwise-mode", choices=["f16x3", "f32", "f16"], default=None,
+                    help="profiling only: run the WHOLE bench in this arithmetic mode (the line then carries mode_override; "
+                         "the driver's headline never uses it)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     ap.add_argument("--files-per-step", type=int, default=FILES_PER_STEP,
@@ -483,6 +533,8 @@ def main() -> int:
             e.set_group_windows(args.group_windows)
         if args.sep_variant is not None:
             e.set_fusion(True, args.sep_variant)
+        if args.pointwise_mode is not None:
+            e.set_pointwise_mode(args.pointwise_mode)
         if args.pw_variant is not None:
             for layer in range(5, 15):
                 e.set_pointwise_variant(layer, args.pw_variant)
@@ -643,6 +695,36 @@ def main() -> int:
         engine.profile_enable(False)
         ms, launches = engine.profile_read()
 
+    # region 3 (single GPU): `value`'s workload once more with every product an exact f32 product - the reference's own
+    # precision.  The SAME run_files() loop (50 distinct recordings per step as 1024/1024/1024/678-window batches, three
+    # analyzer streams, one read-back per step), then the same kernel-event region, in the exact-f32 mode.
+    strict = None
+    if world == 1 and not args.no_extras and "f32" in getattr(engine, "POINTWISE_MODES", ()):
+        strict_steps = max(5, min(args.steps, 8))
+        for e in engines:
+            e.set_pointwise_mode("f32")
+        try:
+            run_files(1)
+            read_back.update(batches=0, rows=0, nonfinite=0)
+            s_elapsed = timed_region(strict_steps)
+            strict = {"value": round(windows_per_step * strict_steps / s_elapsed, 1), "steps": strict_steps,
+                      "ms_per_step": round(1e3 * s_elapsed / strict_steps, 4), "read_back": dict(read_back)}
+            log(f"exact-f32 mode, same loop: {strict['value']:.0f} windows/s ({strict['ms_per_step']:.3f} ms/step, {strict_steps} steps)")
+            if events_on:
+                engine.profile_read()
+                engine.profile_enable(True)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(streams[0]):
+                    for i in range(ev_steps):
+                        for first, n in batches:
+                            engine.predict(files[i % len(files)][first:first + n], framehop_s)
+                torch.cuda.synchronize()
+                engine.profile_enable(False)
+                strict["ms"], strict["launches"] = engine.profile_read()
+        finally:
+            for e in engines:
+                e.set_pointwise_mode("f16x3")
+
     rc = 0
     if rank == 0:
         out = {
@@ -679,6 +761,8 @@ def main() -> int:
                        "timing": "value from K clean steps; per-kernel HIP-event times from a second region "
                                  f"({ev_steps} recordings, one stream)"},
         }
+        if args.pointwise_mode is not None:
+            out["mode_override"] = args.pointwise_mode
         if ranks_seen is not None:
             out["ranks_seen"] = ranks_seen
             out["ranks_seen_note"] = ("counted on rank 0 from the gathered blocks of the timed region: rounds in which the block "
@@ -689,7 +773,7 @@ def main() -> int:
             out["power"] = power
             log(f"board power {power['avg_W']} W of {power['cap_W']} W, shader clock {power['sclk_MHz_avg']} MHz")
         if events_on and launches.sum() > 0 and args.per_slot:
-            for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches, pool_fused=args.sep_variant is None).items()):
+            for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None).items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
                 wl = windows_per_file * ev_steps / max(int(launches[slot]), 1)     # windows per launch on average
                 log(f"slot {slot:2d} {nm:10s} {fam:24s} {us:8.1f} us  {nb * wl / us / 1e6:6.2f} TB/s  "
@@ -698,7 +782,7 @@ def main() -> int:
             out["ms_per_recording_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
             out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * files_per_step), 4)
             fams = {}
-            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant is None).items():
+            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                 f["ms"] += ms[slot]
                 f["launches"] += int(launches[slot])
@@ -708,7 +792,7 @@ def main() -> int:
             total_ms = float(ms.sum())
             # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise (layer 12) or the
             #  average pool (layer 14) in the epilogue)
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_w12_ndw_kernel", "stem3_kernel",
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_w12_ndw_kernel", "stem3_kernel",
                          "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
@@ -762,6 +846,53 @@ def main() -> int:
                                "TFLOPs_algorithmic": round(k["flops"] / sec / 1e12, 2)}
             out["stages"] = stages
 
+        if strict is not None:
+            out["value_strict_f32"] = strict["value"]
+            out["strict_f32"] = {"value": strict["value"], "unit": "windows/s", "steps": strict["steps"],
+                                 "ms_per_step": strict["ms_per_step"], "timed_read_back": strict["read_back"],
+                                 "workload": out["config"]["workload"],
+                                 "what": "`value`'s workload and loop (run_files: the same recordings, batches, analyzer streams and "
+                                         "per-step read-back) with bd_set_pointwise_mode 0: every 1x1-convolution product on "
+                                         "v_mfma_f32_32x32x2_f32, exact f32 products"}
+            tfw = strict["value"] * CNN_FLOP_PER_WINDOW / 1e12
+            out["strict_f32"]["pipeline_frac"] = round(tfw / PEAK_F32_MFMA_TFLOPS, 4)
+            if "ms" in strict and strict["launches"].sum() > 0:
+                sms, sl = strict["ms"], strict["launches"]
+                sf = {}
+                for slot, (nm, fam, nb, fl) in slot_plan_f32(sl).items():
+                    f = sf.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
+                    f["ms"] += sms[slot]
+                    f["launches"] += int(sl[slot])
+                    f["bytes"] += nb * windows_per_file * ev_steps
+                    f["flops"] += fl * windows_per_file * ev_steps
+                    f["slots"].append(nm)
+                    if args.per_slot:
+                        us = 1e3 * sms[slot] / max(int(sl[slot]), 1)
+                        wl = windows_per_file * ev_steps / max(int(sl[slot]), 1)
+                        log(f"f32 slot {slot:2d} {nm:12s} {fam:20s} {us:8.1f} us  {fl * wl / us / 1e6:7.1f} TFLOP/s")
+                sdom = max(sf, key=lambda k: sf[k]["ms"])
+                d = sf[sdom]
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                out["roofline_strict"] = {
+                    "kernel": f"{sdom} ({', '.join(d['slots'])})", "bound": "mfma", "achieved": round(ach, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2), "launches": d["launches"],
+                    "flop_per_launch_avg": d["flops"] // d["launches"], "bytes_per_launch_avg": d["bytes"] // d["launches"],
+                    "share_of_step_time": round(d["ms"] / float(sms.sum()), 4),
+                    "peak_note": "v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md); achieved = algorithmic FLOP of the 1x1 "
+                                 "convolutions + the depthwise in their epilogues over HIP-event time of their launches",
+                    "stages": {fam: {"slots": k["slots"], "ms_per_recording": round(k["ms"] / ev_steps, 4),
+                                     "share": round(k["ms"] / float(sms.sum()), 4),
+                                     "TFLOPs_algorithmic": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)}
+                               for fam, k in sorted(sf.items(), key=lambda kv: -kv[1]["ms"])}}
+                try:
+                    with open(os.path.join(REPO, PMC_TRAFFIC_STRICT_FILE)) as f:
+                        pmc = json.load(f)["per_kernel_family"].get(sdom)
+                    if pmc:
+                        out["roofline_strict"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                        out["roofline_strict"]["traffic_source"] = PMC_TRAFFIC_STRICT_FILE
+                except (OSError, ValueError, KeyError):
+                    pass
         if world == 1 and not args.no_extras:
             try:
                 extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s)
@@ -862,12 +993,16 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
     del x_fe, lm
 
     legs = {}
-    for name, hours, chunk, hp in (("config2_1h_hop1.0", 1, WINDOWS_PER_BATCH * FRAMELENGTH_S, 1.0),
-                                   ("config3_24h_600s_hop1.0", 24, 600.0, 1.0),
-                                   ("config3_24h_600s_hop0.5", 24, 600.0, 0.5)):
-        legs[name] = analyze_leg(dev_index, hours, chunk, hp, engines=engines[:2])
+    for name, hours, chunk, hp, nfiles in (("config2_1h_hop1.0", 1, WINDOWS_PER_BATCH * FRAMELENGTH_S, 1.0, 1),
+                                           ("config3_24h_600s_hop1.0", 24, 600.0, 1.0, 1),
+                                           ("config3_24h_600s_hop0.5", 24, 600.0, 0.5, 1),
+                                           # config 4's single-rank share in shape: many one-hour recordings in one call
+                                           ("config4_share_50x1h_hop1.0", 1, WINDOWS_PER_BATCH * FRAMELENGTH_S, 1.0, 50),
+                                           ("config4_share_50x1h_hop0.5", 1, 600.0, 0.5, 50)):
+        legs[name] = analyze_leg(dev_index, hours, chunk, hp, engines=engines[:2], files=nfiles)
         log(f"analyze() {name}: {legs[name]['audio_s_per_s']:.0f} audio-s/s, {legs[name]['windows_per_s']:.0f} windows/s "
-            f"(second call: {legs[name]['second_call']['audio_s_per_s']:.0f} audio-s/s)")
+            f"(second call: {legs[name]['second_call']['audio_s_per_s']:.0f} audio-s/s, {legs[name]['second_call']['windows_per_s']:.0f} "
+            f"windows/s); busy {legs[name]['second_call']['stage_busy_s']}")
     one, day = legs["config2_1h_hop1.0"], legs["config3_24h_600s_hop1.0"]
     if day["seconds"] > one["seconds"]:
         # both calls pay the same fixed cost (threads, planning, the last recording's sorted rewrite): the difference is
@@ -968,8 +1103,10 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
     for e in engines:
         e.set_pointwise_mode("f16x3")
     if "f32" in modes:
-        out["value_mode0_f32"] = {**modes["f32"], "what": "1x1 convolutions on v_mfma_f32_32x32x2_f32 (exact f32 products)"}
-        out["value_strict_f32"] = modes["f32"]["value"]
+        out["value_mode0_f32"] = {**modes["f32"], "what": "1x1 convolutions on v_mfma_f32_32x32x2_f32 (exact f32 products); k x ONE "
+                                                          "repeated 1024-window batch, no read-back (value_strict_f32 is the headline loop)"}
+        if out.get("value_strict_f32") is None:
+            out["value_strict_f32"] = modes["f32"]["value"]
         # the same mode with every separable layer as one kernel (bd_set_fusion separable = 6, sepf32.hip): bit-identical rows,
         # the depthwise output never in HBM; selectable, not the default (it loses a few % on three streams)
         for e in engines:

@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 EMBEDDER_BLOB_FLOATS = 3_217_344
 EMBEDDING_SIZE = 1024
 MEL_BANDS = 64
@@ -53,6 +53,8 @@ PROTOTYPES = {
     "bd_resample_taps": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bd_set_resample_quality": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bd_format_rows": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_int64]),
     "bd_resample_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "bd_debug_fir_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "bd_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

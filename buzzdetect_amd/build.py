@@ -18,7 +18,13 @@ import tempfile
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libbuzzdetect_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ("engine.hip", "frontend.hip", "resample.hip", "sepf32.hip", "sepchip.hip", "cnn.hip")
+SOURCES = ("engine.hip", "frontend.hip", "resample.hip", "sepf32.hip", "sepchip.hip", "cnn.hip", "rowfmt.hip")
+# extra compiler flags of single files (part of the source hash below, like the sources themselves)
+FILE_FLAGS = {
+    # sep_chip_kernel lives at the 256-register limit of two waves per SIMD: the default machine scheduler spills 4-28 of its
+    # long-lived values (address bases, pending tiles) depending on unrelated edits; the occupancy-driven one keeps them
+    "sepchip.hip": ("-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"),
+}
 HEADERS = ("bd_internal.h", os.path.join("..", "..", "include", "buzzdetect_hip.h"))
 ARCH = "gfx950"
 
@@ -35,6 +41,7 @@ STAMP_PATH = LIB_PATH + ".srchash"      # sha256 of the sources the library was 
 
 def source_hash() -> str:
     h = hashlib.sha256()
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read() + b"\0")
@@ -64,13 +71,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 return LIB_PATH
             fd, tmp = tempfile.mkstemp(prefix=LIB_NAME + ".", suffix=".tmp", dir=CSRC)
             os.close(fd)
-            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-                   "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-                   "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            objdir = tempfile.mkdtemp(prefix=".obj.", dir=CSRC)
+            common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+                      "-Wno-unused-function"]
+            jobs = [(common + ["-c", os.path.join(CSRC, s), "-o", os.path.join(objdir, s + ".o")] + list(FILE_FLAGS.get(s, ())))
+                    for s in SOURCES]
+            cmd = common + ["-shared", "-o", tmp] + [j[j.index("-o") + 1] for j in jobs]
             if verbose:
+                for j in jobs:
+                    print("[buzzdetect_amd.build]", " ".join(j), file=sys.stderr, flush=True)
                 print("[buzzdetect_amd.build]", " ".join(cmd), file=sys.stderr, flush=True)
             stamp = source_hash()
             try:
+                # one translation unit per process, side by side (the kernels are independent files), then one link
+                procs = [subprocess.Popen(j, stdout=sys.stderr) for j in jobs]
+                rcs = [p.wait() for p in procs]
+                if any(rcs):
+                    raise subprocess.CalledProcessError(next(r for r in rcs if r), jobs[[bool(r) for r in rcs].index(True)])
                 subprocess.run(cmd, check=True, stdout=sys.stderr)
                 os.chmod(tmp, 0o755)
                 with open(STAMP_PATH + ".tmp", "w") as f:
@@ -83,6 +100,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)
+                shutil.rmtree(objdir, ignore_errors=True)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH

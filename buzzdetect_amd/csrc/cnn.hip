@@ -3448,8 +3448,8 @@ int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int
     }
     const long long M = (long long)windows * 24;
     if (n < 2 || windows <= 0 || M >= (1LL << 31)) return 0;
-    if (on_chip) launch_separable_chip(a, (n & 1) ? b : a, windows, L, n, stream);      // sepchip.hip: only a and the result in HBM
-    else launch_sep_w12<96>(a, b, L, n, M, stream);
+    // sepchip.hip: only a and the result touch global memory
+    if (!on_chip || !launch_separable_chip(a, (n & 1) ? b : a, windows, L, n, stream)) launch_sep_w12<96>(a, b, L, n, M, stream);
     return n;
 }
 

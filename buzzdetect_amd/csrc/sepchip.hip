@@ -71,7 +71,7 @@ static_assert(sizeof(ChipChain) == 24 * 8, "six tables of four pointers");
 template <bool PLAIN, int NSLOT, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, const float* X, float* Y, int nl,
                                                            long long M, unsigned* __restrict__ range_flag,
-                                                           unsigned long long* __restrict__ dbg = nullptr) {
+                                                           unsigned long long* __restrict__ dbg = nullptr, int tune = 0) {
     static_assert(NSLOT >= 9 && NSLOT <= 16, "ring size");
     constexpr int K = 512, KQ = K / 16;
     constexpr int NPEND = 16 - NSLOT;              // stages that wait in registers; their owners are waves 8 - NPEND .. 7
@@ -92,32 +92,28 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
     }
     CHIP_TS()
 
-    // publisher: byte offset of this lane's k (= frow) in a row whose swizzle key is m; rows 48 fh + r' follow as immediates
-    int wb[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) wb[m] = fh * (48 * 64 + 64) + ((((frow >> 3) ^ m)) << 4) + 2 * (frow & 7);
-    // reader: lane (frow, fh) supplies A[row 32 i + frow][k = 16 s + 8 fh ..]; the key (row >> 2) & 3 is the same for all i
-    int ro[3][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int row = 32 * i + frow;
-            ro[i][s] = row * 64 + (row >= 48 ? 64 : 0) + ((((2 * s + fh) ^ ((frow >> 2) & 3))) << 4);
-        }
+    // publisher: lane (frow = k, fh) writes element k of rows 48 fh + r'.  Byte offset of k in a row whose swizzle key is m:
+    // (((k >> 3) ^ m) << 4) + 2 (k & 7) = wb0 ^ (m << 4) (bits 4-5 of everything else in wb0 are zero); rows follow as immediates
+    const int wb0 = fh * (48 * 64 + 64) + ((frow >> 3) << 4) + 2 * (frow & 7);
+    // reader: lane (frow, fh) supplies A[row 32 i + frow][k = 16 s + 8 fh ..] from slot (2 s + fh) ^ key, key = (row >> 2) & 3 =
+    // (frow >> 2) & 3 for every i; s = 1 is the s = 0 address with bit 5 flipped.  Row tile 2 is row tile 0 + 4096 + 64 (an
+    // immediate); row tile 1 straddles row 48 (the 64-byte skew starts at frow = 16) and keeps its own register.
+    const int ra0 = frow * 64 + ((fh ^ ((frow >> 2) & 3)) << 4);
+    const int ra1 = ra0 + 2048 + (frow >= 16 ? 64 : 0);
+    const unsigned lane16 = lane * 16, c4 = frow * 4;
 
     f32x16 acc[3][2];
-    unsigned pend[48];
+    unsigned pend[48], out0[48];
 
     // Depthwise 3 x 3 + shift + ReLU + split of column block J (stage ST) of the tile held as in2[y][x] = (window 2 fh,
     // window 2 fh + 1) at map position (y, x) of channel c: 48 outputs per lane, published into slot ST of the ring, or -
     // always for J = 1, only waves 8 - NPEND .. 7 use them - kept as packed (hi | lo << 16) dwords in pend[].
-#define CHIP_DW(J, ST, DW_W, DW_B)                                                                        \
+#define CHIP_DW(J, ST, TAPS)                                                                              \
     {                                                                                                     \
         float wt[9];                                                                                      \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = (DW_W)[t * K + 32 * (ST) + frow];           \
-        const float shift = (DW_B)[32 * (ST) + frow];                                                     \
-        char* const slot = sm + ((J) == 0 ? (ST) : 0) * kChipSlotBytes;                                   \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                     \
+            wt[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TAPS, c4, (t * K + 32 * (ST)) * 4, 0)); \
+        const float shift = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TAPS, c4, (9 * K + 32 * (ST)) * 4, 0)); \
         _Pragma("unroll") for (int y = 0; y < 6; ++y)                                                     \
             _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                               \
                 v2f a = {shift, shift};                                                                   \
@@ -129,45 +125,64 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
                     }                                                                                     \
                 _Pragma("unroll") for (int w = 0; w < 2; ++w) {                                           \
                     const float v = fmaxf(w ? a.y : a.x, 0.0f);                                           \
-                    rmax = fmaxf(rmax, v);                                                                \
                     unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v);              \
-                    asm("v_fma_mixhi_f16 %0, %0, -1.0, %1 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(pk) : "v"(v)); \
-                    const int rl = 24 * w + 4 * y + x;      /* row 48 fh + rl; key ((48 fh + rl) >> 2) & 3 */ \
+                    /* lo half = f16(v - hi) and the range guard's running maximum, in ONE ordered statement: as a plain */ \
+                    /* fmaxf chain the compiler sums the maxima up at the end and keeps (spills) all 48 values until then */ \
+                    asm volatile("v_fma_mixhi_f16 %0, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_max_f32 %1, %1, %2" \
+                                 : "+v"(pk), "+v"(rmax) : "v"(v));                                        \
+                    const int rl = 24 * w + 4 * y + x;      /* row 48 fh + rl */                          \
                     if ((J) == 1) pend[rl] = pk;                                                          \
-                    else CHIP_PUT(slot, rl, pk)                                                           \
+                    else out0[rl] = pk;                                                                   \
                 }                                                                                         \
             }                                                                                             \
-        if ((J) == 1 && (ST) < NSLOT) {           /* one wave-uniform branch */                           \
-            char* const slot1 = sm + (ST) * kChipSlotBytes;                                               \
+    }
+    // ... and their publication: column block 0 (stage wc) always, column block 1 (stage wc + 8) when its slot exists now
+#define CHIP_PUBLISH()                                                                                    \
+    {                                                                                                     \
+        int wbl = wb0;       /* the four swizzle variants of the address are formed per use: as values of the whole kernel */ \
+        asm volatile("" : "+v"(wbl));                      /* they were spilled and reloaded behind vmcnt(0) waits */ \
+        char* const slot0 = sm + wc * kChipSlotBytes;                                                     \
+        _Pragma("unroll") for (int rl = 0; rl < 48; ++rl) CHIP_PUT(slot0, rl, out0[rl])                   \
+        if (wc + 8 < NSLOT) {                     /* one wave-uniform branch */                           \
+            char* const slot1 = sm + (wc + 8) * kChipSlotBytes;                                           \
             _Pragma("unroll") for (int rl = 0; rl < 48; ++rl) CHIP_PUT(slot1, rl, pend[rl])               \
         }                                                                                                 \
     }
 #define CHIP_PUT(SLOT, RL, PK)                                                                            \
     {                                                                                                     \
-        char* const p_ = (SLOT) + wb[((RL) >> 2) & 3] + (RL) * 64;                                        \
+        char* const p_ = (SLOT) + (wbl ^ ((((RL) >> 2) & 3) << 4)) + (RL) * 64;                           \
         *reinterpret_cast<unsigned short*>(p_) = (unsigned short)(PK);                                    \
         *reinterpret_cast<unsigned short*>(p_ + kChipHalfBytes) = (unsigned short)((PK) >> 16);           \
     }
+    // taps [9][512] and shift [512] of a layer are one [10][512] table (engine.hip lays dw_b16 behind dw_w16; the launcher checks)
+#define CHIP_TAPS_RSRC(DW_W) __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DW_W), 0, 10 * K * 4, 0x00020000)
 
     // ---------------------------------------------------------------------- layer 0: its depthwise reads the run's input
+    // through a buffer resource that covers exactly this tile's valid rows: a row past the end of the batch (tail tile)
+    // reads as zero, with no clamping code, and every load is resource + one per-lane offset register + a scalar row offset
+    const long long rows_left = M - m0;
+    const unsigned tile_bytes = (unsigned)(rows_left < 96 ? rows_left : 96) * (K * 4);
+    {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (size_t)m0 * K, 0, tile_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t taps0 = CHIP_TAPS_RSRC(ch.dw_w[0]);
+        const unsigned xo = (48u * fh * K) * 4 + c4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int st = j ? wc + 8 : wc;
-        const int c = 32 * st + frow;
-        v2f in2[6][4];
+        for (int j = 0; j < 2; ++j) {
+            const int st = j ? wc + 8 : wc;
+            v2f in2[6][4];
 #pragma unroll
-        for (int y = 0; y < 6; ++y)
+            for (int y = 0; y < 6; ++y)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                long long ra = m0 + 48 * fh + 4 * y + x, rb = ra + 24;
-                ra = ra < M ? ra : M - 1;
-                rb = rb < M ? rb : M - 1;
-                in2[y][x].x = X[(size_t)ra * K + c];
-                in2[y][x].y = X[(size_t)rb * K + c];
-            }
-        if (j == 0) CHIP_DW(0, st, ch.dw_w[0], ch.dw_b[0])
-        else CHIP_DW(1, st, ch.dw_w[0], ch.dw_b[0])
-        CHIP_TS()
+                for (int x = 0; x < 4; ++x) {
+                    in2[y][x].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo, ((4 * y + x) * K + 32 * st) * 4, 0));
+                    in2[y][x].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo, ((24 + 4 * y + x) * K + 32 * st) * 4, 0));
+                }
+            if (j == 0) CHIP_DW(0, st, taps0)
+            else CHIP_DW(1, st, taps0)
+            CHIP_TS()
+            __builtin_amdgcn_sched_barrier(0);    // (the second block's 48 loads hoisted over the first's sums cost a spill)
+        }
+        CHIP_PUBLISH()
     }
 
     for (int li = 0; li < nl; ++li) {
@@ -177,58 +192,74 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
         CHIP_TS()
 
         // ------------------------------------------------------------------ 1 x 1 convolution of layer li
+        // (a zero the compiler cannot form early: as plain constants the 96 clears were hoisted above the barrier into the
+        //  depthwise phase, where the accumulators' registers are what its 96 results live in - 43 spills)
+        float zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        // B fragments: column tile (wc, wc + 8), k16 step q -> ((tile * KQ + q) * 64 + lane) * 8 halves
-        const _Float16* const wbh0 = Wfhi + ((size_t)wc * KQ * 64 + lane) * 8;
-        const _Float16* const wbl0 = Wflo + ((size_t)wc * KQ * 64 + lane) * 8;
-        constexpr int jstep = 8 * KQ * 512;       // halves between column tiles wc and wc + 8
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = zero;
+        // B fragments: column tile (wc, wc + 8), k16 step q -> ((tile * KQ + q) * 64 + lane) * 16 bytes: resource + lane * 16 in
+        // one register + a scalar offset
+        const __amdgpu_buffer_rsrc_t bhr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wfhi), 0, K * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t blr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wflo), 0, K * K * 2, 0x00020000);
+        const int btile = wc * (KQ * 1024);       // bytes of a column tile's fragments: KQ k16 steps of 1 KB
+        constexpr int jstep = 8 * KQ * 1024;      // bytes between column tiles wc and wc + 8
         f16x8 bh0[2], bl0[2], bh1[2], bl1[2];
-#define CHIP_BLOAD(BH, BL, Q)                                                                             \
-    {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
-            BH[j] = *reinterpret_cast<const f16x8*>(wbh0 + j * jstep + (Q) * 512);                        \
-            BL[j] = *reinterpret_cast<const f16x8*>(wbl0 + j * jstep + (Q) * 512);                        \
-        }                                                                                                 \
-    }
-#define CHIP_ALOAD(AH, AL, S, I)                                                                          \
-    {                                                                                                     \
-        AH = *reinterpret_cast<const f16x8*>(abase + ro[I][S]);                                           \
-        AL = *reinterpret_cast<const f16x8*>(abase + ro[I][S] + kChipHalfBytes);                          \
-    }
-#define CHIP_STEP(I, AH, AL, BH, BL)                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-        if constexpr (!PLAIN) {                                                                           \
-            acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH[j], acc[I][j], 0, 0, 0);            \
-            acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL[j], acc[I][j], 0, 0, 0);            \
-        }                                                                                                 \
-        acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH[j], acc[I][j], 0, 0, 0);                \
-    }
+        // ---- the K loop.  One stage = 6 steps (k16 step s = 0, 1 x row tile i = 0..2) of 6 MFMAs (2 in the plain-f16 mode).
+        // Every memory request sits in its own MFMA gap, pinned there by a scheduling barrier (left alone the compiler
+        // bunches the four B loads of a k16 step at the top of the stage - an in-order wave then issues no MFMA while they
+        // go out - and sinks the A reads to just before their use):
+        //   A fragments   a ring of three (hi, lo) pairs, step t uses pair t mod 3 and requests the pair of step t + 2 (the one
+        //                 step t - 1 has finished with): two steps = 12 MFMAs between request and use, across stages too;
+        //   B fragments   two sets (k16 step 0 / 1 of a stage); a register is requested again in the gap after the last MFMA
+        //                 that reads it, three steps = 18 MFMAs before its next use.
+#define CHIP_LB(R, B, Q, J) B[J] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(R, lane16, btile + (J) * jstep + (Q) * 1024, 0));
+#define CHIP_LAH(A, S, I) A = *reinterpret_cast<const f16x8*>(abase + (((I) == 1 ? ra1 : ra0) ^ ((S) << 5)) + ((I) == 2 ? 4096 + 64 : 0));
+#define CHIP_LAL(A, S, I) A = *reinterpret_cast<const f16x8*>(abase + (((I) == 1 ? ra1 : ra0) ^ ((S) << 5)) + ((I) == 2 ? 4096 + 64 : 0) + kChipHalfBytes);
+#define CHIP_MF(I, J, A, B) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[I][J], 0, 0, 0);
+#define CHIP_SB __builtin_amdgcn_sched_barrier(0);
+#define CHIP_NOP
+        // a step: row tile I against both column tiles; M1 .. M6 = the request (or nothing) that follows each MFMA
+#define CHIP_STEP(I, AH, AL, BH, BL, M1, M2, M3, M4, M5, M6)                                              \
+    if constexpr (!PLAIN) {                                                                               \
+        CHIP_MF(I, 0, AL, BH[0]) M1 CHIP_SB                                                               \
+        CHIP_MF(I, 0, AH, BL[0]) M2 CHIP_SB                                                               \
+    } else {                                                                                              \
+        M1 M2                                                                                             \
+    }                                                                                                     \
+    CHIP_MF(I, 0, AH, BH[0]) M3 CHIP_SB                                                                   \
+    if constexpr (!PLAIN) {                                                                               \
+        CHIP_MF(I, 1, AL, BH[1]) M4 CHIP_SB                                                               \
+        CHIP_MF(I, 1, AH, BL[1]) M5 CHIP_SB                                                               \
+    } else {                                                                                              \
+        M4 M5                                                                                             \
+    }                                                                                                     \
+    CHIP_MF(I, 1, AH, BH[1]) M6 CHIP_SB
 #define CHIP_STAGES(FROM, TO)                                                                             \
-    for (int kk = (FROM); kk < (TO); ++kk) {                                                              \
-        const char* const abase = sm + (kk < NSLOT ? kk : kk - NSLOT) * kChipSlotBytes;                   \
-        f16x8 ah0, al0, ah1, al1;                                                                         \
-        CHIP_ALOAD(ah0, al0, 0, 0)                                                                        \
-        CHIP_ALOAD(ah1, al1, 0, 1)                                                                        \
-        CHIP_STEP(0, ah0, al0, bh0, bl0)                                                                  \
-        CHIP_ALOAD(ah0, al0, 0, 2)                                                                        \
-        CHIP_STEP(1, ah1, al1, bh0, bl0)                                                                  \
-        CHIP_ALOAD(ah1, al1, 1, 0)                                                                        \
-        CHIP_STEP(2, ah0, al0, bh0, bl0)                                                                  \
-        if (2 * kk + 2 < KQ) CHIP_BLOAD(bh0, bl0, 2 * kk + 2)                                             \
-        CHIP_ALOAD(ah0, al0, 1, 1)                                                                        \
-        CHIP_STEP(0, ah1, al1, bh1, bl1)                                                                  \
-        CHIP_ALOAD(ah1, al1, 1, 2)                                                                        \
-        CHIP_STEP(1, ah0, al0, bh1, bl1)                                                                  \
-        CHIP_STEP(2, ah1, al1, bh1, bl1)                                                                  \
-        if (2 * kk + 3 < KQ) CHIP_BLOAD(bh1, bl1, 2 * kk + 3)                                             \
+    if ((FROM) < (TO)) {                                                                                  \
+        f16x8 ah0, al0, ah1, al1, ah2, al2;                                                               \
+        const char* abase = sm + ((FROM) < NSLOT ? (FROM) : (FROM) - NSLOT) * kChipSlotBytes;             \
+        CHIP_LAH(ah0, 0, 0) CHIP_LAL(al0, 0, 0) CHIP_LAH(ah1, 0, 1) CHIP_LAL(al1, 0, 1)                   \
+        _Pragma("nounroll") for (int kk = (FROM); kk < (TO); ++kk) {                                      \
+            const int q1 = 2 * kk + 1, q2 = 2 * kk + 2 < KQ ? 2 * kk + 2 : 0;     /* (the last stage re-reads step 0: unused) */ \
+            const char* const anext = sm + (kk + 1 < (TO) ? (kk + 1 < NSLOT ? kk + 1 : kk + 1 - NSLOT) : (kk < NSLOT ? kk : kk - NSLOT)) * kChipSlotBytes; \
+            CHIP_STEP(0, ah0, al0, bh0, bl0, CHIP_LB(bhr, bh1, q1, 0), CHIP_LB(blr, bl1, q1, 0), CHIP_LB(bhr, bh1, q1, 1),  \
+                      CHIP_LB(blr, bl1, q1, 1), CHIP_LAH(ah2, 0, 2), CHIP_LAL(al2, 0, 2))                 \
+            CHIP_STEP(1, ah1, al1, bh0, bl0, CHIP_LAH(ah0, 1, 0), CHIP_LAL(al0, 1, 0), CHIP_NOP, CHIP_NOP, CHIP_NOP, CHIP_NOP) \
+            CHIP_STEP(2, ah2, al2, bh0, bl0, CHIP_LAH(ah1, 1, 1), CHIP_LAL(al1, 1, 1), CHIP_LB(blr, bl0, q2, 0),            \
+                      CHIP_LB(bhr, bh0, q2, 0), CHIP_NOP, CHIP_LB(blr, bl0, q2, 1))                       \
+            CHIP_STEP(0, ah0, al0, bh1, bl1, CHIP_LB(bhr, bh0, q2, 1), CHIP_LAH(ah2, 1, 2), CHIP_LAL(al2, 1, 2), CHIP_NOP, CHIP_NOP, CHIP_NOP) \
+            abase = anext;         /* the first two steps of the next stage (the same stage again behind the last: unused) */ \
+            CHIP_STEP(1, ah1, al1, bh1, bl1, CHIP_LAH(ah0, 0, 0), CHIP_LAL(al0, 0, 0), CHIP_NOP, CHIP_NOP, CHIP_NOP, CHIP_NOP) \
+            CHIP_STEP(2, ah2, al2, bh1, bl1, CHIP_LAH(ah1, 0, 1), CHIP_LAL(al1, 0, 1), CHIP_NOP, CHIP_NOP, CHIP_NOP, CHIP_NOP) \
+        }                                                                                                 \
     }
+#define CHIP_BLOAD(BH, BL, Q) { CHIP_LB(bhr, BH, Q, 0) CHIP_LB(blr, BL, Q, 0) CHIP_LB(bhr, BH, Q, 1) CHIP_LB(blr, BL, Q, 1) }
         CHIP_BLOAD(bh0, bl0, 0)
-        CHIP_BLOAD(bh1, bl1, 1)
         CHIP_STAGES(0, NPEND)
         CHIP_TS()
         if constexpr (NPEND > 0) {
@@ -236,34 +267,40 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
             CHIP_TS()
             if (wc >= 8 - NPEND) {
                 char* const slot = sm + (wc + 8 - NSLOT) * kChipSlotBytes;
+                int wbl = wb0;
+                asm volatile("" : "+v"(wbl));
 #pragma unroll
                 for (int rl = 0; rl < 48; ++rl) CHIP_PUT(slot, rl, pend[rl])
             }
         }
         CHIP_TS()
-        CHIP_STAGES(NPEND, NSLOT)
-        CHIP_TS()
+        // ... and the other waves wait for them HERE, not at stage NSLOT: a wave that publishes beside a neighbour's
+        // back-to-back MFMAs gets an LDS write through every ~90 cycles (9 000 cycles for its 96, measured) and everyone
+        // waited for it ten stages later; with the whole workgroup at the barrier the 96 writes take ~1 000
         if constexpr (NPEND > 0) __syncthreads();  // pending stages published
         CHIP_TS()
-        CHIP_STAGES(NSLOT, 16)
+        CHIP_STAGES(NPEND, 16)
         CHIP_TS()
 #undef CHIP_STAGES
 #undef CHIP_STEP
-#undef CHIP_ALOAD
 #undef CHIP_BLOAD
-        __syncthreads();                          // the ring is free for the next layer's tile
-        CHIP_TS()
+#undef CHIP_LB
+#undef CHIP_LAH
+#undef CHIP_LAL
+#undef CHIP_MF
+#undef CHIP_SB
+#undef CHIP_NOP
         if (li + 1 == nl) break;
 
         // ------------------------------------------------------------------ depthwise of layer li + 1 on the accumulators
-        const float* const dw_w = chain_ptr<float>(0, li + 1);
-        const float* const dw_b = chain_ptr<float>(1, li + 1);
-        const float* const pu = chain_ptr<float>(4, li);
-        const float* const pb = chain_ptr<float>(5, li);
+        const __amdgpu_buffer_rsrc_t taps = CHIP_TAPS_RSRC(chain_ptr<float>(0, li + 1));
+        const __amdgpu_buffer_rsrc_t pur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(chain_ptr<float>(4, li)), 0, K * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t pbr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(chain_ptr<float>(5, li)), 0, K * 4, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int st = j ? wc + 8 : wc;       // stage of layer li + 1 = column block of layer li
-            const float u = pu[32 * st + frow], b = pb[32 * st + frow];
+            const float u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pur, c4, 128 * st, 0));
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pbr, c4, 128 * st, 0));
             // stacked map row R = 8 i + 2 (r >> 2) + owner half, x = r & 3.  Pair q (rows 2 q, 2 q + 1) of windows 0-1 is
             // accumulator quad (q >> 2, q & 3); the same pair of windows 2-3 is quad ((q + 6) >> 2, (q + 6) & 3).
             float ev[12][4];                      // this lane's two windows, local map rows 0..11
@@ -284,29 +321,41 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
             for (int y = 0; y < 6; ++y)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) in2[y][x] = v2f{ev[y][x], ev[6 + y][x]};
-            if (j == 0) CHIP_DW(0, st, dw_w, dw_b)
-            else CHIP_DW(1, st, dw_w, dw_b)
+            if (j == 0) CHIP_DW(0, st, taps)
+            else CHIP_DW(1, st, taps)
             CHIP_TS()
         }
+        // The barrier that frees the ring stands HERE, behind the depthwise: the two matrix waves of a SIMD do not finish a
+        // layer's K loop together (the older one gets the pipe first), and everything above needs only the wave's own
+        // accumulators - so the early wave's vector work runs beside the late wave's last MFMAs, and the late wave's has the
+        // vector unit to itself, instead of both waiting and then sharing it.
+        __syncthreads();                          // every wave has read every stage: the ring is free for this layer's tile
+        CHIP_TS()
+        CHIP_PUBLISH()
     }
 #undef CHIP_DW
+#undef CHIP_PUBLISH
+#undef CHIP_TAPS_RSRC
 #undef CHIP_PUT
 
     // ---------------------------------------------------------------------- the run's output: bias + ReLU from the accumulators
+    // (stores past the tile's valid rows are dropped by the resource's range check: no per-store masks)
     {
-        const float* const pu = chain_ptr<float>(4, nl - 1);
-        const float* const pb = chain_ptr<float>(5, nl - 1);
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)m0 * K, 0, tile_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t pur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(chain_ptr<float>(4, nl - 1)), 0, K * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t pbr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(chain_ptr<float>(5, nl - 1)), 0, K * 4, 0x00020000);
+        const unsigned yo = (4u * fh * K) * 4 + c4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int c = 32 * (j ? wc + 8 : wc) + frow;
-            const float u = pu[c], b = pb[c];
+            const int st = j ? wc + 8 : wc;
+            const float u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pur, c4, 128 * st, 0));
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pbr, c4, 128 * st, 0));
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + 32 * i + 8 * (r >> 2) + 4 * fh + (r & 3);
-                    if (m < M) Y[(size_t)m * K + c] = fmaxf(fmaf(acc[i][j][r], u, b), 0.0f);
-                }
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(acc[i][j][r], u, b), 0.0f)), yrs, yo,
+                                                          ((32 * i + 8 * (r >> 2) + (r & 3)) * K + 32 * st) * 4, 0);
         }
     }
     if (range_flag && !(rmax <= kF16MaxChip)) *range_flag = 1u;
@@ -339,7 +388,9 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const long long tiles = (M + 95) / 96;
-#ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=7 stamps the phases of workgroup 0 (waves 0 and 5)
+    int tune = 0;
+#ifdef BD_KERNEL_TRACE      // developer build only: BD_CHIP_TUNE = priority policy under test; BD_WS_TRACE=7 stamps workgroup 0
+    if (const char* tn = getenv("BD_CHIP_TUNE")) tune = atoi(tn);
     const char* tr = getenv("BD_WS_TRACE");
     if (tr && tr[0] == '7') {
         static unsigned long long* dbg = nullptr;
@@ -351,14 +402,14 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
         }
         (void)hipMemsetAsync(dbg, 0, 128 * 8, stream);
         hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT, true>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl,
-                           M, L[0].range_flag, dbg);
+                           M, L[0].range_flag, dbg, tune);
         (void)hipStreamSynchronize(stream);
         unsigned long long h[128];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         if (++shots == 8)
             for (int w = 0; w < 2; ++w) {
                 fprintf(stderr, "[trace] on-chip run, wave %d: cycles between stamps (start | dw0 j0 j1 | per layer: B1, stages 0-2, B2, pend, "
-                                "stages 3-12, B3, stages 13-15, B4, [dw j0, dw j1] | stores):", w ? 5 : 0);
+                                "B3, stages 3-15, [dw j0, dw j1, B4] | stores):", w ? 5 : 0);
                 for (int i = 1; i < 64 && h[w * 64 + i]; ++i) fprintf(stderr, " %llu", h[w * 64 + i] - h[w * 64 + i - 1]);
                 fprintf(stderr, "\n");
             }
@@ -366,18 +417,22 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
     }
 #endif
     hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl, M,
-                       L[0].range_flag, (unsigned long long*)nullptr);
+                       L[0].range_flag, (unsigned long long*)nullptr, tune);
 }
 
 }  // namespace
 
 // A run of stride-1 512 -> 512 layers on the 6 x 4 map with the tiles between its layers kept on the CU: reads `in`, writes
-// `out`.  They may be the same buffer: a workgroup has read all rows of its tile (a tail tile's clamped rows are its own)
-// before it writes any.  The caller has checked the shapes (launch_separable_run).
-void launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream) {
+// `out`.  They may be the same buffer: a workgroup has read all rows of its tile before it writes any.  The caller has
+// checked the shapes (launch_separable_run).  False (nothing launched) when a layer's shift table does not follow its taps
+// (the kernel reads both through one [10][512] resource; engine.hip lays dw_b16 behind dw_w16).
+bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream) {
+    for (int i = 0; i < nl; ++i)
+        if (dw_b_of(L[i]) != dw_w_of(L[i]) + 9 * 512) return false;
     const long long M = (long long)windows * 24;
     if (L[0].pw_mode == 2) launch_chip<true>(in, out, L, nl, M, stream);
     else launch_chip<false>(in, out, L, nl, M, stream);
+    return true;
 }
 
 }  // namespace bd

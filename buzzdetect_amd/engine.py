@@ -408,9 +408,10 @@ class HipEngine:
         with self._lock:
             _lib.check(self._lib.bd_set_resample_quality(self._handle, self.RESAMPLE_QUALITIES[quality]))
 
-    def resample(self, samples, rate_in: int, rate_out: int = SAMPLE_RATE) -> torch.Tensor:
+    def resample(self, samples, rate_in: int, rate_out: int = SAMPLE_RATE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[n] or [n, channels] float32 — or int16 PCM, scaled by 1/32768 — at ``rate_in`` -> mono float32 [m] at
-        ``rate_out`` on the device (np.mean(axis=1) + librosa.resample of src/stream/worker.py:116-128 as one kernel)."""
+        ``rate_out`` on the device (np.mean(axis=1) + librosa.resample of src/stream/worker.py:116-128 as one kernel).
+        ``out``: a caller-owned float32 device tensor of exactly the output's length (the feeder's staging arena)."""
         is_s16 = (samples.dtype == torch.int16) if isinstance(samples, torch.Tensor) else (np.asarray(samples).dtype == np.int16)
         dt_t, dt_n = (torch.int16, np.int16) if is_s16 else (torch.float32, np.float32)
         if isinstance(samples, torch.Tensor):
@@ -427,7 +428,11 @@ class HipEngine:
         t = t.contiguous()
         n_in, channels = t.shape
         n_out = _lib.check(self._lib.bd_resample_length(n_in, int(rate_in), int(rate_out)))
-        out = torch.empty(max(n_out, 1), dtype=torch.float32, device=self.device)[:n_out]
+        if out is None:
+            out = torch.empty(max(n_out, 1), dtype=torch.float32, device=self.device)[:n_out]
+        elif (out.dim() != 1 or out.numel() != n_out or out.dtype != torch.float32 or out.device != self.device
+              or not out.is_contiguous() or out.data_ptr() % 16):
+            raise ValueError(f"out must be a contiguous, 16-byte aligned float32 [{n_out}] tensor on {self.device}")
         fn = self._lib.bd_resample_s16 if is_s16 else self._lib.bd_resample
         with self._lock, torch.cuda.device(self.device):      # (the first use of a rate ratio adds its filter to the handle)
             _lib.check(fn(self._handle, t.data_ptr(), n_in, channels, int(rate_in), int(rate_out),

@@ -146,5 +146,44 @@ def rows(start: np.ndarray, values: np.ndarray) -> Optional[bytes]:
     return flat[flat != 0].tobytes()
 
 
+_NATIVE = None          # the C-ABI library's bd_format_rows, False once it turned out to be unavailable
+BD_ERANGE = -5              # include/buzzdetect_hip.h
+
+
+def rows_native(start: np.ndarray, raw: np.ndarray, keep: Optional[Sequence[int]] = None) -> Optional[bytes]:
+    """The bytes of ``rows(start, raw.round(2)[:, keep])`` from the library's host-side formatter (``bd_format_rows``,
+    csrc/rowfmt.hip: a plain C loop, ~30 x the NumPy assembly above, GIL released).  ``raw`` are the UNROUNDED float32
+    logits ``[rows, classes]`` (any row stride); ``None`` when the library is not there or a value does not fit the fixed form
+    - the caller then goes through ``rows`` / pandas, which is what decides the bytes in that case."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            from . import _lib
+            _NATIVE = _lib.load(build_if_missing=False).bd_format_rows
+        except Exception:                                   # noqa: BLE001 - formatting must never depend on the library
+            _NATIVE = False
+    if _NATIVE is False:
+        return None
+    raw = np.asarray(raw)
+    start = np.ascontiguousarray(start, dtype=np.float64)
+    if raw.ndim != 2 or raw.dtype != np.float32 or raw.shape[0] != start.shape[0]:
+        return None
+    n, c = raw.shape
+    if n == 0:
+        return b""
+    if raw.strides[1] != 4 or raw.strides[0] % 4:
+        return None
+    idx = None if keep is None else np.ascontiguousarray(keep, dtype=np.int32)
+    cols = c if idx is None else int(idx.size)
+    out = np.empty(n * (10 * cols + 12) + 8, np.uint8)
+    got = _NATIVE(raw.ctypes.data, n, c, raw.strides[0] // 4, None if idx is None else idx.ctypes.data, 0 if idx is None else cols,
+                  start.ctypes.data, out.ctypes.data, out.size)
+    if got < 0:
+        if got == BD_ERANGE:
+            return None
+        raise ValueError(f"bd_format_rows failed ({got})")
+    return out[:got].tobytes()
+
+
 def header(columns: Sequence[str]) -> bytes:
     return (",".join(columns) + "\n").encode()

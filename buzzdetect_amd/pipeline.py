@@ -51,6 +51,8 @@ BATCH_WINDOWS = 1024              # windows gathered per launch set
 BATCH_CHUNKS = 64                 # bd_predict_batch's limit
 FILE_SIZE_MINIMUM = 5000          # src/config.py:20
 BOTTLENECK_SECONDS = 0.01         # src/inference/worker.py:86
+BAD_READ_ALLOWANCE = 0.01         # src/config.py:18: share of a file's tail that may be unreadable before it is a WARNING
+RESULT_BLOCKS = 6                 # pinned result blocks per analyzer: batches in flight between the GPU and the writer
 
 
 class PipelineAborted(Exception):
@@ -68,6 +70,7 @@ class FileJob:
     track: Optional[WavTrack] = None
     header: bytes = b""
     bodies: List[Tuple[float, bytes]] = field(default_factory=list)      # (chunk start, rows) of a fresh recording
+    bad_read: bool = False        # the file ended before its header said it would: said once (handle_bad_read)
     index: int = -1               # position in the run's recording list (gather mode)
     rows: List[Tuple[float, "np.ndarray"]] = field(default_factory=list)  # (chunk start, logits) when a file sink takes the rows
 
@@ -98,6 +101,7 @@ class WriteItem:
     done: object                  # torch.cuda.Event
     analyzer: int
     t_start: float
+    block: object = None          # the pinned result block `host` is a view of; goes back to its analyzer's pool when written
 
 
 @dataclass
@@ -109,6 +113,11 @@ class Report:
     windows: int = 0
     audio_seconds: float = 0.0
     messages: List[str] = field(default_factory=list)
+    # wall seconds each stage spent doing its work (summed over the stage's threads; waiting on a queue is not work):
+    # read = file -> pinned buffer, pin = first use of a pinned buffer (page locking), analyze = enqueueing a batch's copies
+    # and kernels, settle = waiting for a batch's range verdict, write_wait = the writer waiting for a batch's event,
+    # format = rows -> CSV text, write = appending it to the result files
+    busy: Dict[str, float] = field(default_factory=dict)
     end_reason: str = "completed"     # or "interrupted": the caller's stop event ended the run (coordination.py:147-154)
 
 
@@ -118,9 +127,11 @@ class PinnedRing:
     last goes out first, so only as many buffers are ever pinned as are in flight at once (pinning costs ~0.25 s per GB,
     and a queue would walk through - and pin - every slot of the ring)."""
 
-    def __init__(self, slots: int):
+    def __init__(self, slots: int, pin: bool = True):
         import torch
         self._torch = torch
+        self._pin = pin               # (False: a reader stage without a device, tests/test_analyze.py)
+        self.pin_seconds = 0.0        # (summed without a lock: a diagnostic)
         self._free: "queue.LifoQueue[int]" = queue.LifoQueue()
         self._buf: List[Optional["torch.Tensor"]] = [None] * slots
         for i in reversed(range(slots)):
@@ -137,7 +148,9 @@ class PinnedRing:
                 continue
         buf = self._buf[slot]
         if buf is None or buf.numel() < nbytes:
-            self._buf[slot] = buf = self._torch.empty(max(nbytes, 1 << 20), dtype=self._torch.uint8, pin_memory=True)
+            t0 = time.perf_counter()
+            self._buf[slot] = buf = self._torch.empty(max(nbytes, 1 << 20), dtype=self._torch.uint8, pin_memory=self._pin)
+            self.pin_seconds += time.perf_counter() - t0
         return slot, buf
 
     def buffer(self, slot: int):
@@ -166,12 +179,62 @@ class EventPool:
         self._free.put(event)
 
 
+class ResultPool:
+    """The pinned [rows, classes] float32 blocks one analyzer's logits land in, allocated ONCE when the analyzer starts
+    (page-locking memory per batch cost the first call of analyze() a third of its time).  A block
+    travels analyzer -> writer inside its WriteItem and comes back when its rows have been formatted; with all blocks out
+    the analyzer waits for the writer - the bound on results in flight."""
+
+    def __init__(self, torch, blocks: int, rows: int, classes: int):
+        self._torch, self._classes, self.rows = torch, classes, rows
+        self._free: "queue.SimpleQueue" = queue.SimpleQueue()
+        for _ in range(blocks):
+            self._free.put(torch.empty((rows, classes), dtype=torch.float32, pin_memory=True))
+
+    def take(self, rows: int, aborted: threading.Event):
+        while True:
+            if aborted.is_set():
+                raise PipelineAborted()
+            try:
+                block = self._free.get(timeout=0.2)
+                break
+            except queue.Empty:
+                continue
+        if block.shape[0] < rows:                      # a batch larger than planned (never with the sizes Pipeline derives)
+            log.debug(f"result block grows to {rows} rows")
+            block = self._torch.empty((rows, self._classes), dtype=self._torch.float32, pin_memory=True)
+        return block
+
+    def give(self, block) -> None:
+        self._free.put(block)
+
+
+class DeviceArena:
+    """Two grow-only device buffers of one analyzer, used alternately: batch n + 1 is copied in while batch n computes.  A
+    buffer is reused two batches later, behind the event recorded after the kernels that read it - no allocation in the
+    steady state, no caching-allocator bookkeeping across the two streams."""
+
+    def __init__(self, torch, device, dtype):
+        self._torch, self._device, self._dtype = torch, device, dtype
+        self._buf = [None, None]
+        self.free = [None, None]                      # event recorded on the compute stream after the last reader of a buffer
+
+    def get(self, which: int, count: int, stream):
+        buf = self._buf[which]
+        if buf is None or buf.numel() < count:
+            if buf is not None:
+                buf.record_stream(stream)
+            self._buf[which] = buf = self._torch.empty(max(int(count * 1.25), 1 << 20), dtype=self._dtype, device=self._device)
+        return buf
+
+
 class Pipeline:
     def __init__(self, *, make_engine: Callable[[], object], classes: Sequence[str], framehop_s: float, hop: int, step: int,
                  chunklength: float, framelength_s: float, digits_time: int, digits_results: int, classes_out,
                  threshold: Optional[float], readers: int = 4, analyzers: int = 2, device=None,
                  file_sink: Optional[Callable[[FileJob, List[Tuple[float, "np.ndarray"]]], None]] = None,
-                 ignore_partial: bool = False, stop_event=None, stream_buffer_depth: Optional[int] = None):
+                 ignore_partial: bool = False, stop_event=None, stream_buffer_depth: Optional[int] = None,
+                 pin_memory: bool = True):
         import torch
         self.torch = torch
         self.make_engine = make_engine
@@ -193,12 +256,16 @@ class Pipeline:
         self.stop_event = stop_event          # anything with is_set(): threading.Event, multiprocessing.Event
         self.q_write: "queue.Queue" = queue.Queue()
         # queue + readers' hands + batches being copied
-        self.ring = PinnedRing(max(1, depth) + 2 * self.n_readers + 16 * self.n_analyzers)
+        self.ring = PinnedRing(max(1, depth) + 2 * self.n_readers + 16 * self.n_analyzers, pin_memory)
         self.events = EventPool(torch)
         self.aborted = threading.Event()
         self.error: Optional[BaseException] = None
         self.lock = threading.Lock()
         self.report = Report()
+
+    def _busy(self, stage: str, seconds: float) -> None:
+        with self.lock:
+            self.report.busy[stage] = self.report.busy.get(stage, 0.0) + seconds
 
     # ------------------------------------------------------------------ failure handling
     def fail(self, exc: BaseException, who: str) -> None:
@@ -279,23 +346,48 @@ class Pipeline:
         if finish:
             self._put(self.q_write, job)
 
+    def _bad_read(self, job: FileJob, track: WavTrack, frames_reached: int) -> None:
+        """The reference's handle_bad_read (src/stream/worker.py:41-59): the file holds fewer frames than its header
+        declares - a recorder whose battery died.  Said ONCE per file: WARNING when more than BAD_READ_ALLOWANCE of the
+        declared length is missing, DEBUG when the loss is at the very end; the file stops there (chunks behind the end
+        read nothing and are dropped)."""
+        with self.lock:
+            if job.bad_read:
+                return
+            job.bad_read = True
+        final_second = frames_reached / track.samplerate
+        msg = f"Unreadable audio at {round(final_second, 1)}s out of {round(track.duration, 1)}s for {job.shortpath}."
+        if 1 - (final_second / track.duration) > BAD_READ_ALLOWANCE:
+            log.warning(f"streamer: {msg}\nAborting early due to corrupt audio data.")
+            with self.lock:
+                self.report.messages.append(f"unreadable audio, stopped at {round(final_second, 1)}s: {job.shortpath}")
+        else:
+            log.debug(f"streamer: {msg}\nBad audio is near file end, results should be mostly unaffected.")
+
     def _read_unit(self, unit: ReadUnit) -> None:
         job, chunk, track = unit.job, unit.chunk, unit.job.track
         a, b = framing.chunk_sample_range(chunk, track.samplerate)
-        want = min(b, track.frames) - a
+        want = min(b, track.frames_declared) - a           # what the header promises for this chunk
         if want <= 0:
             return self._drop(job)
-        raw_bytes = want * track.bytes_per_frame
-        out_bytes = raw_bytes if track.is_s16 else want * track.channels * 4
+        have = min(want, max(track.frames - a, 0))          # what the file holds
+        if have <= 0:                                       # the whole chunk lies behind the end of a file cut short
+            self._bad_read(job, track, track.frames)
+            return self._drop(job)
+        raw_bytes = have * track.bytes_per_frame
+        out_bytes = raw_bytes if track.is_s16 else have * track.channels * 4
         slot, buf = self.ring.acquire(max(raw_bytes, out_bytes), self.aborted)
         try:
             host = buf.numpy()
-            got = track.read_raw_into(a, want, host)       # the one host copy; releases the GIL
+            t0 = time.perf_counter()
+            got = track.read_raw_into(a, have, host)       # the one host copy; releases the GIL
+            self._busy("read", time.perf_counter() - t0)
+            if got < want:                                 # short read (src/stream/worker.py:119-127): say it, truncate the
+                self._bad_read(job, track, a + got)        # chunk, and the file ends here
+                chunk = (chunk[0], round(chunk[0] + got / track.samplerate, 1))
             if got == 0:
                 self.ring.release(slot)
                 return self._drop(job)
-            if got < b - a:                                # short read: truncate the chunk (src/stream/worker.py:119-127)
-                chunk = (chunk[0], round(chunk[0] + got / track.samplerate, 1))
             if track.is_s16:
                 nbytes = got * track.bytes_per_frame
             else:                                          # any other sample format: float32 on the host
@@ -335,10 +427,20 @@ class Pipeline:
             copy_stream = torch.cuda.Stream(device)         # host-to-device copies of batch n + 1 run under the kernels of batch n
             copied = torch.cuda.Event()
             n_classes = engine.n_classes
+            # everything a batch needs is allocated here, once: pinned result blocks sized for the largest batch the
+            # batching rule below can form, and (grow-only) device buffers for the raw bytes and the 16 kHz PCM
+            chunk_windows = int(self.chunklength / self.framehop_s) + 2
+            results_pool = ResultPool(torch, RESULT_BLOCKS, BATCH_WINDOWS + chunk_windows + 8, n_classes)
+            raw_arena = DeviceArena(torch, device, torch.uint8)
+            pcm_arena = DeviceArena(torch, device, torch.float32)
+            logit_dev = [torch.empty((results_pool.rows, n_classes), dtype=torch.float32, device=device) for _ in range(2)]
+            arena_free = [torch.cuda.Event(), torch.cuda.Event()]
+            arena_used = [False, False]
             log.info(f"analyzer {aid}: processing on GPU")
             t_wait = time.perf_counter()
             finished = False
             pending = None                                  # the batch before the current one: (item, range word, its PCM)
+            n_batch = 0
 
             def settle(p) -> None:
                 """Forward a batch to the writer once it is known to be sound: the f16 matrix path cannot represent an
@@ -346,7 +448,10 @@ class Pipeline:
                 computed again with exact f32 products.  Runs while the NEXT batch occupies the GPU, so the wait costs
                 nothing."""
                 item, verdict, pcms = p
-                if verdict.wait():
+                t0 = time.perf_counter()
+                raised = verdict.wait()
+                self._busy("settle", time.perf_counter() - t0)
+                if raised:
                     log.warning(f"analyzer {aid}: an activation left the f16 range; recomputing {len(item.tasks)} chunk(s) in exact f32")
                     with torch.cuda.stream(stream):
                         _, whole, _ = engine.launch(pcms, self.hop, self.step, False, True, mode="f32")
@@ -382,36 +487,50 @@ class Pipeline:
                     batch.append(nxt)
                     windows += engine.num_windows(self._out_samples(nxt), self.hop, self.step)
                 held = [t.slot for t in batch]
+                which = n_batch & 1
+                n_batch += 1
+                # raw bytes of the batch, back to back (256-byte aligned), in this batch's half of the arena
+                offs, at = [], 0
+                for t in batch:
+                    offs.append(at)
+                    at += (t.nbytes + 255) & ~255
+                outs = [self._out_samples(t) if (t.s16 or t.rate != 16000 or t.channels > 1) else 0 for t in batch]
                 with torch.cuda.stream(copy_stream):
-                    devs = []
-                    for t in batch:
-                        pinned = self.ring.buffer(t.slot)[: t.nbytes]
-                        dev = torch.empty(t.nbytes, dtype=torch.uint8, device=device)
-                        dev.copy_(pinned, non_blocking=True)
-                        devs.append(dev)
+                    raw = raw_arena.get(which, at, stream)
+                    if arena_used[which]:
+                        copy_stream.wait_event(arena_free[which])      # the kernels of two batches ago have read it
+                    for t, o in zip(batch, offs):
+                        raw[o:o + t.nbytes].copy_(self.ring.buffer(t.slot)[: t.nbytes], non_blocking=True)
                     copied.record(copy_stream)           # one event per analyzer, recorded again for every batch: the
                                                          # wait below captures the state it has at this moment
                 with torch.cuda.stream(stream):
                     stream.wait_event(copied)
-                    pcms = []
-                    for t, dev in zip(batch, devs):
-                        dev.record_stream(stream)          # allocated on the copy stream, read by this one
-                        view = dev.view(torch.int16 if t.s16 else torch.float32).view(t.frames, t.channels)
-                        if t.s16 or t.rate != 16000 or t.channels > 1:
-                            pcms.append(engine.resample(view, t.rate, 16000))     # also s16 -> f32 and the channel mean
+                    pcm = pcm_arena.get(which, sum((n + 63) & ~63 for n in outs), stream)
+                    pcms, pat = [], 0
+                    for t, o, n_out in zip(batch, offs, outs):
+                        view = raw[o:o + t.nbytes].view(torch.int16 if t.s16 else torch.float32).view(t.frames, t.channels)
+                        if n_out:
+                            pcms.append(engine.resample(view, t.rate, 16000, out=pcm[pat:pat + n_out]))   # also s16 -> f32, channel mean
+                            pat += (n_out + 63) & ~63
                         else:
                             pcms.append(view[:, 0])
                     verdict = LaunchVerdict(stream)
-                    _, whole, counts = engine.launch(pcms, self.hop, self.step, False, True, verdict=verdict)
-                    total = sum(counts)
-                    host = torch.empty((max(total, 1), n_classes), dtype=torch.float32, pin_memory=True)[:total]
+                    total = sum(engine.num_windows(int(p.numel()), self.hop, self.step) for p in pcms)
+                    block = results_pool.take(total, self.aborted)
+                    dev_rows = logit_dev[which] if total <= logit_dev[which].shape[0] else None
+                    _, whole, counts = engine.launch(pcms, self.hop, self.step, False, True, verdict=verdict,
+                                                     out=dev_rows[:total] if dev_rows is not None and total else None)
+                    host = block[:total]
                     if total:
                         host.copy_(whole, non_blocking=True)
                     done = self.events.take()
                     done.record(stream)
+                    arena_free[which].record(stream)
+                    arena_used[which] = True
+                self._busy("analyze", time.perf_counter() - t_start)
                 # the pinned slots go back to the ring when the batch's event has fired (the writer waits for it anyway);
                 # the batch itself goes to the writer one batch later, after its range word has been looked at
-                item = WriteItem(batch, host.numpy(), counts, done, aid, t_start)
+                item = WriteItem(batch, host.numpy(), counts, done, aid, t_start, (results_pool, block))
                 held = []
                 if pending is not None:
                     settle(pending)
@@ -476,7 +595,9 @@ class Pipeline:
                 if isinstance(item, FileJob):              # a recording whose last planned chunk turned out to be empty
                     self._finalize(item)
                     continue
+                t0 = time.perf_counter()
                 item.done.synchronize()
+                self._busy("write_wait", time.perf_counter() - t0)
                 self.events.give(item.done)
                 for t in item.tasks:                       # the H2D copies that read the pinned slots are long done
                     self.ring.release(t.slot)
@@ -484,6 +605,7 @@ class Pipeline:
                 audio = sum(t.chunk[1] - t.chunk[0] for t in item.tasks)
                 rate = audio / seconds if seconds > 0 else float("inf")
                 at = 0
+                t_fmt0, t_io = time.perf_counter(), 0.0
                 for t, n in zip(item.tasks, item.counts):
                     rows = item.host[at:at + n]
                     at += n
@@ -497,7 +619,9 @@ class Pipeline:
                         head, body = results.detection_csv(rows, self.threshold, self.classes, self.framehop_s,
                                                            self.digits_time, t.chunk[0])
                     if head is not None:
+                        t1 = time.perf_counter()
                         t.job.rf.append_text(head, body)
+                        t_io += time.perf_counter() - t1
                     if head is not None and t.job.fresh:
                         t.job.header = head
                         t.job.bodies.append((t.chunk[0], body))
@@ -510,7 +634,13 @@ class Pipeline:
                         t.job.outstanding -= 1
                         finish = t.job.outstanding == 0
                     if finish:
+                        t1 = time.perf_counter()
                         self._finalize(t.job)
+                        t_io += time.perf_counter() - t1
+                self._busy("format", time.perf_counter() - t_fmt0 - t_io)
+                self._busy("write", t_io)
+                if item.block is not None:                 # every row of the block has been turned into text (or copied)
+                    item.block[0].give(item.block[1])
             log.debug("writer: terminating")
         except PipelineAborted:
             pass
@@ -567,6 +697,7 @@ class Pipeline:
         finished.set()
         if watcher is not None:
             watcher.join()
+        self.report.busy["pin"] = self.report.busy.get("pin", 0.0) + self.ring.pin_seconds
         if self.error is not None:
             raise self.error
         return self.report

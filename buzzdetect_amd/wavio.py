@@ -29,7 +29,7 @@ class WavTrack:
             if len(head) < 12 or head[:4] not in (b"RIFF", b"RF64") or head[8:12] != b"WAVE":
                 raise WavFormatError(f"{path}: not a RIFF/WAVE file")
             fmt = None
-            data_off = data_len = None
+            data_off = data_len = data_declared = None
             size = f.seek(0, 2)
             f.seek(12)
             while f.tell() + 8 <= size:
@@ -38,7 +38,9 @@ class WavTrack:
                 if cid == b"fmt ":
                     fmt = f.read(min(clen, 40))
                 elif cid == b"data":
-                    data_off, data_len = at, min(clen, size - at)      # a recorder that died mid-file leaves a long count
+                    # a recorder that died mid-file leaves a count longer than the file: `frames` below is what can be
+                    # read, `frames_declared` what the header promises (libsndfile's .frames, the reference's duration)
+                    data_off, data_len, data_declared = at, min(clen, size - at), clen
                     break
                 f.seek(at + clen + (clen & 1))
         if fmt is None or len(fmt) < 16 or data_off is None:
@@ -54,6 +56,9 @@ class WavTrack:
         self.samplerate, self.channels = int(rate), int(channels)
         self._tag, self._width = tag, width
         self.frames = data_len // block
+        # 0xFFFFFFFF is the "length unknown" convention of streaming writers (and RF64's placeholder): the file's own length
+        # is the only statement there is
+        self.frames_declared = self.frames if data_declared == 0xFFFFFFFF else max(self.frames, data_declared // block)
         self._data_off, self._block = data_off, block
         self._fd = os.open(path, os.O_RDONLY)
         self._pos = 0
@@ -63,6 +68,12 @@ class WavTrack:
 
     @property
     def duration(self) -> float:
+        """Seconds the HEADER declares (soundfile's frames / samplerate, what the reference plans its chunks over,
+        src/stream/worker.py:84-107); a file cut short holds less: `duration_readable`."""
+        return self.frames_declared / self.samplerate
+
+    @property
+    def duration_readable(self) -> float:
         return self.frames / self.samplerate
 
     @property

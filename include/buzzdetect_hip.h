@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 3
+#define BD_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define BD_API __attribute__((visibility("default")))
@@ -154,6 +154,18 @@ BD_API int bd_resample(bd_handle h, const float* in_dev, int64_t n_in, int32_t c
    rate_in == rate_out and one channel it is a plain s16 -> f32 conversion on the device */
 BD_API int bd_resample_s16(bd_handle h, const int16_t* in_dev, int64_t n_in, int32_t channels, int32_t rate_in,
                            int32_t rate_out, float* out_dev, void* stream);
+
+/* Host only (no device, no handle): the result rows of one chunk as the CSV text the reference's writer produces
+   (src/write/formatting.py:31-50 add_time + round(2), then DataFrame.to_csv in src/write/worker.py:67-87): per row
+   `start`, then the kept activation columns, each rounded to two decimals as numpy's float32 round does and written in
+   shortest form with at least one decimal ("-1.28", "0.5", "3.0", "-0.0"), '\n' line ends, no header.
+     values[n_rows][row_stride] float32 logits, n_cols of them valid per row; keep[n_keep] = the columns to write, in order
+     (n_keep == 0: all n_cols); starts[n_rows] = the rows' start times, already rounded (framing.window_starts);
+     out / capacity: at least n_rows * (10 * columns + 12) + 8 bytes.
+   Returns the number of bytes written; BD_ERANGE when a value has no two-decimal fixed form below 100 000 (non-finite or
+   huge - the caller then formats that chunk the slow way, as buzzdetect_amd/fastcsv.py does); BD_EWORKSPACE / BD_EINVAL. */
+BD_API int64_t bd_format_rows(const float* values, int64_t n_rows, int32_t n_cols, int64_t row_stride, const int32_t* keep,
+                              int32_t n_keep, const double* starts, char* out, int64_t capacity);
 
 /* logmel_dev[n_frames][64] -> patches_dev[W][96][64], W = 1 + (n_frames - 96) / patch_step. */
 BD_API int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t patch_step,

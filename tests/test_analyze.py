@@ -136,7 +136,14 @@ def test_wav_parser_formats_the_stdlib_reader_rejects(tmp_path):
     blob = bytearray(_riff(struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16), s.tobytes()))
     blob[blob.index(b"data") + 4: blob.index(b"data") + 8] = struct.pack("<I", 10_000_000)
     (tmp_path / "cut.wav").write_bytes(bytes(blob))
-    assert WavTrack(str(tmp_path / "cut.wav")).frames == 64
+    cut = WavTrack(str(tmp_path / "cut.wav"))
+    assert cut.frames == 64 and cut.frames_declared == 5_000_000           # what can be read / what the header promises
+    assert cut.duration == 5_000_000 / 16000 and cut.duration_readable == 64 / 16000
+    # 0xFFFFFFFF: "length unknown" (streaming writers): the file's own length is all there is
+    blob[blob.index(b"data") + 4: blob.index(b"data") + 8] = struct.pack("<I", 0xFFFFFFFF)
+    (tmp_path / "stream.wav").write_bytes(bytes(blob))
+    t = WavTrack(str(tmp_path / "stream.wav"))
+    assert t.frames == t.frames_declared == 64
     for bad in (b"RIFF\0\0\0\0WAVX", _riff(struct.pack("<HHIIHH", 85, 1, 16000, 2000, 1, 0), b"\0" * 64)):   # not WAVE; MP3-in-WAV
         (tmp_path / "bad.wav").write_bytes(bad)
         with pytest.raises(WavFormatError):
@@ -150,6 +157,97 @@ def _three_recordings(audio):
     write_wav(audio / "two.wav", O.synthetic_audio(16000 * 12, seed=2), 16000)
     t = np.arange(32000 * 9) / 32000.0
     write_wav(audio / "three32k.wav", 0.4 * np.sin(2 * np.pi * 440 * t), 32000)
+
+
+def _cut_short(path, keep_seconds: float, rate: int = 16000):
+    """Truncate a WAV written by write_wav behind `keep_seconds` of audio: the header keeps the full count (a recorder
+    whose battery died, src/stream/worker.py:41-44)."""
+    with open(path, "r+b") as f:
+        f.truncate(44 + int(keep_seconds * rate) * 2)
+
+
+def _reader_stage(tmp_path, chunklength):
+    """A Pipeline whose planner and reader stages run without a device (pageable staging buffers)."""
+    from buzzdetect_amd import pipeline as P, results as R
+    pipe = P.Pipeline(make_engine=None, classes=["a"], framehop_s=0.96, hop=15360, step=96, chunklength=chunklength,
+                      framelength_s=0.96, digits_time=2, digits_results=2, classes_out="all", threshold=None, readers=1,
+                      analyzers=1, pin_memory=False, stream_buffer_depth=64)
+    def job(name):
+        return P.FileJob(str(tmp_path / name), name[:-4], name, R.ResultFile(str(tmp_path / "out" / name[:-4])))
+    def drain(q):
+        got = []
+        while not q.empty():
+            got.append(q.get())
+        return got
+    return pipe, job, drain
+
+
+def test_a_file_cut_short_is_said_once_truncated_and_stopped(tmp_path, caplog):
+    """The reference's only failure handling on this path (src/stream/worker.py:41-59, 119-127; src/config.py:18): a read
+    that returns fewer frames than the header promised -> "Unreadable audio at <x>s out of <y>s for <file>." - WARNING (+
+    "Aborting early ...") when more than 1 % of the file is missing, DEBUG (+ "Bad audio is near file end ...") otherwise -
+    the chunk ends at round(start + got / rate, 1) and the file ends there.  Reader stage only: no device needed."""
+    import logging
+    x = O.synthetic_audio(16000 * 100, seed=3)
+    write_wav(tmp_path / "dead.wav", x, 16000)
+    _cut_short(tmp_path / "dead.wav", 60.3)
+    write_wav(tmp_path / "tail.wav", x, 16000)
+    _cut_short(tmp_path / "tail.wav", 99.5)
+    write_wav(tmp_path / "whole.wav", x, 16000)
+    (tmp_path / "out").mkdir()
+    pipe, job, drain = _reader_stage(tmp_path, 19.2)
+    with caplog.at_level(logging.DEBUG, logger="buzzdetect"):
+        for name in ("dead.wav", "tail.wav", "whole.wav"):
+            j = job(name)
+            pipe._plan_file(j)
+            units = drain(pipe.q_units)
+            assert [u.chunk for u in units] == [(0.0, 19.2), (19.2, 38.4), (38.4, 57.6), (57.6, 76.8), (76.8, 96.0), (96.0, 100.0)]
+            for u in units:
+                pipe._read_unit(u)
+            tasks = [t for t in drain(pipe.q_analyze)]
+            finished = [w for w in drain(pipe.q_write)]
+            if name == "dead.wav":
+                assert [t.chunk for t in tasks] == [(0.0, 19.2), (19.2, 38.4), (38.4, 57.6), (57.6, 60.3)]
+                assert tasks[-1].frames == int(60.3 * 16000) - int(57.6 * 16000)
+                assert j.outstanding == 4 and j.bad_read and not finished          # two chunks dropped, four to analyze
+            elif name == "tail.wav":
+                assert [t.chunk for t in tasks][-1] == (96.0, 99.5) and len(tasks) == 6 and j.bad_read
+            else:
+                assert [t.chunk for t in tasks][-1] == (96.0, 100.0) and not j.bad_read
+    said = [r for r in caplog.records if "Unreadable audio" in r.getMessage()]
+    assert len(said) == 2                                                           # once per file, not once per chunk
+    dead = next(r for r in said if "dead.wav" in r.getMessage())
+    assert dead.levelno == logging.WARNING
+    assert "Unreadable audio at 60.3s out of 100.0s for dead.wav." in dead.getMessage()
+    assert "Aborting early due to corrupt audio data." in dead.getMessage()
+    tail = next(r for r in said if "tail.wav" in r.getMessage())
+    assert tail.levelno == logging.DEBUG and "Unreadable audio at 99.5s out of 100.0s for tail.wav." in tail.getMessage()
+    assert "Bad audio is near file end, results should be mostly unaffected." in tail.getMessage()
+    assert any("dead.wav" in m for m in pipe.report.messages)
+
+
+@pytest.mark.gpu
+def test_analyze_of_a_file_cut_short_writes_what_could_be_read(engine, tmp_path, caplog):
+    """End to end on the device: rows up to the truncation point, the complete file written (a re-run skips it), the
+    reference's WARNING on the log."""
+    import logging
+    import pandas as pd
+    from buzzdetect_amd.analyze import analyze
+    audio, out = tmp_path / "audio", tmp_path / "out"
+    audio.mkdir()
+    x = O.synthetic_audio(16000 * 100, seed=3)
+    write_wav(audio / "dead.wav", x, 16000)
+    _cut_short(audio / "dead.wav", 60.3)
+    with caplog.at_level(logging.DEBUG, logger="buzzdetect"):
+        rep = analyze("model_general_v3", framehop_prop=1, chunklength=19.2, dir_audio=str(audio), dir_out=str(out), engine=engine)
+    assert rep.files_done == 1
+    a = pd.read_csv(out / "dead_buzzdetect.csv")
+    assert a["start"].iloc[0] == 0.0 and 59.0 < a["start"].iloc[-1] <= 60.3 and a["start"].is_monotonic_increasing
+    # chunk (57.6, 60.3): 2.7 s = 43 200 samples -> 1 + ceil((43 200 - 15 600) / 15 360) = 3 windows at 57.6, 58.56, 59.52
+    assert a["start"].tolist()[-3:] == [57.6, 58.56, 59.52] and len(a) == 3 * 20 + 3
+    assert sum("Unreadable audio at 60.3s out of 100.0s" in r.getMessage() for r in caplog.records) == 1
+    rep2 = analyze("model_general_v3", framehop_prop=1, chunklength=19.2, dir_audio=str(audio), dir_out=str(out), engine=engine)
+    assert rep2.files_skipped == 1 and rep2.files_done == 0
 
 
 @pytest.mark.gpu

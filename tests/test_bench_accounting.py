@@ -14,10 +14,10 @@ DEFAULT = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                    # layers 8
 PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # bd_set_fusion separable = 3
 
 
-def _plan(slots):
+def _plan(slots, chip=True):
     launches = np.zeros(29, dtype=np.int64)
     launches[slots] = 40
-    return bench.slot_plan(launches)
+    return bench.slot_plan(launches, chip=chip)
 
 
 def _network_flops():
@@ -36,18 +36,44 @@ def test_slot_plan_adds_up_to_the_network_in_both_layouts():
         plan = _plan(slots)
         assert sorted(plan) == sorted(slots)
         assert sum(v[3] for v in plan.values()) == _network_flops()
-    a, b = _plan(DEFAULT), _plan(PER_LAYER)
-    assert sum(v[2] for v in a.values()) == sum(v[2] for v in b.values())       # same bytes: the run still stores every layer
+    a, b = _plan(DEFAULT, chip=False), _plan(PER_LAYER)
+    assert sum(v[2] for v in a.values()) == sum(v[2] for v in b.values())       # round-3 form of the run: it still stores every layer
+    # the on-chip run (sepchip.hip, the default): the same FLOP, and of the four layers' 8 x 49 152 B per window only the
+    # run's input and output are algorithmic traffic
+    c = _plan(DEFAULT)
+    assert sum(v[3] for v in c.values()) == _network_flops()
+    assert c[21][:2] == ("sep8-11", "sep_chip_kernel") and c[21][2] == 2 * 24 * 512 * 4
+    assert sum(v[2] for v in a.values()) - sum(v[2] for v in c.values()) == 6 * 24 * 512 * 4
 
 
 def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():
-    plan = _plan(DEFAULT)
+    plan = _plan(DEFAULT, chip=False)
     assert plan[21][:2] == ("sep8-11", "sep_w12_kernel")
     assert plan[21][3] == 4 * _plan(PER_LAYER)[15][3]
     assert plan[23][:2] == ("sep12+dw13", "sep_w12_ndw_kernel")                 # 512 -> 512 with layer 13's depthwise: 12-wave kernel
     assert plan[11][:2] == ("sep6+dw7", "sep_ws_kernel")                        # 256 -> 256: one column tile, 8-wave kernel
     assert plan[27][:2] == ("sep14+pool", "sep_w12_ndw_kernel") and plan[28][0] == "head"     # two 512-column halves + pool
     assert plan[25][:2] == ("pw13", "sep_ws_kernel")
+
+
+def test_strict_f32_is_measured_like_the_headline():
+    """value_strict_f32 comes from the SAME run_files() loop as `value` (asserted on the source: the line
+    needs a GPU), says so with the same workload description, and carries a kernel-event roofline block of its own; the
+    exact-f32 mode's slot plan adds up to the network like the default one."""
+    src = open(bench.__file__).read()
+    assert 's_elapsed = timed_region(strict_steps)' in src and 'e.set_pointwise_mode("f32")' in src
+    assert '"workload": out["config"]["workload"]' in src                       # one workload description for both values
+    for key in ('"roofline_strict"', '"strict_f32"', '"avg_launch_us"', '"flop_per_launch_avg"', 'PEAK_F32_MFMA_TFLOPS', '"traffic"',
+                'PMC_TRAFFIC_STRICT_FILE'):
+        assert key in src, key
+    launches = np.zeros(29, dtype=np.int64)
+    f32_slots = [0, 5, 7] + list(range(9, 28, 2)) + [28]
+    launches[f32_slots] = 40
+    plan = bench.slot_plan_f32(launches)
+    assert sorted(plan) == f32_slots
+    assert sum(v[3] for v in plan.values()) == _network_flops()
+    assert plan[5][1] == "stem3_f32_kernel" and plan[7][1] == "l4_f32_kernel" and plan[27][0] == "pw14+pool"
+    assert all(plan[s][1] == "pointwise_kernel" for s in range(9, 28, 2))
 
 
 def test_the_line_says_what_was_measured():

@@ -26,14 +26,14 @@ def declared_symbols():
 
 def test_header_and_binding_list_the_same_functions():
     assert declared_symbols() == sorted(_lib.PROTOTYPES)
-    assert len(declared_symbols()) == 38
+    assert len(declared_symbols()) == 39
 
 
 def test_library_exports_every_declared_symbol(lib):
     raw = C.CDLL(_lib.library_path())
     for name in declared_symbols():
         assert hasattr(raw, name), f"{name} not exported"
-    assert lib.bd_abi_version() == 3
+    assert lib.bd_abi_version() == 4
 
 
 def test_header_constants_match_binding():

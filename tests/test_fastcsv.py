@@ -42,6 +42,47 @@ def test_values_outside_the_fast_form_fall_back_to_pandas():
     assert fastcsv.rows(np.zeros(0), np.zeros((0, 3), np.float32)) == b""
 
 
+def test_native_formatter_writes_fastcsv_bytes():
+    """bd_format_rows (csrc/rowfmt.hip, host code of the C-ABI library) against fastcsv.rows on the ROUNDED values, which the
+    tests above hold to pandas: random logits at five scales, every two-decimal tie and boundary, negative zero, a strided
+    view (the writer formats slices of a batch's pinned block), column subsets in model order."""
+    assert fastcsv.rows_native(np.zeros(1), np.zeros((1, 2), np.float32)) is not None, "the library must be loadable on a CPU box"
+    edge = np.array([0.0, -0.0, 0.004, 0.005, 0.0050001, 0.015, 0.025, 0.035, -0.004, -0.005, -0.0051, 0.994, 0.995, 0.996, 9.995,
+                     99.98, 99.985, 99.99, 99.994, 99.995, 99.996, 100.0, 100.004, 100.005, 123.456, 999.995, 1000.0, 12345.678,
+                     65535.996, 99999.0, 99999.98, 99999.99, -99999.99, -100.0, -99.995, 1e-30, -1e-30, 0.1, 0.7, 2.675, 1.005],
+                    np.float32)
+    for seed, scale in [(0, 1.0), (1, 8.0), (2, 300.0), (3, 0.004), (4, 30000.0)]:
+        rng = np.random.default_rng(seed)
+        x = (rng.standard_normal((977, 13)) * scale).astype(np.float32)
+        x[:edge.size, 5] = edge
+        x[:edge.size, 0] = -edge
+        for start, hop in ((0.0, 0.96), (199.68, 0.96), (86000.0, 0.48), (99990.0, 0.96)):
+            starts = np.round(np.arange(x.shape[0]) * hop + start, 2)
+            if (starts >= 100000).any():
+                assert fastcsv.rows_native(starts, x) is None and fastcsv.rows(starts, x.round(2)) is None
+                continue
+            want = fastcsv.rows(starts, x.round(2))
+            if scale > 1000:                                                # some |x| >= 1e5: both refuse, pandas decides
+                assert want is None and fastcsv.rows_native(starts, x) is None
+                small = np.clip(x, -99999.0, 99999.0)
+                assert fastcsv.rows_native(starts, small) == fastcsv.rows(starts, small.round(2)) != None      # noqa: E711
+                continue
+            assert want is not None
+            assert fastcsv.rows_native(starts, x) == want, (seed, start)
+            keep = [2, 5, 11]
+            assert fastcsv.rows_native(starts, x, keep) == fastcsv.rows(starts, x.round(2)[:, keep])
+            big = np.zeros((x.shape[0] + 7, 16), np.float32)               # a strided view: rows 3.. of a wider block
+            big[3:3 + x.shape[0], :13] = x
+            assert fastcsv.rows_native(starts, big[3:3 + x.shape[0], :13]) == want
+    for bad in (np.nan, np.inf, -np.inf, 2.5e6, -1e9, 1e5, -100000.0):
+        y = np.zeros((5, 4), np.float32)
+        y[2, 1] = bad
+        assert fastcsv.rows_native(np.arange(5) * 0.96, y) is None, bad
+        assert fastcsv.rows(np.arange(5) * 0.96, y.round(2)) is None, bad
+    assert fastcsv.rows_native(np.zeros(0), np.zeros((0, 3), np.float32)) == b""
+    assert fastcsv.rows_native(np.zeros(3), np.zeros((3, 3), np.float64)) is None       # float32 only: others take the NumPy path
+
+
 def test_detection_rows_equal_pandas():
     rng = np.random.default_rng(7)
     x = rng.standard_normal((300, len(CLASSES))).astype(np.float32) * 2
