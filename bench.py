@@ -47,7 +47,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f
 PEAK_F16_MFMA_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (the 2:1-sparse figure is never used)
 PEAK_SPLIT_F16_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # ... / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
 PMC_TRAFFIC_STRICT_FILE = os.path.join("profiles", "r05_pmc_traffic_strict_f32.json")
 # What the board's 1400 W limit leaves of the paper peak: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, constant operands,
 # held for 3 s, settles at 1987 TFLOP/s (2.0 GHz, 1345 W) - tools/ubench_power.hip, profiles/r03_ubench_power.txt.  The headline
@@ -113,6 +113,8 @@ def slot_plan(launches, pool_fused=True, chip=True):
                     # (512 output channels - layer 12 - run the 12-wave kernel, which then applies this depthwise to
                     #  256 channels at a time: cnn.hip launch_separable_fused_next_dw)
                     prev_fam = "l4_window_kernel" if layer == 5 else ("sep_w12_ndw_kernel" if pool_fused and c == 512 else "sep_ws_kernel")
+                    if fam == "sep_chip_kernel":       # the on-chip run took layer 12 and this depthwise along (sepchip.hip, NDW)
+                        prev_fam = fam
                     plan[pw_slot - 2] = (nm + f"+dw{layer}", prev_fam, nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
             else:                 # depthwise inside the GEMM: layer input in, layer output out
                 # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
@@ -440,6 +442,14 @@ def analyze_leg(device_index: int, hours: int, chunklength: float, framehop_prop
                 for _ in range(hours):
                     w.writeframes(block)
         del block, hour
+        # read every file once before the clock starts: the FIRST pass over tmpfs pages that have just been written runs at
+        # a quarter of the rate of any later one (12 vs 50 GB/s on the GPU box whatever the destination buffer -
+        # tools/read_probe.py) - an artefact of generating the recordings a moment ago, not a cost of analyze()
+        for name in sorted(os.listdir(audio)):
+            with open(os.path.join(audio, name), "rb", buffering=0) as f:
+                buf = bytearray(16 << 20)
+                while f.readinto(buf):
+                    pass
         secs, busy = [], []
         for call in range(2):      # the first call pins its staging buffers (host allocator cold), the second is the sustained rate
             t0 = time.perf_counter()

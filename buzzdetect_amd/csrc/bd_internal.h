@@ -156,7 +156,9 @@ void launch_stem_f32(const float* logmel, int patch_step, const WindowMap& map, 
                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,
                          bool on_chip = true);
-bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream);   // sepchip.hip
+bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
+                           const SepLayer* next = nullptr);   // sepchip.hip
+int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     bool band_tiles, hipStream_t stream, bool twelve_waves = true);
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,

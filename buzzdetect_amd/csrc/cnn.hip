@@ -3453,6 +3453,23 @@ int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int
     return n;
 }
 
+// The same run extended by the layer that closes it - the stride-1 512 -> 512 layer whose successor is a stride-2 one (layer
+// 12) - with that successor's depthwise in the epilogue: layers 8-12 + depthwise 13 as ONE launch of the on-chip kernel
+// (sepchip.hip), a -> b = [windows][3][2][512].  Returns the number of layers of L it ran (5) or 0 (the caller goes on as
+// before: launch_separable_run + launch_separable_fused_next_dw).
+int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream) {
+    int n = 0;
+    while (n < 5 && n + 1 < max_layers) {
+        const SepLayer& l = L[n];
+        if (l.stride != 1 || l.cin != 512 || l.cout != 512 || l.h_out != 6 || l.w_out != 4 || l.pw_mode != L[0].pw_mode) return 0;
+        ++n;
+        if (L[n].stride != 1) break;
+    }
+    if (n < 2 || n > 5 || n >= max_layers || L[n].stride != 2 || L[n].cin != 512 || windows <= 0 || (long long)windows * 24 >= (1LL << 31))
+        return 0;
+    return launch_separable_chip(a, b, windows, L, n, stream, &L[n]) ? n : 0;
+}
+
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;

@@ -62,6 +62,8 @@ struct bd_engine {
     bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
     bool chip_run = true;             // ... with the tiles between its layers kept on the CU (sepchip.hip; separable = 7: the
                                       // round-3 form that hands them over through global memory)
+    bool chip_ndw = true;             // ... and layer 12 + depthwise 13 behind them in the same launch (separable = 8: layer 12 on
+                                      // its own kernel, as until round 5)
     bool ndw_w12 = true;              // layer 12 (+ the next layer's depthwise) on the 12-wave kernel (separable = 4: 8-wave)
     bool pool_w12 = true;             // layer 14 + pool on the 12-wave kernel, two 512-column halves (separable = 5: 8-wave, four quarters)
     int sep_variant = 0;
@@ -994,6 +996,21 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                     break;
                 }
             }
+            // layers 8-12 + the stride-2 depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchip.hip): reads
+            // buf_a, writes only [windows][3][2][512] into buf_b; timed in layer 12's pointwise slot
+            if (e->fuse_sep && e->fuse_next_dw && e->fuse_run && e->chip_run && e->chip_ndw && mode != 0 && e->sep_variant <= 1 &&
+                stop_stage < 0 && skip_dw_layer != l) {
+                const int ran = bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
+                if (ran > 0) {
+                    BD_REPEAT_EXTRA(3 + 2 * (l + ran - 1)) (void)bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
+                    l += ran - 1;
+                    if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                    skip_dw_layer = l + 1;
+                    last = buf_b;
+                    last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * sep[l].cout;
+                    continue;
+                }
+            }
             // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
             // ... and when the NEXT layer is a stride-2 one, its depthwise is applied in that kernel's epilogue
             // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
@@ -1379,10 +1396,11 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     if (stem != 0 && stem != 2 && stem != 3) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2 or 3");
     if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 6 &&
-        separable != 7 && separable != 9 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 7, 9 or 12");
+        separable != 7 && separable != 8 && separable != 9 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 7, 8, 9 or 12");
     h->chip_run = separable != 7;            // 7: layers 8-11 as one launch that hands its tiles over through global memory
-    if (separable == 7) separable = 1;
+    h->chip_ndw = separable != 7 && separable != 8;      // 8: the on-chip run stops at layer 11; layer 12 + depthwise 13 on their own
+    if (separable == 7 || separable == 8) separable = 1;
     h->fuse_f32 = separable == 6;            // exact-f32 mode: one kernel per separable layer (sepf32.hip); the f16 modes as 1
     if (separable == 6) separable = 1;
     h->fuse_stem = stem != 0;

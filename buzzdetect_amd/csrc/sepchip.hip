@@ -49,26 +49,32 @@ constexpr float kF16MaxChip = 65504.0f;
 constexpr int kChipHalfBytes = 97 * 64;
 constexpr int kChipSlotBytes = 2 * kChipHalfBytes;
 
+constexpr int kChipMaxLayers = 5;
 struct ChipChain {
-    const float* dw_w[4];          // [9][512] depthwise taps * bn scale * 2^act_exp
-    const float* dw_b[4];          // [512]
-    const _Float16* whi[4];        // pointwise weights, MFMA B-fragment order [512/32][512/16][64][8]
-    const _Float16* wlo[4];
-    const float* pw_u[4];          // [512] epilogue factors
-    const float* pw_b[4];          // [512]
+    const float* dw_w[kChipMaxLayers];          // [9][512] depthwise taps * bn scale * 2^act_exp ([512] shift behind them)
+    const float* dw_b[kChipMaxLayers];          // [512]
+    const _Float16* whi[kChipMaxLayers];        // pointwise weights, MFMA B-fragment order [512/32][512/16][64][8]
+    const _Float16* wlo[kChipMaxLayers];
+    const float* pw_u[kChipMaxLayers];          // [512] epilogue factors
+    const float* pw_b[kChipMaxLayers];          // [512]
+    const float* ndw_w;                         // NDW: taps [9][512] + shift [512] of the stride-2 depthwise behind the run
 };
 // Pointer `field` of layer `li`, read from the kernel-argument segment with a scalar load (the chain is the kernel's FIRST
 // argument, i.e. at offset 0).  Indexing the by-value argument with a run-time layer makes a scratch copy of it; selecting
-// among its 24 pointers keeps all of them in scalar registers for the whole kernel (144 of them spilled to lanes).
+// among its 30 pointers keeps all of them in scalar registers for the whole kernel (144 of them spilled to lanes).
 template <typename T>
 __device__ __forceinline__ const T* chain_ptr(int field, int li) {
     typedef const __attribute__((address_space(4))) unsigned long long* kptr;
     const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    return reinterpret_cast<const T*>(ka[field * 4 + li]);
+    return reinterpret_cast<const T*>(ka[field * kChipMaxLayers + li]);
 }
-static_assert(sizeof(ChipChain) == 24 * 8, "six tables of four pointers");
+static_assert(sizeof(ChipChain) == (6 * kChipMaxLayers + 1) * 8, "six tables of five pointers + one");
 
-template <bool PLAIN, int NSLOT, bool TRACE = false>
+// NDW (layer 12 closes the run and layer 13 is a stride-2 layer): the run's output is not written; layer 13's depthwise
+// (3 x 3, stride 2, SAME = pad 0 before / 1 after on the 6 x 4 map: outputs 3 x 2) is applied to it in registers - after the
+// same half-wave swap as between the layers a lane holds whole windows of its channel - and only [windows][3][2][512] goes
+// to Y: the arithmetic of sep_w12_kernel's NDW = 1 epilogue (shift, then the taps in row-major order with fmaf, ReLU).
+template <bool PLAIN, int NSLOT, bool TRACE = false, bool NDW = false>
 __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, const float* X, float* Y, int nl,
                                                            long long M, unsigned* __restrict__ range_flag,
                                                            unsigned long long* __restrict__ dbg = nullptr, int tune = 0) {
@@ -341,21 +347,70 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
     // ---------------------------------------------------------------------- the run's output: bias + ReLU from the accumulators
     // (stores past the tile's valid rows are dropped by the resource's range check: no per-store masks)
     {
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)m0 * K, 0, tile_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t pur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(chain_ptr<float>(4, nl - 1)), 0, K * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t pbr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(chain_ptr<float>(5, nl - 1)), 0, K * 4, 0x00020000);
-        const unsigned yo = (4u * fh * K) * 4 + c4;
+        if constexpr (!NDW) {
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)m0 * K, 0, tile_bytes, 0x00020000);
+            const unsigned yo = (4u * fh * K) * 4 + c4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int st = j ? wc + 8 : wc;
-            const float u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pur, c4, 128 * st, 0));
-            const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pbr, c4, 128 * st, 0));
+            for (int j = 0; j < 2; ++j) {
+                const int st = j ? wc + 8 : wc;
+                const float u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pur, c4, 128 * st, 0));
+                const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pbr, c4, 128 * st, 0));
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(acc[i][j][r], u, b), 0.0f)), yrs, yo,
-                                                          ((32 * i + 8 * (r >> 2) + (r & 3)) * K + 32 * st) * 4, 0);
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(acc[i][j][r], u, b), 0.0f)), yrs, yo,
+                                                              ((32 * i + 8 * (r >> 2) + (r & 3)) * K + 32 * st) * 4, 0);
+            }
+        } else {
+            // the tile's windows are rows m0 / 24 .. + 3 of the [windows][6][512] output: 6 output rows per window, a quarter
+            // of the tile's bytes
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)(m0 / 4) * K, 0, tile_bytes / 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ntaps = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ch.ndw_w), 0, 10 * K * 4, 0x00020000);
+            const unsigned yo = (12u * fh * K) * 4 + c4;            // this lane's windows 2 fh, 2 fh + 1: output rows 12 fh ..
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int st = j ? wc + 8 : wc;
+                const float u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pur, c4, 128 * st, 0));
+                const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pbr, c4, 128 * st, 0));
+                float wt[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    wt[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ntaps, c4, (t * K + 32 * st) * 4, 0));
+                const float shift = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ntaps, c4, (9 * K + 32 * st) * 4, 0));
+                float ev[12][4];
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const float a01 = fmaxf(fmaf(acc[q >> 2][j][4 * (q & 3) + x], u, b), 0.0f);
+                        const float a23 = fmaxf(fmaf(acc[(q + 6) >> 2][j][4 * ((q + 6) & 3) + x], u, b), 0.0f);
+                        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a01),
+                                                                        __builtin_bit_cast(unsigned, a23), false, false);
+                        ev[2 * q][x] = __builtin_bit_cast(float, (unsigned)r[0]);
+                        ev[2 * q + 1][x] = __builtin_bit_cast(float, (unsigned)r[1]);
+                    }
+#pragma unroll
+                for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox) {
+                        v2f a = {shift, shift};
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) {
+                                const int iy = 2 * oy + kh, ix = 2 * ox + kw;
+                                if (iy >= 6 || ix >= 4) continue;            // SAME padding of a stride-2 layer: one row / column behind the map
+                                a = __builtin_elementwise_fma(v2f{ev[iy][ix], ev[6 + iy][ix]}, v2f{wt[kh * 3 + kw], wt[kh * 3 + kw]}, a);
+                            }
+#pragma unroll
+                        for (int w = 0; w < 2; ++w)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(w ? a.y : a.x, 0.0f)), yrs, yo,
+                                                                  ((6 * w + 2 * oy + ox) * K + 32 * st) * 4, 0);
+                    }
+            }
         }
     }
     if (range_flag && !(rmax <= kF16MaxChip)) *range_flag = 1u;
@@ -366,8 +421,8 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
 
 constexpr int kMaxDevicesChip = 64;
 
-template <bool PLAIN>
-void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long long M, hipStream_t stream) {
+template <bool PLAIN, bool NDW>
+void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long long M, const float* ndw_w, hipStream_t stream) {
     ChipChain ch{};
     for (int i = 0; i < nl; ++i) {
         ch.dw_w[i] = dw_w_of(L[i]);
@@ -377,6 +432,7 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
         ch.pw_u[i] = L[i].pw_u;
         ch.pw_b[i] = L[i].pw_b;
     }
+    ch.ndw_w = ndw_w;
     constexpr int NSLOT = 13;
     constexpr int lds = NSLOT * kChipSlotBytes;
     static_assert(lds <= 160 * 1024, "the ring must fit the CU's LDS");
@@ -384,39 +440,37 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (kMaxDevicesChip - 1)], [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_chip_kernel<PLAIN, NSLOT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_chip_kernel<PLAIN, NSLOT, false, NDW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const long long tiles = (M + 95) / 96;
     int tune = 0;
-#ifdef BD_KERNEL_TRACE      // developer build only: BD_CHIP_TUNE = priority policy under test; BD_WS_TRACE=7 stamps workgroup 0
+#ifdef BD_KERNEL_TRACE      // developer build only: BD_CHIP_TUNE = policy under test; BD_WS_TRACE=7 stamps workgroup 0
     if (const char* tn = getenv("BD_CHIP_TUNE")) tune = atoi(tn);
     const char* tr = getenv("BD_WS_TRACE");
     if (tr && tr[0] == '7') {
         static unsigned long long* dbg = nullptr;
         static int shots = 0;
-        if (!dbg) {
-            (void)hipMalloc(&dbg, 128 * 8);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_chip_kernel<PLAIN, NSLOT, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        }
+        if (!dbg) (void)hipMalloc(&dbg, 128 * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_chip_kernel<PLAIN, NSLOT, true, NDW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipMemsetAsync(dbg, 0, 128 * 8, stream);
-        hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT, true>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl,
+        hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT, true, NDW>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl,
                            M, L[0].range_flag, dbg, tune);
         (void)hipStreamSynchronize(stream);
         unsigned long long h[128];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         if (++shots == 8)
             for (int w = 0; w < 2; ++w) {
-                fprintf(stderr, "[trace] on-chip run, wave %d: cycles between stamps (start | dw0 j0 j1 | per layer: B1, stages 0-2, B2, pend, "
-                                "B3, stages 3-15, [dw j0, dw j1, B4] | stores):", w ? 5 : 0);
+                fprintf(stderr, "[trace] on-chip run of %d layers, wave %d: cycles between stamps (start | dw0 j0 j1 | per layer: B1, stages 0-2, B2, pend, "
+                                "B3, stages 3-15, [dw j0, dw j1, B4] | stores):", nl, w ? 5 : 0);
                 for (int i = 1; i < 64 && h[w * 64 + i]; ++i) fprintf(stderr, " %llu", h[w * 64 + i] - h[w * 64 + i - 1]);
                 fprintf(stderr, "\n");
             }
         return;
     }
 #endif
-    hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl, M,
+    hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT, false, NDW>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl, M,
                        L[0].range_flag, (unsigned long long*)nullptr, tune);
 }
 
@@ -424,14 +478,25 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
 
 // A run of stride-1 512 -> 512 layers on the 6 x 4 map with the tiles between its layers kept on the CU: reads `in`, writes
 // `out`.  They may be the same buffer: a workgroup has read all rows of its tile before it writes any.  The caller has
-// checked the shapes (launch_separable_run).  False (nothing launched) when a layer's shift table does not follow its taps
-// (the kernel reads both through one [10][512] resource; engine.hip lays dw_b16 behind dw_w16).
-bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream) {
+// checked the shapes (launch_separable_run).  With `next` (the stride-2 layer behind the run) the run's output is not written:
+// next's depthwise is applied in the epilogue and out = [windows][3][2][512] (then `out` must not be `in`: the tiles' rows
+// differ).  False (nothing launched) when a layer's shift table does not follow its taps (the kernel reads both through
+// one [10][512] resource; engine.hip lays dw_b16 behind dw_w16).
+bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
+                           const SepLayer* next) {
+    if (nl < 1 || nl > kChipMaxLayers) return false;
     for (int i = 0; i < nl; ++i)
         if (dw_b_of(L[i]) != dw_w_of(L[i]) + 9 * 512) return false;
+    if (next && (dw_b_of(*next) != dw_w_of(*next) + 9 * 512 || next->cin != 512 || next->stride != 2 || in == out)) return false;
     const long long M = (long long)windows * 24;
-    if (L[0].pw_mode == 2) launch_chip<true>(in, out, L, nl, M, stream);
-    else launch_chip<false>(in, out, L, nl, M, stream);
+    const float* nw = next ? dw_w_of(*next) : nullptr;
+    if (L[0].pw_mode == 2) {
+        if (next) launch_chip<true, true>(in, out, L, nl, M, nw, stream);
+        else launch_chip<true, false>(in, out, L, nl, M, nw, stream);
+    } else {
+        if (next) launch_chip<false, true>(in, out, L, nl, M, nw, stream);
+        else launch_chip<false, false>(in, out, L, nl, M, nw, stream);
+    }
     return true;
 }
 

@@ -47,7 +47,9 @@ logging.addLevelName(PROGRESS, "PROGRESS")
 log = logging.getLogger("buzzdetect")
 
 EXIT = "exit"
-BATCH_WINDOWS = 1024              # windows gathered per launch set
+BATCH_WINDOWS = 4096              # windows gathered per launch set (when that many are waiting): the engine walks a set in
+                                  # passes of 1024 windows, so a set of one 600 s chunk (625 / 1249 windows) ends in a pass that
+                                  # is a fifth full; four passes' worth leaves at most one partial pass in five
 BATCH_CHUNKS = 64                 # bd_predict_batch's limit
 FILE_SIZE_MINIMUM = 5000          # src/config.py:20
 BOTTLENECK_SECONDS = 0.01         # src/inference/worker.py:86

@@ -272,8 +272,10 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    workgroup, l4_window_kernel), and layers 8-11 (one shape, windows independent) are ONE launch
                    in which every workgroup takes its four windows through the four layers with the tiles between the
                    layers kept on the CU - accumulators -> depthwise in registers -> LDS ring, sepchip.hip - so that only
-                   the run's input and output touch global memory (timed in layer 11's pointwise slot).  7: as 1 with the
-                   round-3 form of that launch, which hands the tiles over through global memory (test hook).  2: the same with layer 4 as overlapping band tiles of the generic kernel (test
+                   the run's input and output touch global memory - and layer 12 with the stride-2 depthwise of layer 13 rides
+                   in the same launch (timed in layer 12's pointwise slot).  8: as 1 with that launch ending at layer 11 and
+                   layer 12 + depthwise 13 on the 12-wave kernel (timed in layer 11's / 12's slots; test hook).  7: as 8 with the
+                   round-3 form of the run, which hands the tiles over through global memory (test hook).  2: the same with layer 4 as overlapping band tiles of the generic kernel (test
                    hook).  3: as 1 with one launch per layer for layers 8-11 (test hook).  4: as 1 with layer 12 on the
                    8-wave kernel (256-column tiles) instead of the 12-wave one (test hook).  5: as 1 with layer 14 + pool on the
                    8-wave kernel (four 256-column tiles on all CUs: faster alone, slower in a full pipeline) instead of the

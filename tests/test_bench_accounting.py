@@ -10,7 +10,8 @@ import bench
 from oracle import yamnet_oracle as O
 
 # profile slots that see a launch per batch (engine.hip run_chunks): slot 2 l + 1 is layer l + 2's pointwise / fused kernel
-DEFAULT = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                    # layers 8-11 as one launch, timed in layer 11's slot
+DEFAULT = [0, 5, 7, 9, 11, 13, 23, 25, 27, 28]                        # layers 8-12 + depthwise 13 as one launch, timed in layer 12's slot
+RUN_TO_11 = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                  # bd_set_fusion separable = 8 / 7: the run ends at layer 11
 PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # bd_set_fusion separable = 3
 
 
@@ -32,22 +33,28 @@ def _network_flops():
 
 
 def test_slot_plan_adds_up_to_the_network_in_both_layouts():
-    for slots in (DEFAULT, PER_LAYER):
-        plan = _plan(slots)
-        assert sorted(plan) == sorted(slots)
-        assert sum(v[3] for v in plan.values()) == _network_flops()
-    a, b = _plan(DEFAULT, chip=False), _plan(PER_LAYER)
+    for slots in (DEFAULT, RUN_TO_11, PER_LAYER):
+        for chip in (True, False):
+            if slots is DEFAULT and not chip:
+                continue
+            plan = _plan(slots, chip)
+            assert sorted(plan) == sorted(slots)
+            assert sum(v[3] for v in plan.values()) == _network_flops()
+    a, b = _plan(RUN_TO_11, chip=False), _plan(PER_LAYER)
     assert sum(v[2] for v in a.values()) == sum(v[2] for v in b.values())       # round-3 form of the run: it still stores every layer
-    # the on-chip run (sepchip.hip, the default): the same FLOP, and of the four layers' 8 x 49 152 B per window only the
-    # run's input and output are algorithmic traffic
-    c = _plan(DEFAULT)
-    assert sum(v[3] for v in c.values()) == _network_flops()
+    # the on-chip run (sepchip.hip): the same FLOP, and of the four layers' 8 x 49 152 B per window only the run's input and
+    # output are algorithmic traffic
+    c = _plan(RUN_TO_11)
     assert c[21][:2] == ("sep8-11", "sep_chip_kernel") and c[21][2] == 2 * 24 * 512 * 4
     assert sum(v[2] for v in a.values()) - sum(v[2] for v in c.values()) == 6 * 24 * 512 * 4
+    # ... and with layer 12 + depthwise 13 along (the default): [24][512] in, [6][512] out per window
+    d = _plan(DEFAULT)
+    assert d[23][:2] == ("sep8-12+dw13", "sep_chip_kernel") and d[23][2] == (24 + 6) * 512 * 4
+    assert d[23][3] == c[21][3] + c[23][3]
 
 
 def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():
-    plan = _plan(DEFAULT, chip=False)
+    plan = _plan(RUN_TO_11, chip=False)
     assert plan[21][:2] == ("sep8-11", "sep_w12_kernel")
     assert plan[21][3] == 4 * _plan(PER_LAYER)[15][3]
     assert plan[23][:2] == ("sep12+dw13", "sep_w12_ndw_kernel")                 # 512 -> 512 with layer 13's depthwise: 12-wave kernel

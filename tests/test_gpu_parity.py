@@ -371,8 +371,9 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
 
 @pytest.mark.parametrize("windows", [1, 4, 5, 131, 1025])
 def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, windows):
-    """Default path: every workgroup takes its four windows through layers 8-11 in ONE launch with the tiles between the
-    layers kept on the CU (sepchip.hip: accumulators -> depthwise in registers -> LDS ring); hook 7: the round-3 form (each
+    """Default path: every workgroup takes its four windows through layers 8-12 AND the stride-2 depthwise of layer 13 in ONE
+    launch with the tiles between the layers kept on the CU (sepchip.hip: accumulators -> depthwise in registers -> LDS ring);
+    hook 8: that launch ending at layer 11; hook 7: the round-3 form (each
     layer's output written to the other buffer and read back by the same workgroup).  Against one launch per layer
     (bd_set_fusion separable = 3): the same bits, in both f16 modes, whole and partial tiles, first and last workgroup."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=800 + windows)
@@ -382,7 +383,8 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
             engine.set_fusion(True, 3)
             ref_logits = engine.predict(x, 0.96).numpy()
             ref_emb = engine.embed(x, 0.96).numpy()
-            for hook in (4, 5, 7):               # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel
+            for hook in (4, 5, 7, 8):            # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel;
+                                                 # 8 / 7: the on-chip run ending at layer 11 / the round-3 run through global memory
                 engine.set_fusion(True, hook)
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), (mode, hook)
                 assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), (mode, hook)

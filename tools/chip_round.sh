@@ -9,5 +9,5 @@ tail -3 gpurun_out/r05/t_chip$tag.log
 grep -q "rc=0" gpurun_out/r05/t_chip$tag.log || exit 1
 BD_WS_TRACE=7 BUZZDETECT_HIP_LIB=$PWD/buzzdetect_amd/csrc/libtrace.so timeout -k 10 300 python tools/w12_trace.py 1 2>&1 | grep trace > gpurun_out/r05/trace_chip$tag.log
 cat gpurun_out/r05/trace_chip$tag.log
-bash tools/ab_variant.sh 7 "sep8|sep11" > gpurun_out/r05/ab_chip$tag.log 2>&1
+bash tools/ab_variant.sh ${AB_VARIANT:-7} "sep8|sep11|sep12" > gpurun_out/r05/ab_chip$tag.log 2>&1
 tail -12 gpurun_out/r05/ab_chip$tag.log
