@@ -494,6 +494,7 @@ def main() -> int:
     ap.add_argument("--pointwise-mode", choices=["f16x3", "f32", "f16"], default=None,
                     help="profiling only: run the WHOLE bench in this arithmetic mode (the line then carries mode_override; "
                          "the driver's headline never uses it)")
+    ap.add_argument("--stem", type=int, default=None, help="tuning: bd_set_fusion stem code (3 = block stem, 4 = walking stem)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     ap.add_argument("--files-per-step", type=int, default=FILES_PER_STEP,
@@ -541,8 +542,8 @@ def main() -> int:
     for e in engines:
         if args.group_windows:
             e.set_group_windows(args.group_windows)
-        if args.sep_variant is not None:
-            e.set_fusion(True, args.sep_variant)
+        if args.sep_variant is not None or args.stem is not None:
+            e.set_fusion(True if args.stem is None else args.stem, True if args.sep_variant is None else args.sep_variant)
         if args.pointwise_mode is not None:
             e.set_pointwise_mode(args.pointwise_mode)
         if args.pw_variant is not None:

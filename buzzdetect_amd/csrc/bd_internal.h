@@ -164,6 +164,8 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
+void launch_stem_roll(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);   // stemroll.hip
 void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);

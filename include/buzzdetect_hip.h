@@ -265,6 +265,9 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
    stem == 3       (default) ... and layer 3's pointwise convolution: layers 1-3 are one kernel that
                    reads log-mel patches and writes the [24][16][128] layer-3 output; profile slot 5;
                    (in the exact-f32 mode stem != 0 selects the same fusion on v_mfma_f32_32x32x2_f32, sepf32.hip);
+   stem == 4       as 3 on the kernel that walks a window top to bottom and carries the rows its steps share in LDS instead of
+                   recomputing them per row block (stemroll.hip): bit-identical, a quarter fewer vector instructions and
+                   slower (155 vs 130 us per launch, round 5) - a measured alternative, not the default;
    separable != 0  stride-1 layers 4, 6, 8-12, 14: depthwise computed inside the pointwise GEMM, timed
                    in the layer's pointwise slot.  With 1 (default) layers 4, 6 and 12 also apply the NEXT
                    layer's stride-2 depthwise in their epilogue, so depthwise 5, 7 and 13 have no launch of

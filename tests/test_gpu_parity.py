@@ -338,12 +338,22 @@ def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
         plain_pw3 = engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy()
         plain = engine.predict(x, 0.96).numpy()
         plain_half = engine.predict(x, 0.48).numpy()      # overlapping windows read shared log-mel rows
-        for mode in (2, 3):
+        for mode in (2, 3, 4):             # 4: layers 1-3 by walking thirds of a window (stemroll.hip); the taps use the block kernel
             engine.set_fusion(mode, False)
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy(), plain_pw2), mode
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy(), plain_pw3), mode
             assert np.array_equal(engine.predict(x, 0.96).numpy(), plain), mode
             assert np.array_equal(engine.predict(x, 0.48).numpy(), plain_half), mode
+        # the walking stem against the block stem inside the default path, both f16 modes, more windows than resident walks
+        y = O.synthetic_audio(HOP * 1050 + 15600, seed=56)      # (1051 windows: more than one pass, under 2^24 samples)
+        for pw_mode in ("f16x3", "f16"):
+            engine.set_pointwise_mode(pw_mode)
+            engine.set_fusion(3, True)
+            ref, ref_emb = engine.predict(y, 0.96).numpy(), engine.embed(y, 0.96).numpy()
+            engine.set_fusion(4, True)
+            assert np.array_equal(engine.predict(y, 0.96).numpy(), ref), pw_mode
+            assert np.array_equal(engine.embed(y, 0.96).numpy(), ref_emb), pw_mode
+        engine.set_pointwise_mode("f16x3")
     finally:
         engine.set_fusion(True, True)
 
