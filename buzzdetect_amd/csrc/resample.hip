@@ -160,8 +160,12 @@ __device__ __forceinline__ void fir_put8(char* a_hi, char* a_lo, int phys, const
         hv[e] = h0[e]; hv[4 + e] = h1[e];
         lv[e] = l0[e]; lv[4 + e] = l1[e];
     }
+#if defined(BD_FIR_ABLATE) && BD_FIR_ABLATE == 2      // developer build: no staging writes
+    asm volatile("" ::"v"(hv), "v"(lv), "v"(phys));
+#else
     *reinterpret_cast<f16x8*>(a_hi + 16 * phys) = hv;
     *reinterpret_cast<f16x8*>(a_lo + 16 * phys) = lv;
+#endif
 }
 
 // The staged signal of a workgroup: chunk q (eight samples) -> its first frame and its place in LDS.
@@ -324,8 +328,13 @@ __device__ __forceinline__ void fir_body(const T* __restrict__ in, long long n_i
     for (int i = 0; i < KQ; ++i) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
+#if defined(BD_FIR_ABLATE) && BD_FIR_ABLATE == 1      // developer build: no fragment reads (which LDS access conflicts?)
+            f16x8 ah = bh[i], al = bl[i];
+            asm volatile("" : "+v"(ah), "+v"(al));
+#else
             const f16x8 ah = *reinterpret_cast<const f16x8*>(a_hi + abase[t] + koff[i]);
             const f16x8 al = *reinterpret_cast<const f16x8*>(a_lo + abase[t] + koff[i]);
+#endif
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i], acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i], acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i], acc[t], 0, 0, 0);
@@ -333,23 +342,31 @@ __device__ __forceinline__ void fir_body(const T* __restrict__ in, long long n_i
     }
     __syncthreads();                                       // every wave is done with the staged signal
 
-    // ---- the four partial tiles meet in LDS: red[wave][tile][register quad][lane] as float4 ----
-    float4* const red = reinterpret_cast<float4*>(smem);
+    // ---- the four partial tiles meet in LDS: red[wave][tile][register quad][lane], 16 bytes per lane ----
+    // (a native 4-vector, so that both sides are ONE ds_write_b128 / ds_read_b128 per lane: with HIP's float4 struct the
+    //  compiler split the reads into ds_read_b32 / ds_read2_b32 at a 16-byte lane stride - 8 lanes per bank, 24 conflict cycles
+    //  per instruction, 92 % of the kernel's SQ_LDS_BANK_CONFLICT (round 5, tools/fir_conflicts.sh))
+    typedef float fir_v4 __attribute__((ext_vector_type(4)));
+    fir_v4* const red = reinterpret_cast<fir_v4*>(smem);
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            red[((wave * MT + t) * 4 + g) * 64 + lane] =
-                make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+#if defined(BD_FIR_ABLATE) && BD_FIR_ABLATE == 3      // developer build: partial tiles not written (the sums below read garbage)
+            asm volatile("" ::"v"(acc[t][4 * g]), "v"(acc[t][4 * g + 1]), "v"(acc[t][4 * g + 2]), "v"(acc[t][4 * g + 3]));
+#else
+            red[((wave * MT + t) * 4 + g) * 64 + lane] = fir_v4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+#endif
     __syncthreads();
     const int g = wave;                                    // this wave sums register quad g of every tile
     const int col = lane & 31;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        float4 s = red[((0 * MT + t) * 4 + g) * 64 + lane];
+        fir_v4 s = red[((0 * MT + t) * 4 + g) * 64 + lane];
 #pragma unroll
         for (int w = 1; w < kFirWaves; ++w) {
-            const float4 r = red[((w * MT + t) * 4 + g) * 64 + lane];
+            fir_v4 r = red[((w * MT + t) * 4 + g) * 64 + lane];
+            asm volatile("" : "+v"(r));                     // (one 16-byte read: not four dword reads the scheduler may spread out)
             s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
         }
         // accumulator register 4 g + e of lane l is row e + 8 g + 4 (l >> 5), column l & 31 of the tile
