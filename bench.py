@@ -70,11 +70,26 @@ def slot_plan(launches, pool_fused=True, chip=True):
     if launches[1] > 0:
         plan[1] = ("conv1", "conv1_kernel", conv1[0], conv1[1])
     run = None            # layers 8-11 as one launch: [first layer, bytes, flops] of the layers that had no launch of their own
+    # pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one launch (sepmid.hip): nothing in slots 9 and 11, all of it in 13
+    mid_mode = launches[7] > 0 and launches[8] == 0 and launches[9] == 0 and launches[10] == 0 and launches[11] == 0 and \
+        launches[12] == 0 and launches[13] > 0
+    mid = None            # [bytes in, flops] while the layers of that launch are walked
     for layer, (stride, cout) in enumerate(_DEF[1:], start=2):
         ho, wo = h // stride, w // stride
         dw_slot, pw_slot = 2 * layer - 2, 2 * layer - 1
         dw = ((h * w * c + ho * wo * c) * 4, 2 * 9 * ho * wo * c)
         pw = ((ho * wo * c + ho * wo * cout) * 4, 2 * ho * wo * c * cout)
+        if mid_mode and layer in (5, 6, 7):
+            if layer == 5:        # its stride-2 depthwise ran in the layer-4 kernel's epilogue (as below), its 1x1 opens the launch
+                nm, fam, nb, fl = plan[7]
+                plan[7] = (nm + "+dw5", "l4_window_kernel", nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
+                mid = [ho * wo * c * 4, pw[1]]
+            else:
+                mid[1] += dw[1] + pw[1]
+            if layer == 7:
+                plan[13] = ("pw5-pw7", "sep_mid_kernel", mid[0] + ho * wo * cout * 4, mid[1])
+            h, w, c = ho, wo, cout
+            continue
         if stride == 1 and c == 512 and cout == 512 and launches[dw_slot] == 0 and launches[pw_slot] == 0 and launches[0] > 0:
             # timed (and launched) with the last layer of its run (round-3 form, --sep-variant 7: every layer of the run still
             # stores its output and reads it back as the next layer's slabs; default: sepchip.hip keeps them on the CU)
@@ -803,7 +818,7 @@ def main() -> int:
             total_ms = float(ms.sum())
             # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise (layer 12) or the
             #  average pool (layer 14) in the epilogue)
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_w12_ndw_kernel", "stem3_kernel",
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "stem3_kernel",
                          "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]

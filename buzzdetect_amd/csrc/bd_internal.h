@@ -158,6 +158,8 @@ int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int
                          bool on_chip = true);
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
                            const SepLayer* next = nullptr);   // sepchip.hip
+bool launch_separable_mid(const float* in, float* out, int windows, const SepLayer& L5, const SepLayer& L6, const SepLayer& L7,
+                          hipStream_t stream);       // sepmid.hip
 int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     bool band_tiles, hipStream_t stream, bool twelve_waves = true);

@@ -65,6 +65,8 @@ struct bd_engine {
                                       // round-3 form that hands them over through global memory)
     bool chip_ndw = true;             // ... and layer 12 + depthwise 13 behind them in the same launch (separable = 8: layer 12 on
                                       // its own kernel, as until round 5)
+    bool chip_mid = true;             // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one on-chip launch (sepmid.hip;
+                                      // separable = 10, 8, 7: the four kernels of round 4)
     bool ndw_w12 = true;              // layer 12 (+ the next layer's depthwise) on the 12-wave kernel (separable = 4: 8-wave)
     bool pool_w12 = true;             // layer 14 + pool on the 12-wave kernel, two 512-column halves (separable = 5: 8-wave, four quarters)
     int sep_variant = 0;
@@ -1004,6 +1006,19 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                     break;
                 }
             }
+            // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as ONE launch, a window per tile, tiles on the CU (sepmid.hip):
+            // reads the depthwise-5 output the layer-4 kernel left in buf_b, writes the layer-7 output into buf_a; timed in
+            // layer 7's pointwise slot
+            if (l == 3 && skip_dw_layer == 3 && e->fuse_sep && e->fuse_next_dw && e->fuse_run && e->chip_run && e->chip_mid &&
+                mode != 0 && e->sep_variant <= 1 && stop_stage < 0 &&
+                bd::launch_separable_mid(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream)) {
+                BD_REPEAT_EXTRA(13) (void)bd::launch_separable_mid(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream);
+                l = 5;
+                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                last = buf_a;
+                last_floats = (int64_t)gw * sep[5].h_out * sep[5].w_out * sep[5].cout;
+                continue;
+            }
             // layers 8-12 + the stride-2 depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchip.hip): reads
             // buf_a, writes only [windows][3][2][512] into buf_b; timed in layer 12's pointwise slot
             if (e->fuse_sep && e->fuse_next_dw && e->fuse_run && e->chip_run && e->chip_ndw && mode != 0 && e->sep_variant <= 1 &&
@@ -1406,8 +1421,10 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     h->stem_roll = stem == 4;                // 4: as 3 on the kernel that walks thirds of a window (stemroll.hip)
     if (stem == 4) stem = 3;
     if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 6 &&
-        separable != 7 && separable != 8 && separable != 9 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 7, 8, 9 or 12");
+        separable != 7 && separable != 8 && separable != 9 && separable != 10 && separable != 12)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10 or 12");
+    h->chip_mid = separable != 7 && separable != 8 && separable != 10;      // 10: as 1 with layers 5-7 on their four kernels
+    if (separable == 10) separable = 1;
     h->chip_run = separable != 7;            // 7: layers 8-11 as one launch that hands its tiles over through global memory
     h->chip_ndw = separable != 7 && separable != 8;      // 8: the on-chip run stops at layer 11; layer 12 + depthwise 13 on their own
     if (separable == 7 || separable == 8) separable = 1;

@@ -276,7 +276,9 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    in which every workgroup takes its four windows through the four layers with the tiles between the
                    layers kept on the CU - accumulators -> depthwise in registers -> LDS ring, sepchip.hip - so that only
                    the run's input and output touch global memory - and layer 12 with the stride-2 depthwise of layer 13 rides
-                   in the same launch (timed in layer 12's pointwise slot).  8: as 1 with that launch ending at layer 11 and
+                   in the same launch (timed in layer 12's pointwise slot); pointwise 5, layer 6, depthwise 7 and pointwise 7
+                   are one on-chip launch too, a window per tile (sepmid.hip; timed in layer 7's pointwise slot).  10: as 1 with
+                   layers 5-7 on the four kernels of round 4 (test hook).  8: as 10 with the first launch ending at layer 11 and
                    layer 12 + depthwise 13 on the 12-wave kernel (timed in layer 11's / 12's slots; test hook).  7: as 8 with the
                    round-3 form of the run, which hands the tiles over through global memory (test hook).  2: the same with layer 4 as overlapping band tiles of the generic kernel (test
                    hook).  3: as 1 with one launch per layer for layers 8-11 (test hook).  4: as 1 with layer 12 on the

@@ -10,7 +10,8 @@ import bench
 from oracle import yamnet_oracle as O
 
 # profile slots that see a launch per batch (engine.hip run_chunks): slot 2 l + 1 is layer l + 2's pointwise / fused kernel
-DEFAULT = [0, 5, 7, 9, 11, 13, 23, 25, 27, 28]                        # layers 8-12 + depthwise 13 as one launch, timed in layer 12's slot
+DEFAULT = [0, 5, 7, 13, 23, 25, 27, 28]                               # layers 5-7 one launch (slot 13), layers 8-12 + depthwise 13 one (slot 23)
+NO_MID = [0, 5, 7, 9, 11, 13, 23, 25, 27, 28]                         # bd_set_fusion separable = 10: layers 5-7 on their four kernels
 RUN_TO_11 = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                  # bd_set_fusion separable = 8 / 7: the run ends at layer 11
 PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # bd_set_fusion separable = 3
 
@@ -33,7 +34,7 @@ def _network_flops():
 
 
 def test_slot_plan_adds_up_to_the_network_in_both_layouts():
-    for slots in (DEFAULT, RUN_TO_11, PER_LAYER):
+    for slots in (DEFAULT, NO_MID, RUN_TO_11, PER_LAYER):
         for chip in (True, False):
             if slots is DEFAULT and not chip:
                 continue
@@ -48,9 +49,13 @@ def test_slot_plan_adds_up_to_the_network_in_both_layouts():
     assert c[21][:2] == ("sep8-11", "sep_chip_kernel") and c[21][2] == 2 * 24 * 512 * 4
     assert sum(v[2] for v in a.values()) - sum(v[2] for v in c.values()) == 6 * 24 * 512 * 4
     # ... and with layer 12 + depthwise 13 along (the default): [24][512] in, [6][512] out per window
-    d = _plan(DEFAULT)
+    d = _plan(NO_MID)
     assert d[23][:2] == ("sep8-12+dw13", "sep_chip_kernel") and d[23][2] == (24 + 6) * 512 * 4
     assert d[23][3] == c[21][3] + c[23][3]
+    # ... and pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one launch: [96][128] in, [24][512] out per window
+    m = _plan(DEFAULT)
+    assert m[13][:2] == ("pw5-pw7", "sep_mid_kernel") and m[13][2] == (96 * 128 + 24 * 512) * 4
+    assert m[13][3] == d[9][3] + d[11][3] + d[13][3] and m[7] == d[7]
 
 
 def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():

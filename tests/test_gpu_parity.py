@@ -393,7 +393,8 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
             engine.set_fusion(True, 3)
             ref_logits = engine.predict(x, 0.96).numpy()
             ref_emb = engine.embed(x, 0.96).numpy()
-            for hook in (4, 5, 7, 8):            # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel;
+            for hook in (4, 5, 7, 8, 10):        # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel;
+                                                 # 10: layers 5-7 on their four kernels instead of the on-chip launch (sepmid.hip);
                                                  # 8 / 7: the on-chip run ending at layer 11 / the round-3 run through global memory
                 engine.set_fusion(True, hook)
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), (mode, hook)
