@@ -14,8 +14,12 @@
 //     columns 4 h .. 4 h + 3 of ALL twelve map rows of its channel; the one column it lacks for a 3 x 3 window (x = 4 h - 1 or
 //     4 h + 4: the other half-wave's edge) comes with one more swap per map row, columns outside the map are a select to zero.
 //     The depthwise of layer 6 and the stride-2 depthwise of layer 7 then run in registers with compile-time neighbours;
-//   * K <= 256, so a whole A operand fits the ring (8 stages = 97 KB) - no pending stages, three barriers per layer pair:
-//     LDS = [A5 | A7: 49.7 KB] + [A6: 99.3 KB] = 149 KB, one persistent workgroup per CU walking windows.
+//   * K <= 256, so a whole A operand fits the ring (8 stages = 97 KB) - no pending stages.  A5 (4 stages) and A6 (8) share the
+//     ring; A7 has its own 48 KB and collects TWO windows (24 + 24 rows) before layer 7 runs: with one window's 24 rows per
+//     pass layer 7 streamed its 512 KB of weights per window from L2 - 85 B/clk/CU, more than the path delivers - and took 13.5 k
+//     cycles for 6 k of matrix work.  LDS = 97 + 48 + 1 KB, one persistent workgroup per CU walking a contiguous run of windows.
+// Same-box A/B at 938 windows per launch (bench.py --per-slot, three alternations): 99.3 / 98.9 / 99.7 us against 31.3 + 64.2 +
+// 28.8 us for the launches it replaces, 1.844 against 1.779 M windows/s for the job (one window per layer-7 pass: 106.4 us).
 // Arithmetic per element is that of the kernels it replaces (pw_res_kernel, sep_ws_kernel<NDW = 1>): products lo*hi, hi*lo,
 // hi*hi per k16 step in ascending order, relu(fma(acc, u, b)), depthwise = shift then taps in row-major order with fmaf, the
 // range guard's maximum over everything that is split.  Taps outside the map are skipped or multiply a zero (sepchip.hip).
@@ -24,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace bd {
 
@@ -35,11 +40,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kF16MaxMid = 65504.0f;
 constexpr int kHalfA = 97 * 64;                 // one f16 half of a 96-row stage (rows 48.. one row further)
 constexpr int kSlotA = 2 * kHalfA;              // 12416
-constexpr int kHalf7 = 32 * 64;                 // layer 7's A operand: 24 (of 32) rows per stage
-constexpr int kSlot7 = 2 * kHalf7;              // 4096
-constexpr int kOffR2 = 4 * kSlotA;              // A6 behind A5 / A7
-constexpr int kMidLds = kOffR2 + 8 * kSlotA;    // 148992
-static_assert(8 * kSlot7 <= 4 * kSlotA, "layer 7's operand fits the region of layer 5's");
+constexpr int kHalf7 = 48 * 64;                 // layer 7's A operand: the 24 rows of TWO windows per stage
+constexpr int kSlot7 = 2 * kHalf7;              // 6144
+constexpr int kOffA7 = 8 * kSlotA;              // A7 behind the ring A5 and A6 share
+constexpr int kMidLds = kOffA7 + 8 * kSlot7 + 1024;   // 149504 (+ 1 KB: the second row tile of layer 7 reads 16 rows past a stage)
 static_assert(kMidLds <= 160 * 1024, "one workgroup per CU");
 
 struct MidArgs {
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
     }
     // publisher (96-row stages): lane (k = frow, fh) writes rows 48 fh + rl; byte offset of k in a row whose key is m = wb0 ^ (m << 4)
     const int wb0 = fh * (48 * 64 + 64) + ((frow >> 3) << 4) + 2 * (frow & 7);
-    // publisher (layer 7's 32-row stages): rows 4 oy + 2 fh + j
+    // publisher (layer 7's 48-row stages): rows 24 half + 4 oy + 2 fh + j
     const int wb7 = fh * 128 + ((frow >> 3) << 4) + 2 * (frow & 7);
     // reader: lane (frow, fh) supplies A[row 32 i + frow][k = 16 s + 8 fh ..]: slot (2 s + fh) ^ key, key = (frow >> 2) & 3
     const int ra0 = frow * 64 + ((fh ^ ((frow >> 2) & 3)) << 4);
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
     }
 
     // this wave's share of a window's input (the depthwise-5 output): stage wc & 3, rows 24 (wc >> 2) .. + 23 of the lane's half.
-    // Requested a layer ahead of its use: the loads of window n + 1 fly behind the depthwise 7 and pointwise 7 of window n.
+    // Requested a layer ahead of its use: the loads of window n + 1 fly behind the depthwise 7 (and pointwise 7) of window n.
     float vin[24];
     auto fetch_window = [&](int win) {
         const __amdgpu_buffer_rsrc_t xr = MID_RSRC(X + (size_t)win * 96 * 128, 96 * 128 * 4);
@@ -129,10 +133,10 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             vin[t] = MID_LD32(xr, vo, ((8 * (rl >> 2) + (rl & 3)) * 128 + 32 * st) * 4);
         }
     };
-    MID_TS()
-    if ((int)blockIdx.x < windows) fetch_window(blockIdx.x);
-    for (int win = blockIdx.x; win < windows; win += gridDim.x) {
-        // ------------------------------------------------------------------ A5: the window's depthwise-5 output, split, stage wc & 3
+    // one window through pointwise 5, layer 6 and depthwise 7; its 24 depthwise-7 rows land at rows 24 HALF .. of A7
+    auto window_to_a7 = [&](auto half_c, int win, int win_next) {
+        constexpr int HALF = decltype(half_c)::value;
+        // ---- A5: split, stage wc & 3 of the ring
         {
             const int st = wc & 3;
             int wbl = wb0;
@@ -152,10 +156,9 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
                 }
             }
         }
-        __syncthreads();                          // A5 published (and every wave is past the previous window's layer 7)
+        __syncthreads();                          // A5 published
         MID_TS()
-
-        // ------------------------------------------------------------------ pointwise 5: [96][128] x [128][256], column tile wc
+        // ---- pointwise 5: [96][128] x [128][256], column tile wc
         f32x16 acc[3];
         float zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
@@ -188,46 +191,51 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             }
         }
         MID_TS()
-
-        // ------------------------------------------------------------------ depthwise 6 in registers -> A6 stage wc
+        // ---- depthwise 6 in registers; its outputs wait (packed) for the ring: A6 takes the slots A5 is still read from
         {
-            const __amdgpu_buffer_rsrc_t ur = MID_RSRC(a.u5, 1024), br = MID_RSRC(a.b5, 1024), tr = MID_RSRC(a.dw6, 10 * 256 * 4);
-            const float u = MID_LD32(ur, c4, 128 * wc), b = MID_LD32(br, c4, 128 * wc);
-            float wt[9];
+            unsigned out6[48];
+            {
+                const __amdgpu_buffer_rsrc_t ur = MID_RSRC(a.u5, 1024), br = MID_RSRC(a.b5, 1024), tr = MID_RSRC(a.dw6, 10 * 256 * 4);
+                const float u = MID_LD32(ur, c4, 128 * wc), b = MID_LD32(br, c4, 128 * wc);
+                float wt[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wt[t] = MID_LD32(tr, c4, (t * 256 + 32 * wc) * 4);
-            const float shift = MID_LD32(tr, c4, (9 * 256 + 32 * wc) * 4);
-            float ev[12][4], lh[12], rh[12];
-            MID_TILE_TO_MAP(acc, u, b, ev)
-            MID_HALO(ev, lh, rh)
+                for (int t = 0; t < 9; ++t) wt[t] = MID_LD32(tr, c4, (t * 256 + 32 * wc) * 4);
+                const float shift = MID_LD32(tr, c4, (9 * 256 + 32 * wc) * 4);
+                float ev[12][4], lh[12], rh[12];
+                MID_TILE_TO_MAP(acc, u, b, ev)
+                MID_HALO(ev, lh, rh)
+#pragma unroll
+                for (int y = 0; y < 12; ++y)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float sacc = shift;
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh) {
+                            const int iy = y + kh - 1;
+                            if (iy < 0 || iy >= 12) continue;
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) {
+                                const int ie = e + kw - 1;                 // -1: left halo, 4: right halo
+                                const float xv = ie < 0 ? lh[iy] : ie > 3 ? rh[iy] : ev[iy][ie];
+                                sacc = fmaf(xv, wt[kh * 3 + kw], sacc);
+                            }
+                        }
+                        const float o = fmaxf(sacc, 0.0f);
+                        MID_SPLIT(o, pk)
+                        out6[4 * y + e] = pk;
+                    }
+            }
+            __syncthreads();                      // every wave has read A5: the ring is free for A6
+            MID_TS()
             int wbl = wb0;
             asm volatile("" : "+v"(wbl));
-            char* const slot = sm + kOffR2 + wc * kSlotA;
+            char* const slot = sm + wc * kSlotA;
 #pragma unroll
-            for (int y = 0; y < 12; ++y)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float s = shift;
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {
-                        const int iy = y + kh - 1;
-                        if (iy < 0 || iy >= 12) continue;
-#pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) {
-                            const int ie = e + kw - 1;                     // -1: left halo, 4: right halo
-                            const float xv = ie < 0 ? lh[iy] : ie > 3 ? rh[iy] : ev[iy][ie];
-                            s = fmaf(xv, wt[kh * 3 + kw], s);
-                        }
-                    }
-                    const float o = fmaxf(s, 0.0f);
-                    MID_SPLIT(o, pk)
-                    MID_PUT(slot, 4 * y + e, pk)
-                }
+            for (int rl = 0; rl < 48; ++rl) MID_PUT(slot, rl, out6[rl])
         }
         __syncthreads();                          // A6 published
         MID_TS()
-
-        // ------------------------------------------------------------------ pointwise 6: [96][256] x [256][256], column tile wc
+        // ---- pointwise 6: [96][256] x [256][256], column tile wc
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
                     bh[(q + 2) % 3] = MID_LD128(r6h, lane16, (wc * KQ + q + 2) * 1024);
                     bl[(q + 2) % 3] = MID_LD128(r6l, lane16, (wc * KQ + q + 2) * 1024);
                 }
-                const char* const ab = sm + kOffR2 + (q >> 1) * kSlotA;
+                const char* const ab = sm + (q >> 1) * kSlotA;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const char* const ap = ab + ((i == 1 ? ra1 : ra0) ^ ((q & 1) << 5)) + (i == 2 ? 4096 + 64 : 0);
@@ -258,9 +266,8 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             }
         }
         MID_TS()
-
-        // ------------------------------------------------------------------ depthwise 7 (stride 2) in registers -> A7 stage wc
-        if (win + (int)gridDim.x < windows) fetch_window(win + gridDim.x);
+        // ---- depthwise 7 (stride 2) in registers -> rows 24 HALF .. of A7, stage wc; the next window's input is requested here
+        if (win_next >= 0) fetch_window(win_next);
         {
             const __amdgpu_buffer_rsrc_t ur = MID_RSRC(a.u6, 1024), br = MID_RSRC(a.b6, 1024), tr = MID_RSRC(a.dw7, 10 * 256 * 4);
             const float u = MID_LD32(ur, c4, 128 * wc), b = MID_LD32(br, c4, 128 * wc);
@@ -274,14 +281,14 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             (void)lh;
             int wbl = wb7;
             asm volatile("" : "+v"(wbl));
-            char* const slot = sm + wc * kSlot7;
+            char* const slot = sm + kOffA7 + wc * kSlot7;
             // output (oy, ox = 2 fh + j) reads map rows 2 oy + kh, columns 2 ox + kw = 4 fh + 2 j + kw; SAME padding of a
             // stride-2 layer: one row / column BEHIND the map (row 12; column 8 = the upper half's right halo = 0)
 #pragma unroll
             for (int oy = 0; oy < 6; ++oy)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float s = shift;
+                    float sacc = shift;
 #pragma unroll
                     for (int kh = 0; kh < 3; ++kh) {
                         const int iy = 2 * oy + kh;
@@ -290,69 +297,93 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
                         for (int kw = 0; kw < 3; ++kw) {
                             const int ie = 2 * j + kw;
                             const float xv = ie > 3 ? rh[iy] : ev[iy][ie];
-                            s = fmaf(xv, wt[kh * 3 + kw], s);
+                            sacc = fmaf(xv, wt[kh * 3 + kw], sacc);
                         }
                     }
-                    const float o = fmaxf(s, 0.0f);
+                    const float o = fmaxf(sacc, 0.0f);
                     MID_SPLIT(o, pk)
-                    // row 4 oy + 2 fh + j of the 32-row stage: key (row >> 2) & 3 = oy & 3
-                    char* const p_ = slot + (wbl ^ ((oy & 3) << 4)) + (4 * oy + j) * 64;
+                    // row 24 HALF + 4 oy + 2 fh + j of the 48-row stage: key (row >> 2) & 3 = (6 HALF + oy) & 3
+                    char* const p_ = slot + (wbl ^ (((6 * HALF + oy) & 3) << 4)) + (24 * HALF + 4 * oy + j) * 64;
                     *reinterpret_cast<unsigned short*>(p_) = (unsigned short)pk;
                     *reinterpret_cast<unsigned short*>(p_ + kHalf7) = (unsigned short)(pk >> 16);
                 }
         }
-        __syncthreads();                          // A7 published
+        __syncthreads();                          // A7's rows of this window published; every wave has read A6
         MID_TS()
-
-        // ------------------------------------------------------------------ pointwise 7: [24 (32)][256] x [256][512], column tiles wc, wc + 8
-        {
-            f32x16 c7[2];
-            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    };
+    // pointwise 7 over the NW windows collected in A7: [24 NW (32 NW)][256] x [256][512], column tiles wc, wc + 8
+    auto layer7 = [&](auto nw_c, int win) {
+        constexpr int NW = decltype(nw_c)::value;
+        f32x16 c7[NW][2];
+        float zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c7[j][r] = zero;
-            constexpr int KQ = 16;
-            const __amdgpu_buffer_rsrc_t r7h = MID_RSRC(a.w7h, 256 * 512 * 2), r7l = MID_RSRC(a.w7l, 256 * 512 * 2);
-            f16x8 bh[4][2], bl[4][2];             // three k16 steps (18 MFMAs) ahead: a step is only six MFMAs here
+                for (int r = 0; r < 16; ++r) c7[i][j][r] = zero;
+        constexpr int KQ = 16;
+        const __amdgpu_buffer_rsrc_t r7h = MID_RSRC(a.w7h, 256 * 512 * 2), r7l = MID_RSRC(a.w7l, 256 * 512 * 2);
+        f16x8 bh[3][2], bl[3][2];
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bh[q][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * KQ + q) * 1024);
-                    bl[q][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * KQ + q) * 1024);
-                }
-            const int ra7 = frow * 64 + ((fh ^ ((frow >> 2) & 3)) << 4);
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                if (q + 3 < KQ) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        bh[(q + 3) & 3][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * KQ + q + 3) * 1024);
-                        bl[(q + 3) & 3][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * KQ + q + 3) * 1024);
-                    }
-                }
-                const char* const ap = sm + (q >> 1) * kSlot7 + (ra7 ^ ((q & 1) << 5));
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(ap), al = *reinterpret_cast<const f16x8*>(ap + kHalf7);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { MID_MMA(c7[j], ah, al, bh[q & 3][j], bl[q & 3][j]) }
-            }
-            MID_TS()
-            // bias + ReLU: accumulator (r, half fh) is output position 8 (r >> 2) + 4 fh + (r & 3) of the 6 x 4 map (< 24: r < 12)
-            const __amdgpu_buffer_rsrc_t ur = MID_RSRC(a.u7, 2048), br = MID_RSRC(a.b7, 2048);
-            const __amdgpu_buffer_rsrc_t yr = MID_RSRC(Y + (size_t)win * 24 * 512, 24 * 512 * 4);
-            const unsigned yo = (4u * fh * 512) * 4 + c4;
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float u = MID_LD32(ur, c4, 128 * (wc + 8 * j)), b = MID_LD32(br, c4, 128 * (wc + 8 * j));
+                bh[q][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * KQ + q) * 1024);
+                bl[q][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * KQ + q) * 1024);
+            }
+        const int ra7 = frow * 64 + ((fh ^ ((frow >> 2) & 3)) << 4);          // row frow (+ 32): key (row >> 2) & 3
 #pragma unroll
-                for (int r = 0; r < 12; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(c7[j][r], u, b), 0.0f)), yr, yo,
-                                                          ((8 * (r >> 2) + (r & 3)) * 512 + 32 * (wc + 8 * j)) * 4, 0);
+        for (int q = 0; q < KQ; ++q) {
+            if (q + 2 < KQ) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[(q + 2) % 3][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * KQ + q + 2) * 1024);
+                    bl[(q + 2) % 3][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * KQ + q + 2) * 1024);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const char* const ap = sm + kOffA7 + (q >> 1) * kSlot7 + (ra7 ^ ((q & 1) << 5)) + i * 2048;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(ap), al = *reinterpret_cast<const f16x8*>(ap + kHalf7);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { MID_MMA(c7[i][j], ah, al, bh[q % 3][j], bl[q % 3][j]) }
             }
         }
-        __syncthreads();                          // every wave has read A7: its region takes the next window's A5
         MID_TS()
+        // bias + ReLU: accumulator (i, r, half fh) is row 32 i + 8 (r >> 2) + 4 fh + (r & 3) of the NW x 24 output rows of the
+        // windows win, win + 1 (consecutive in Y); rows past them are dropped by the resource's range
+        const __amdgpu_buffer_rsrc_t ur = MID_RSRC(a.u7, 2048), br = MID_RSRC(a.b7, 2048);
+        const __amdgpu_buffer_rsrc_t yr = MID_RSRC(Y + (size_t)win * 24 * 512, NW * 24 * 512 * 4);
+        const unsigned yo = (4u * fh * 512) * 4 + c4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float u = MID_LD32(ur, c4, 128 * (wc + 8 * j)), b = MID_LD32(br, c4, 128 * (wc + 8 * j));
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+#pragma unroll
+                for (int r = 0; r < (NW == 1 ? 12 : 16); ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(c7[i][j][r], u, b), 0.0f)), yr, yo,
+                                                          ((32 * i + 8 * (r >> 2) + (r & 3)) * 512 + 32 * (wc + 8 * j)) * 4, 0);
+        }
+        MID_TS()
+    };
+
+    MID_TS()
+    // a contiguous run of windows per workgroup, taken two at a time (the last one alone when the run is odd)
+    const int w_begin = (int)(((long long)blockIdx.x * windows) / gridDim.x);
+    const int w_end = (int)(((long long)(blockIdx.x + 1) * windows) / gridDim.x);
+    if (w_begin < w_end) fetch_window(w_begin);
+    for (int win = w_begin; win < w_end; win += 2) {
+        const bool two = win + 1 < w_end;
+        window_to_a7(std::integral_constant<int, 0>{}, win, win + 1 < w_end ? win + 1 : -1);
+        if (two) {
+            window_to_a7(std::integral_constant<int, 1>{}, win + 1, win + 2 < w_end ? win + 2 : -1);
+            layer7(std::integral_constant<int, 2>{}, win);
+        } else {
+            layer7(std::integral_constant<int, 1>{}, win);
+        }
     }
     if (range_flag && !(rmax <= kF16MaxMid)) *range_flag = 1u;
 #undef MID_TS
@@ -399,7 +430,7 @@ void launch_mid(const float* in, float* out, int windows, const SepLayer& L5, co
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         if (++shots == 8)
             for (int w = 0; w < 2; ++w) {
-                fprintf(stderr, "[trace] mid run, wave %d: cycles between stamps (per window: A5+B1, K5, dw6+B2, K6, dw7+B3, K7, stores+B4):", w ? 5 : 0);
+                fprintf(stderr, "[trace] mid run, wave %d: cycles between stamps (per window: A5+B1, K5, dw6+Bx, publish+B2, K6, dw7+B3; per pair: K7, stores):", w ? 5 : 0);
                 for (int i = 1; i < 64 && h[w * 64 + i]; ++i) fprintf(stderr, " %llu", h[w * 64 + i] - h[w * 64 + i - 1]);
                 fprintf(stderr, "\n");
             }
