@@ -20,6 +20,8 @@
 // column halves for the 1024-channel layers) the depthwise is computed once per position.
 #include "bd_internal.h"
 
+#include <type_traits>
+
 #include <mutex>
 
 namespace bd {
@@ -286,35 +288,43 @@ __global__ __launch_bounds__(256, 3) void stem3_f32_kernel(const float* __restri
 }
 
 // Layer 4 (128 -> 128 on the 24 x 16 map) + the stride-2 depthwise of layer 5 in exact f32 as ONE kernel, in the manner of
-// the stem: a tile is two output rows of depthwise 5 in one window; they need five layer-4 rows (one is shared with the
-// neighbouring tile and computed twice; 80 positions, padded to three 32-row matrix tiles) and seven input rows.
-// Persistent workgroups (two per CU, 67 KB of LDS each) walk the 6 x windows tiles.  The 128 input channels go through in
-// four chunks of 32, software-pipelined with ONE barrier per chunk (two band buffers, two A buffers):
+// the stem: a tile is two output rows of depthwise 5 in one window; they need the five layer-4 rows 4 ob .. 4 ob + 4, the last
+// of which is the first row of the tile below.  Persistent workgroups (two per CU, 74 KB of LDS each) walk a contiguous run of
+// tiles, each window from its bottom tile UP, so that row 4 ob + 4 is already there: the tile below left it in LDS (the window's
+// bottom tile: the zero padding).  A tile therefore computes FOUR rows = 64 positions = exactly two 32-row matrix tiles, from
+// six input rows (round 5; until then every tile computed all five rows as three matrix tiles: 1.5 x the layer's MFMAs).  Only
+// the first tile of a run that starts inside a window has nothing to take over and runs the five-row form (NT = 3).
+// The 128 input channels go through in four chunks of 32, software-pipelined with ONE barrier per chunk (two band buffers, two
+// A buffers):
 //   chunk k     v_mfma_f32_32x32x2_f32 on A buffer k & 1, weights as the A operand (lane = position in the accumulators),
-//               k ascending; then depthwise 4 of chunk k + 1: band buffer -> f32 A tile [96][32] (16-byte chunks XORed with
-//               (row >> 1) & 7); the band [7][18][32] of chunk k + 2 (zero halo columns, zero rows outside the map) is in
+//               k ascending; then depthwise 4 of chunk k + 1: band buffer -> f32 A tile [32 NT][32] (16-byte chunks XORed with
+//               (row >> 1) & 7); the band [6 (7)][18][32] of chunk k + 2 (zero halo columns, zero rows outside the map) is in
 //               flight from HBM into registers meanwhile - for the last two chunks that is the NEXT tile's first band
-//   then        bias + ReLU -> f32 tile P[80][132] (rows past the map are depthwise 5's zero padding), depthwise 5 on P -> HBM
+//   then        bias + ReLU -> f32 tile P[64 (80)][132], depthwise 5 on P and the kept row -> HBM; the tile's first row goes to
+//               the keep buffer behind the next barrier (from the registers of the lanes that hold it)
 // Both depthwise layers' taps sit in LDS for the life of the workgroup.  The chain of IEEE operations per element is that
 // of depthwise_kernel, pointwise_kernel, depthwise_kernel: bit-identical to the three kernels it replaces (316 us per 1024
-// windows -> 214 us), whose two intermediate tensors (201 MB each) never exist.  The matrix pipe is busy 55-60 % of the time
-// (1.5 x the layer's MFMAs: 96 rows for 64 new positions): what is left is the phases of a tile that no other wave covers
-// at two waves per SIMD.
+// windows), whose two intermediate tensors (201 MB each) never exist.
 __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict__ X, const float* __restrict__ dw4_w,
                                                         const float* __restrict__ dw4_b, const float* __restrict__ W4,
                                                         const float* __restrict__ pw4_b, const float* __restrict__ dw5_w,
                                                         const float* __restrict__ dw5_b, float* __restrict__ out, int windows) {
-    constexpr int H = 24, W = 16, C = 128, R4 = 5, NPOS = R4 * W;   // 80 positions
+    constexpr int H = 24, W = 16, C = 128;
     constexpr int KC = 32, PW = C + 4;
-    constexpr int BAND_BYTES = 7 * 18 * KC * 4, A_BYTES = 96 * KC * 4;   // 16128, 12288; two of each (chunk k + 1 is prepared
-    constexpr int OFF_BAND = 0, OFF_A = 2 * BAND_BYTES;                  // while chunk k is multiplied)
-    constexpr int P_BYTES = NPOS * PW * 4;                          // 42240, aliases from 0 after the product
-    constexpr int LDS_BYTES = P_BYTES > OFF_A + 2 * A_BYTES ? P_BYTES : OFF_A + 2 * A_BYTES;
+    constexpr int BAND_BYTES = 7 * 18 * KC * 4, A_BYTES = 80 * KC * 4;   // 16128, 10240; two of each (chunk k + 1 is prepared
+    constexpr int OFF_BAND = 0, OFF_A = 2 * BAND_BYTES;                  // while chunk k is multiplied; rows 80 .. 95 of the
+                                                                         // five-row form's third matrix tile read what follows)
+    constexpr int P_BYTES = 80 * PW * 4;                            // 42240, aliases from 0 after the product
+    constexpr int LDS_BYTES = OFF_A + 2 * A_BYTES;                  // 52736
+    static_assert(P_BYTES <= LDS_BYTES, "P aliases the band and A buffers");
     constexpr int OFF_TAPS = LDS_BYTES;                             // both depthwise layers' taps and shifts: [10][128] f32 each
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 2 * 10 * C * 4];
+    constexpr int OFF_KEEP = OFF_TAPS + 2 * 10 * C * 4;             // the layer-4 row the tile above needs: [16][132] f32
+    __shared__ __attribute__((aligned(16))) char smem[OFF_KEEP + W * PW * 4 + 2048];   // (+ 2 KB: rows 80 .. 95 of A buffer 1 end
+                                                                                       //  past the keep row)
     float* const P = reinterpret_cast<float*>(smem);
     float* const s_t4 = reinterpret_cast<float*>(smem + OFF_TAPS);  // rows 0 .. 8 the taps, row 9 the shift
     float* const s_t5 = s_t4 + 10 * C;
+    float* const keep = reinterpret_cast<float*>(smem + OFF_KEEP);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
@@ -339,20 +349,9 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
     // fetched per chunk, 16 registers instead of 64)
     const float* const w4row = W4 + (size_t)(32 * wave + frow) * C + 4 * fh;
     const int c4 = tid & 7, pcol = (tid >> 3) & 15, phalf = tid >> 7;     // depthwise 4: channel quad, map column, row parity
-    const int total = 6 * windows;
-    // Tile id -> (window, band).  Workgroups go to the XCDs round-robin by ID and the grid is a multiple of 8, so tile t runs
-    // on XCD t & 7: the six bands of a window share input rows and go to ONE XCD (one L2).
-    auto tile_of = [&](int id, int& win, int& ob) {
-        const int full = (windows >> 3) * 48;
-        if (id < full) {
-            const int idx = id >> 3;
-            win = (idx / 6) * 8 + (id & 7);
-            ob = idx % 6;
-        } else {
-            win = (windows >> 3) * 8 + (id - full) / 6;
-            ob = (id - full) % 6;
-        }
-    };
+    // this workgroup's run of tiles; tile g = window g / 6, band 5 - g % 6 (bottom band first)
+    const long long total = 6ll * windows;
+    const int g_begin = (int)(blockIdx.x * total / gridDim.x), g_end = (int)((blockIdx.x + 1) * total / gridDim.x);
     // the band of a chunk is fetched into registers ahead of its use (in flight behind the depthwise and the product; the
     // first band of the NEXT tile behind this tile's last chunks and epilogue)
     // Loads WITHOUT a branch (clamped address, zeroed when stored to LDS): a load under a branch cannot be counted by the
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
     // were loaded ahead of them, i.e. in front of the matrix instructions the loads are meant to hide behind.
     float4 band[4];
     unsigned band_ok = 0;
-    auto fetch_band = [&](int win, int ob, int kc) {
+    auto fetch_band = [&](int win, int ob, int kc, int rows) {        // rows = 6, or 7 for the five-row form
         const float* const xin = X + (size_t)win * H * W * C;
         band_ok = 0;
 #pragma unroll
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
             const int cc = i & 7, pos = i >> 3;
             const int row = pos / 18, col = pos - row * 18;
             const int ih = 4 * ob - 1 + row, iw = col - 1;
-            const bool ok = i < 7 * 18 * 8 && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            const bool ok = row < rows && ih >= 0 && ih < H && iw >= 0 && iw < W;
             band_ok |= ok ? 1u << u : 0u;
             const int ihc = ih < 0 ? 0 : ih >= H ? H - 1 : ih, iwc = iw < 0 ? 0 : iw >= W ? W - 1 : iw;
             band[u] = *reinterpret_cast<const float4*>(xin + ((size_t)ihc * W + iwc) * C + kc * KC + cc * 4);
@@ -384,62 +383,57 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
             if (i < 7 * 18 * 8) *reinterpret_cast<float4*>(smem + OFF_BAND + (kc & 1) * BAND_BYTES + i * 16) = v;
         }
     };
-    // depthwise 4 of chunk kc (depthwise_kernel's chain: shift, then the taps in (kh, kw) order, zeros outside the map):
-    // band buffer kc & 1 -> A buffer kc & 1
-    auto depthwise4 = [&](int kc) {
-        const float (*s_x)[18][KC] = reinterpret_cast<const float (*)[18][KC]>(smem + OFF_BAND + (kc & 1) * BAND_BYTES);
-        char* const s_a = smem + OFF_A + (kc & 1) * A_BYTES;
-        v4f a[3];
-        a[0] = a[1] = a[2] = *reinterpret_cast<const v4f*>(s_t4 + 9 * C + kc * KC + c4 * 4);
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const v4f wt = *reinterpret_cast<const v4f*>(s_t4 + (kh * 3 + kw) * C + kc * KC + c4 * 4);
-#pragma unroll
-                for (int it = 0; it < 3; ++it) {
-                    const int r = 2 * it + phalf;       // layer-4 row within the tile: 0, 2, 4 / 1, 3 (row 5 is a dummy)
-                    a[it] = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(&s_x[r < R4 ? r + kh : kh][pcol + kw][c4 * 4]), wt, a[it]);
-                }
-            }
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int r = 2 * it + phalf;
-            if (r < R4) {
-                v4f v = a[it];
-                v.x = fmaxf(v.x, 0.0f);
-                v.y = fmaxf(v.y, 0.0f);
-                v.z = fmaxf(v.z, 0.0f);
-                v.w = fmaxf(v.w, 0.0f);
-                const int row = r * W + pcol;
-                *reinterpret_cast<v4f*>(s_a + row * 128 + ((c4 ^ ((row >> 1) & 7)) << 4)) = v;
-            }
-        }
-    };
-    int tile = blockIdx.x, win = 0, ob = 0;
     v4f w4[2][4];                                       // the layer's weights of this chunk and the next (from L2)
 #pragma unroll
     for (int q = 0; q < 4; ++q) w4[0][q] = *reinterpret_cast<const v4f*>(w4row + 8 * q);
-    if (tile < total) {
-        tile_of(tile, win, ob);
-        fetch_band(win, ob, 0);
-    }
-#pragma unroll 1
-    for (; tile < total; tile += gridDim.x) {           // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...
-        const int r0 = 4 * ob;                          // first layer-4 row of the tile
-        f32x16 acc[3];
+
+    // one tile in its NT-matrix-tile form: NT = 2 takes row 4 ob + 4 from the keep buffer, NT = 3 computes it
+    auto tile_body = [&](auto nt_c, int win, int ob, int nwin, int nob, bool more) {
+        constexpr int NT = decltype(nt_c)::value;
+        constexpr int R4 = NT + 2;                      // layer-4 rows computed: 4 or 5
+        // depthwise 4 of chunk kc (depthwise_kernel's chain: shift, then the taps in (kh, kw) order, zeros outside the map):
+        // band buffer kc & 1 -> A buffer kc & 1
+        auto depthwise4 = [&](int kc) {
+            const float (*s_x)[18][KC] = reinterpret_cast<const float (*)[18][KC]>(smem + OFF_BAND + (kc & 1) * BAND_BYTES);
+            char* const s_a = smem + OFF_A + (kc & 1) * A_BYTES;
+            v4f a[NT];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int it = 0; it < NT; ++it) a[it] = *reinterpret_cast<const v4f*>(s_t4 + 9 * C + kc * KC + c4 * 4);
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const v4f wt = *reinterpret_cast<const v4f*>(s_t4 + (kh * 3 + kw) * C + kc * KC + c4 * 4);
+#pragma unroll
+                    for (int it = 0; it < NT; ++it) {
+                        const int r = 2 * it + phalf;   // layer-4 row within the tile: 0, 2 (, 4) / 1, 3 (five-row form: row 5 is a dummy)
+                        a[it] = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(&s_x[r < R4 ? r + kh : kh][pcol + kw][c4 * 4]), wt, a[it]);
+                    }
+                }
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                const int r = 2 * it + phalf;
+                if (r < R4) {
+                    v4f v = a[it];
+                    v.x = fmaxf(v.x, 0.0f);
+                    v.y = fmaxf(v.y, 0.0f);
+                    v.z = fmaxf(v.z, 0.0f);
+                    v.w = fmaxf(v.w, 0.0f);
+                    const int row = r * W + pcol;
+                    *reinterpret_cast<v4f*>(s_a + row * 128 + ((c4 ^ ((row >> 1) & 7)) << 4)) = v;
+                }
+            }
+        };
+        const int r0 = 4 * ob;                          // first layer-4 row of the tile
+        f32x16 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-        __syncthreads();                                // the previous tile's P has been read (first tile: nothing)
         put_band(0);
-        fetch_band(win, ob, 1);
+        fetch_band(win, ob, 1, R4 + 2);
         __syncthreads();                                // band 0 (and, the first time, the taps) are in LDS
         depthwise4(0);
-        int nwin = 0, nob = 0;
-        const bool more = tile + (int)gridDim.x < total;
-        if (more) tile_of(tile + gridDim.x, nwin, nob);
 #pragma unroll                                   // (unrolled: which band to fetch is then known at compile time - see fetch_band)
         for (int kc = 0; kc < C / KC; ++kc) {
             // this lane's weights of the NEXT chunk (of chunk 0 again behind the last one: the next tile starts with them)
@@ -447,14 +441,14 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
             for (int q = 0; q < 4; ++q) w4[(kc + 1) & 1][q] = *reinterpret_cast<const v4f*>(w4row + ((kc + 1) & 3) * KC + 8 * q);
             if (kc + 1 < C / KC) put_band(kc + 1);      // its buffer was last read two chunks ago
             __syncthreads();                            // A tile kc and band kc + 1 are complete; A tile kc - 1 has been read
-            if (kc + 2 < C / KC) fetch_band(win, ob, kc + 2);
-            else if (kc + 2 == C / KC) fetch_band(more ? nwin : win, more ? nob : ob, 0);   // the next tile's first band (or a
+            if (kc + 2 < C / KC) fetch_band(win, ob, kc + 2, R4 + 2);
+            else if (kc + 2 == C / KC) fetch_band(more ? nwin : win, more ? nob : ob, 0, 6);   // the next tile's first band (or a
                                                         // dummy): stays in registers through the last chunk and the epilogue
             asm volatile("" ::: "memory");              // issued HERE, in front of the matrix instructions, not sunk behind them
-            // ---- [96][32] x [32][128]: wave w = output channels 32 w .., three row tiles (positions 80 .. 95 are not used) ----
+            // ---- [32 NT][32] x [32][128]: wave w = output channels 32 w .. ----
             const char* const s_a = smem + OFF_A + (kc & 1) * A_BYTES;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < NT; ++i) {
                 const int row = i * 32 + frow;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -472,14 +466,15 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
 
         // ---- bias + ReLU -> P (transposed accumulators: lane = position 32 i + frow, registers 4 g .. 4 g + 3 = channels
         //      32 wave + 8 g + 4 fh + (0..3)); layer-4 rows past row 23 are depthwise 5's zero padding ----
+        v4f row0[4];                                    // the tile's first row (lanes frow < 16 of matrix tile 0): the tile above needs it
         {
             v4f b4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const v4f*>(pw4_b + 32 * wave + 8 * g + 4 * fh);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < NT; ++i) {
                 const int pos = i * 32 + frow;
-                if (pos < NPOS) {
+                if (pos < R4 * W) {
                     const bool live = r0 + pos / W < H;
                     float* prow = P + pos * PW + 32 * wave + 4 * fh;
 #pragma unroll
@@ -492,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
                             v.w = fmaxf(acc[i][4 * g + 3] + b4[g].w, 0.0f);
                         }
                         *reinterpret_cast<v4f*>(prow + 8 * g) = v;
+                        if (i == 0) row0[g] = v;
                     }
                 }
             }
@@ -512,7 +508,9 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
                     const int col = 2 * ow + kw;
 #pragma unroll
                     for (int o = 0; o < 2; ++o) {
-                        v4f v = *reinterpret_cast<const v4f*>(P + ((2 * o + kh) * W + (col < W ? col : W - 1)) * PW + c32 * 4);
+                        const int pr = 2 * o + kh;      // row 4: the kept one (four-row form)
+                        const float* const prow = (NT == 2 && pr == 4) ? keep : P + pr * W * PW;
+                        v4f v = *reinterpret_cast<const v4f*>(prow + (col < W ? col : W - 1) * PW + c32 * 4);
                         if (kw == 2) {
                             v.x = right_edge ? 0.0f : v.x;
                             v.y = right_edge ? 0.0f : v.y;
@@ -532,8 +530,37 @@ __global__ __launch_bounds__(256, 2) void l4_f32_kernel(const float* __restrict_
                 *reinterpret_cast<v4f*>(dst + ((size_t)o * 8 + ow) * C + c32 * 4) = v;
             }
         }
-        win = nwin;
-        ob = nob;
+        __syncthreads();                                // P and the kept row have been read
+        // the row the next tile takes over: this tile's first one - zeros if the next tile is the bottom of a window
+        // (nobody reads the keep buffer before the next tile's depthwise 5, four barriers from here)
+        if (frow < 16) {
+            const bool bottom_next = ob == 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4f v = row0[g];
+                if (bottom_next) v = v4f{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<v4f*>(keep + frow * PW + 32 * wave + 4 * fh + 8 * g) = v;
+            }
+        }
+    };
+
+    if (g_begin < g_end) {
+        const int win0 = g_begin / 6, ob0 = 5 - g_begin % 6;
+        const bool cold = ob0 != 5;                     // the run starts inside a window: its first tile computes all five rows
+        fetch_band(win0, ob0, 0, cold ? 7 : 6);
+        if (!cold && frow < 16) {                       // row 24 of a window is depthwise 5's zero padding
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<v4f*>(keep + frow * PW + 32 * wave + 4 * fh + 8 * g) = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                                // the taps are in LDS
+#pragma unroll 1
+        for (int g = g_begin; g < g_end; ++g) {
+            const int win = g / 6, ob = 5 - g % 6;
+            const bool more = g + 1 < g_end;
+            const int nwin = (g + 1) / 6, nob = 5 - (g + 1) % 6;
+            if (g == g_begin && cold) tile_body(std::integral_constant<int, 3>{}, win, ob, nwin, nob, more);
+            else tile_body(std::integral_constant<int, 2>{}, win, ob, nwin, nob, more);
+        }
     }
 }
 
@@ -788,11 +815,9 @@ bool launch_l4_f32(const float* in, float* out, int windows, const SepLayer& L4,
     if (windows <= 0) return true;
     if (L4.cin != 128 || L4.cout != 128 || L4.h_in != 24 || L4.w_in != 16 || L4.stride != 1 || L5.cin != 128 || L5.stride != 2)
         return false;
-    // persistent: two workgroups per CU (67 KB of LDS each) walk the 6 x windows tiles; a multiple of 8 for the XCD mapping
-    const int cus = cu_count();
-    int grid = 2 * cus / 8 * 8;
-    if (grid > 6 * windows) grid = (6 * windows + 7) / 8 * 8;
-    if (grid < 8) grid = 8;
+    // persistent: two workgroups per CU (74 KB of LDS each), each with a contiguous run of the 6 x windows tiles
+    int grid = 2 * cu_count();
+    if (grid > 6 * windows) grid = 6 * windows;
     hipLaunchKernelGGL(l4_f32_kernel, dim3(grid), dim3(256), 0, stream, in, L4.dw_w, L4.dw_b, L4.pw_wt, L4.pw_b, L5.dw_w, L5.dw_b,
                        out, windows);
     return true;
