@@ -799,7 +799,9 @@ def main() -> int:
             out["power"] = power
             log(f"board power {power['avg_W']} W of {power['cap_W']} W, shader clock {power['sclk_MHz_avg']} MHz")
         if events_on and launches.sum() > 0 and args.per_slot:
-            for slot, (nm, fam, nb, fl) in sorted(slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None).items()):
+            plan = (slot_plan_f32(launches) if args.pointwise_mode == "f32"
+                    else slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None))
+            for slot, (nm, fam, nb, fl) in sorted(plan.items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
                 wl = windows_per_file * ev_steps / max(int(launches[slot]), 1)     # windows per launch on average
                 log(f"slot {slot:2d} {nm:10s} {fam:24s} {us:8.1f} us  {nb * wl / us / 1e6:6.2f} TB/s  "

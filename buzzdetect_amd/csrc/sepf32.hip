@@ -20,6 +20,7 @@
 // column halves for the 1024-channel layers) the depthwise is computed once per position.
 #include "bd_internal.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #include <mutex>
@@ -32,16 +33,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Layers 1-3 in exact f32 as ONE kernel: the structure of stem3_kernel<true> (cnn.hip: a workgroup owns two output rows of
-// layer 3 in one window; log-mel band -> conv1 band (7 rows) -> depthwise 2 (5 rows) -> 1x1 32 -> 64 -> f32 tile P -> depthwise 3
-// (stride 2) -> 1x1 64 -> 128 -> HBM; 51.7 KB of LDS, three workgroups per CU) with the two 1x1 convolutions on
-// v_mfma_f32_32x32x2_f32 from f32 tiles, every element through the chain of IEEE operations of conv1_kernel, depthwise_kernel
-// and pointwise_kernel (k in that kernel's order: lane half h takes k = 8 s + 4 h + j for the j-th instruction of super-step
-// s).  Neither the conv1 output (201 MB per 1024 windows), the layer-2 output (402 MB) nor the two depthwise outputs reach
-// HBM: the five kernels this replaces take 547 us per 1024 windows, of which the matrix instructions need 89.
+// Layers 1-3 in exact f32 as ONE kernel: the structure of stem3_kernel<true> (cnn.hip: a tile is two output rows of layer 3
+// in one window; log-mel band -> conv1 band -> depthwise 2 -> 1x1 32 -> 64 -> f32 tile P -> depthwise 3 (stride 2) -> 1x1
+// 64 -> 128 -> HBM; 51.7 KB of LDS, three workgroups per CU) with the two 1x1 convolutions on v_mfma_f32_32x32x2_f32 from
+// f32 tiles, every element through the chain of IEEE operations of conv1_kernel, depthwise_kernel and pointwise_kernel (k in
+// that kernel's order: lane half h takes k = 8 s + 4 h + j for the j-th instruction of super-step s).  Neither the conv1
+// output (201 MB per 1024 windows), the layer-2 output (402 MB) nor the two depthwise outputs reach HBM.
+// A tile's two depthwise-3 rows need the layer-2 rows 4 ob .. 4 ob + 4, the last of which is the first row of the tile below.
+// As in l4_f32_kernel, a workgroup walks a run of tiles, every window from its bottom tile UP, and the tile below leaves that
+// row in LDS (the bottom tile of a window: the zero padding): a tile computes FOUR layer-2 rows = 128 positions from six conv1
+// rows (round 5; before: five rows from seven, 1.25 x the layer's MFMAs and depthwise work, 1.17 x conv1's).  A run that starts
+// inside a window first computes that one row alone (ROWS = 1).
 // LDS tiles read as MFMA operands are [row][16-byte chunk] with the chunk index XORed so that the sixteen rows of a
 // ds_read_b128 lane group land on sixteen different slots of the 256-byte bank row:
-//   A2 [160][32 f32] (128-byte rows: two per bank row)   chunk ^ ((row >> 1) & 7)
+//   A2 [128][32 f32] (128-byte rows: two per bank row)   chunk ^ ((row >> 1) & 7)
 //   A3 [ 32][64 f32] (256-byte rows: one per bank row)   chunk ^ (row & 15)
 __global__ __launch_bounds__(256, 3) void stem3_f32_kernel(const float* __restrict__ logmel, int patch_step, const WindowMap map,
                                                            int w0, const float* __restrict__ c1_w, const float* __restrict__ c1_b,
@@ -49,241 +54,323 @@ __global__ __launch_bounds__(256, 3) void stem3_f32_kernel(const float* __restri
                                                            const float* __restrict__ W2, const float* __restrict__ pw2_b,
                                                            const float* __restrict__ dw3_w, const float* __restrict__ dw3_b,
                                                            const float* __restrict__ W3, const float* __restrict__ pw3_b,
-                                                           float* __restrict__ out) {
-    constexpr int R2 = 5;                       // layer-2 rows in the tile
-    constexpr int C1R = R2 + 2;                 // conv1 rows incl. halo: 7
-    constexpr int LMR = 2 * C1R + 1;            // log-mel rows: 15
-    constexpr int BM = R2 * 32;                 // 160 GEMM rows
+                                                           float* __restrict__ out, int windows, int run) {
     constexpr int PW = 68;                      // padded row of the f32 output tile
-    constexpr int OFF_C1 = 0;
-    constexpr int OFF_A2 = OFF_C1 + C1R * 34 * 32 * 4;              // 30464
-    constexpr int P_BYTES = BM * PW * 4;                            // 43520
-    constexpr int OFF_A3 = P_BYTES;                                 // [32][64] f32
-    constexpr int LDS_BYTES = OFF_A3 + 32 * 64 * 4;                 // 51712; P aliases from 0
-    static_assert(OFF_A2 + BM * 128 <= LDS_BYTES && LMR * 68 * 4 <= BM * 128, "the tiles share the f16 kernel's carve-up");
+    constexpr int OFF_C1 = 0;                   // conv1 band [6][34][32] f32
+    constexpr int OFF_A2 = 6 * 34 * 32 * 4;     // 26112: A2 [128][32] f32; the log-mel band [13][68] sits here before it
+    constexpr int P_BYTES = 128 * PW * 4;       // 34816: P [128][68] f32 aliases from 0 after the first product
+    constexpr int OFF_A3 = P_BYTES;             // [32][64] f32 (over A2, which has been consumed by then)
+    constexpr int OFF_KEEP = OFF_A3 + 32 * 64 * 4;   // 43008: the layer-2 row the tile above needs, [32][68] f32
+    constexpr int LDS_BYTES = OFF_KEEP + 32 * PW * 4;   // 51712
+    static_assert(OFF_A2 + 128 * 128 <= OFF_KEEP && OFF_A2 + 13 * 68 * 4 <= OFF_A3, "the tiles share the f16 kernel's carve-up");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     float (*s_lm)[68] = reinterpret_cast<float (*)[68]>(smem + OFF_A2);
     float (*s_c1)[34][32] = reinterpret_cast<float (*)[34][32]>(smem + OFF_C1);
     char* const s_a2 = smem + OFF_A2;
-    float* const P = reinterpret_cast<float*>(smem);               // [BM][PW], valid from phase E on
+    float* const P = reinterpret_cast<float*>(smem);
+    float* const keep = reinterpret_cast<float*>(smem + OFF_KEEP);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int win = blockIdx.y;
-    const int ob = blockIdx.x;                  // 0..11: depthwise-3 rows 2 ob, 2 ob + 1
-    const int r0 = 4 * ob;                      // first layer-2 row of the tile
-    const float* patch = logmel + window_frame(map, w0 + win, patch_step) * BD_MEL_BANDS;
     const int wr = wave >> 1, wc = wave & 1;
     const int frow = lane & 31, fh = lane >> 5;
-
-    // this lane's layer-2 weights (phase D): channel wc * 32 + frow, k = 8 s + 4 fh .. + 3
-    v4f w2[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w2[q] = *reinterpret_cast<const v4f*>(W2 + (size_t)(wc * 32 + frow) * 32 + 8 * q + 4 * fh);
-
     const int c4 = tid & 7;
     const int col = tid >> 3;
-    v4f c1wt[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) c1wt[t] = *reinterpret_cast<const v4f*>(c1_w + t * 32 + c4 * 4);
-    const v4f c1bias = *reinterpret_cast<const v4f*>(c1_b + c4 * 4);
-    // ---- A: log-mel rows 2 (r0 - 1) .. +14, zero halo columns of the conv1 band ----
-    for (int i = tid; i < LMR * 17; i += 256) {
-        const int j = i / 17, q = i % 17;
-        const int ih = 2 * r0 - 2 + j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < 16 && ih >= 0 && ih < BD_PATCH_FRAMES) v = reinterpret_cast<const float4*>(patch + ih * BD_MEL_BANDS)[q];
-        *reinterpret_cast<float4*>(&s_lm[j][q * 4]) = v;
-    }
-    for (int i = tid; i < C1R * 2 * 8; i += 256) {
-        const int r = i / 16, side = (i >> 3) & 1, cc = i & 7;
-        *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][cc * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
 
-    // ---- B: conv1 rows r0 - 1 .. r0 + 5 (the arithmetic of conv1_kernel: taps in (kh, kw) order, a tap row past the patch
-    //         skipped; a conv1 row outside the map is the depthwise's zero padding) ----
-    v4f d2wt[9];
+    // this workgroup's run of tiles; tile g = window g / 12, band 11 - g % 12 (bottom band first).  run > 0: runs of that many
+    // tiles (a divisor of 12), one per workgroup; run == 0: the tiles dealt evenly to the grid
+    const long long total = 12ll * windows;
+    const int g_begin = run > 0 ? (int)blockIdx.x * run : (int)(blockIdx.x * total / gridDim.x);
+    const int g_end = run > 0 ? g_begin + run : (int)((blockIdx.x + 1) * total / gridDim.x);
+
+    // The per-lane constants of a phase are loaded in front of that phase, every tile again (L1 / L2 hits): kept across the
+    // tile loop they are 168 registers.  The pointers go through an empty asm per tile so that the loads stay where they are.
+    // (global address space spelled out: a pointer that went through an asm is a flat one otherwise, and flat loads count as
+    //  LDS operations too)
+    typedef const __attribute__((address_space(1))) float* gptr;
+    typedef const __attribute__((address_space(1))) v4f* gptr4;
+    gptr pc1w = (gptr)c1_w, pc1b = (gptr)c1_b, pd2w = (gptr)dw2_w, pd2b = (gptr)dw2_b, pw2 = (gptr)W2, pb2 = (gptr)pw2_b,
+         pd3w = (gptr)dw3_w, pd3b = (gptr)dw3_b, pw3 = (gptr)W3, pb3 = (gptr)pw3_b;
+
+    // What a tile's first phases need from global memory - its log-mel band (one float4 per thread), the conv1 taps, the
+    // layer-2 weights - is requested a tile AHEAD, in front of the previous tile's output stores: a load issued behind those
+    // stores could only be waited for together with them (vmcnt counts both, in order).  Loads without a branch: clamped
+    // address, zeroed when stored to LDS.
+    float4 lmv;
+    bool lm_ok = false;
+    v4f w2[4], c1wt[9], c1bias;
+    auto prefetch = [&](int win, int r_first, int lmr) {
+        const float* patch = logmel + window_frame(map, w0 + win, patch_step) * BD_MEL_BANDS;
+        const int j = tid / 17, q = tid % 17;
+        const int ih = 2 * r_first - 2 + j;
+        lm_ok = j < lmr && q < 16 && ih >= 0 && ih < BD_PATCH_FRAMES;
+        const int ihc = ih < 0 ? 0 : ih >= BD_PATCH_FRAMES ? BD_PATCH_FRAMES - 1 : ih;
+        lmv = reinterpret_cast<const float4*>(patch + ihc * BD_MEL_BANDS)[q < 16 ? q : 15];
+        // this lane's layer-2 weights (phase D): channel wc * 32 + frow, k = 8 s + 4 fh .. + 3
 #pragma unroll
-    for (int t = 0; t < 9; ++t) d2wt[t] = *reinterpret_cast<const v4f*>(dw2_w + t * 32 + c4 * 4);
-    const v4f d2bias = *reinterpret_cast<const v4f*>(dw2_b + c4 * 4);
-    {
-        float lm[3][3];
-        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+        for (int q2 = 0; q2 < 4; ++q2) w2[q2] = *(gptr4)(pw2 + (size_t)(wc * 32 + frow) * 32 + 8 * q2 + 4 * fh);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) lm[0][kw] = s_lm[0][2 * col + kw];
+        for (int t = 0; t < 9; ++t) c1wt[t] = *(gptr4)(pc1w + t * 32 + c4 * 4);
+        c1bias = *(gptr4)(pc1b + c4 * 4);
+    };
+    auto arrived = [&]() {                      // a use of everything prefetch() requested: the compiler waits for it HERE
+        asm volatile("" : "+v"(lmv.x), "+v"(lmv.y), "+v"(lmv.z), "+v"(lmv.w), "+v"(c1bias));
 #pragma unroll
-        for (int i = 0; i < C1R; ++i) {
-            const int c1r = r0 - 1 + i;
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(w2[q]));
 #pragma unroll
-            for (int kh = 1; kh < 3; ++kh)
+        for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(c1wt[t]));
+    };
+    // layer-2 rows r_first .. r_first + ROWS - 1 of window win (ROWS = 4: -> P; ROWS = 1: -> the keep row): phases A - E
+    f32x16 acc2[2];
+    auto rows_to_lds = [&](auto rows_c, int r_first) {
+        constexpr int ROWS = decltype(rows_c)::value;
+        constexpr int C1R = ROWS + 2, LMR = 2 * C1R + 1;
+        // ---- A: log-mel rows 2 (r_first - 1) .. + LMR - 1 (prefetched), zero halo columns of the conv1 band ----
+        if (tid < LMR * 17) {
+            float4 v = lmv;
+            if (!lm_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&s_lm[tid / 17][(tid % 17) * 4]) = v;
+        }
+        for (int i = tid; i < C1R * 2 * 8; i += 256) {
+            const int r = i / 16, side = (i >> 3) & 1, cc = i & 7;
+            *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][cc * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        // ---- B: conv1 rows r_first - 1 .. r_first + ROWS (the arithmetic of conv1_kernel: taps in (kh, kw) order, a tap row
+        //         past the patch skipped; a conv1 row outside the map is the depthwise's zero padding) ----
+        v4f d2wt[9];
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) lm[kh][kw] = s_lm[2 * i + kh][2 * col + kw];
-            if (c1r >= 0 && c1r < 48) {          // the same for the whole workgroup: a scalar branch
-                v4f acc = c1bias;
+        for (int t = 0; t < 9; ++t) d2wt[t] = *(gptr4)(pd2w + t * 32 + c4 * 4);
+        const v4f d2bias = *(gptr4)(pd2b + c4 * 4);
+        {
+            float lm[3][3];
+            const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    if (2 * c1r + kh >= BD_PATCH_FRAMES) continue;
+            for (int kw = 0; kw < 3; ++kw) lm[0][kw] = s_lm[0][2 * col + kw];
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const float v = lm[kh][kw];
-                        acc = __builtin_elementwise_fma(v4f{v, v, v, v}, c1wt[kh * 3 + kw], acc);
+            for (int i = 0; i < C1R; ++i) {
+                const int c1r = r_first - 1 + i;
+#pragma unroll
+                for (int kh = 1; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) lm[kh][kw] = s_lm[2 * i + kh][2 * col + kw];
+                if (c1r >= 0 && c1r < 48) {          // the same for the whole workgroup: a scalar branch
+                    v4f acc = c1bias;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        if (2 * c1r + kh >= BD_PATCH_FRAMES) continue;
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float v = lm[kh][kw];
+                            acc = __builtin_elementwise_fma(v4f{v, v, v, v}, c1wt[kh * 3 + kw], acc);
+                        }
                     }
+                    v4f r4;
+                    r4.x = fmaxf(acc.x, 0.0f);
+                    r4.y = fmaxf(acc.y, 0.0f);
+                    r4.z = fmaxf(acc.z, 0.0f);
+                    r4.w = fmaxf(acc.w, 0.0f);
+                    *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = r4;
+                } else {
+                    *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = zero4;
                 }
-                v4f r4;
-                r4.x = fmaxf(acc.x, 0.0f);
-                r4.y = fmaxf(acc.y, 0.0f);
-                r4.z = fmaxf(acc.z, 0.0f);
-                r4.w = fmaxf(acc.w, 0.0f);
-                *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = r4;
-            } else {
-                *reinterpret_cast<v4f*>(&s_c1[i][col + 1][c4 * 4]) = zero4;
-            }
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) lm[0][kw] = lm[2][kw];
-        }
-    }
-    __syncthreads();
-
-    // ---- C: depthwise 2 for rows r0 .. r0 + 4 -> f32 A tile [160][32] (rolling window over the conv1 band) ----
-    {
-        v4f cv[3][3];
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) cv[kh][kw] = *reinterpret_cast<const v4f*>(&s_c1[kh][col + kw][c4 * 4]);
-#pragma unroll
-        for (int r = 0; r < R2; ++r) {
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) cv[2][kw] = *reinterpret_cast<const v4f*>(&s_c1[r + 2][col + kw][c4 * 4]);
-            v4f acc = d2bias;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) acc = __builtin_elementwise_fma(cv[kh][kw], d2wt[kh * 3 + kw], acc);
-            acc.x = fmaxf(acc.x, 0.0f);
-            acc.y = fmaxf(acc.y, 0.0f);
-            acc.z = fmaxf(acc.z, 0.0f);
-            acc.w = fmaxf(acc.w, 0.0f);
-            const int row = r * 32 + col;
-            *reinterpret_cast<v4f*>(s_a2 + row * 128 + ((c4 ^ ((row >> 1) & 7)) << 4)) = acc;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                cv[0][kw] = cv[1][kw];
-                cv[1][kw] = cv[2][kw];
+                for (int kw = 0; kw < 3; ++kw) lm[0][kw] = lm[2][kw];
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    v4f d3wt[9];                                // depthwise-3 taps (channels 4 (tid & 15) ..): in flight during D and E
+        // ---- C: depthwise 2 for the ROWS rows -> f32 A tile [32 ROWS][32] (rolling window over the conv1 band) ----
+        {
+            v4f cv[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) d3wt[t] = *reinterpret_cast<const v4f*>(dw3_w + t * 64 + (tid & 15) * 4);
-    const v4f d3bias = *reinterpret_cast<const v4f*>(dw3_b + (tid & 15) * 4);
-    // ---- D: [160][32] x [32][64].  Waves (wr, wc): column tile wc; row tiles wr, wr + 2 and, for wr == 0, 4.  Weights as the
-    //         A operand, activations as B: the accumulators hold the transposed tile (lane = position, a register quad = four
-    //         consecutive channels), so phase E writes 16 bytes at a time; the same products in the same k order ----
-    f32x16 acc2[3];
+            for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int rt = wr + 2 * i;                                  // row tile 0..4 (5 = none)
+                for (int kw = 0; kw < 3; ++kw) cv[kh][kw] = *reinterpret_cast<const v4f*>(&s_c1[kh][col + kw][c4 * 4]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
-        if (rt < R2) {
-            const int row = rt * 32 + frow;
+            for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4f a4 = *reinterpret_cast<const v4f*>(s_a2 + row * 128 + (((2 * q + fh) ^ ((row >> 1) & 7)) << 4));
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].x, a4.x, acc2[i], 0, 0, 0);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].y, a4.y, acc2[i], 0, 0, 0);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].z, a4.z, acc2[i], 0, 0, 0);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].w, a4.w, acc2[i], 0, 0, 0);
+                for (int kw = 0; kw < 3; ++kw) cv[2][kw] = *reinterpret_cast<const v4f*>(&s_c1[r + 2][col + kw][c4 * 4]);
+                v4f acc = d2bias;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc = __builtin_elementwise_fma(cv[kh][kw], d2wt[kh * 3 + kw], acc);
+                acc.x = fmaxf(acc.x, 0.0f);
+                acc.y = fmaxf(acc.y, 0.0f);
+                acc.z = fmaxf(acc.z, 0.0f);
+                acc.w = fmaxf(acc.w, 0.0f);
+                const int row = r * 32 + col;
+                *reinterpret_cast<v4f*>(s_a2 + row * 128 + ((c4 ^ ((row >> 1) & 7)) << 4)) = acc;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    cv[0][kw] = cv[1][kw];
+                    cv[1][kw] = cv[2][kw];
+                }
             }
         }
-    }
-    __syncthreads();   // every wave is done with the A tile, the conv band and the log-mel band: P may overwrite them
+        __syncthreads();
 
-    // ---- E: bias + ReLU -> P; layer-2 rows past row 47 are the depthwise's zero padding ----
-    {
-        v4f b4[4];
+        // ---- D: [32 ROWS][32] x [32][64].  Waves (wr, wc): column tile wc; row tiles wr and wr + 2.  Weights as the A operand,
+        //         activations as B: the accumulators hold the transposed tile (lane = position, a register quad = four
+        //         consecutive channels), so phase E writes 16 bytes at a time; the same products in the same k order ----
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const v4f*>(pw2_b + wc * 32 + 8 * g + 4 * fh);
+        for (int i = 0; i < 2; ++i) {
+            const int rt = wr + 2 * i;                                  // row tile 0..3
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int rt = wr + 2 * i;
-            if (rt < R2) {
-                const bool live = __builtin_amdgcn_readfirstlane((int)(r0 + rt < 48)) != 0;    // the same for the whole wave
-                float* prow = P + (rt * 32 + frow) * PW + wc * 32 + 4 * fh;
+            for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
+            if (rt < ROWS) {
+                const int row = rt * 32 + frow;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    v4f v = {0.f, 0.f, 0.f, 0.f};
-                    if (live) {
-                        v.x = fmaxf(acc2[i][4 * g + 0] + b4[g].x, 0.0f);     // pointwise_kernel's epilogue: acc + bias, ReLU
+                for (int q = 0; q < 4; ++q) {
+                    const v4f a4 = *reinterpret_cast<const v4f*>(s_a2 + row * 128 + (((2 * q + fh) ^ ((row >> 1) & 7)) << 4));
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].x, a4.x, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].y, a4.y, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].z, a4.z, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q].w, a4.w, acc2[i], 0, 0, 0);
+                }
+            }
+        }
+        if (ROWS == 4) __syncthreads();   // every wave is done with the A tile, the conv band and the log-mel band: P may overwrite them
+                                          // (ROWS == 1 writes the keep row, which nobody reads here)
+        // ---- E: bias + ReLU -> P / the keep row (pointwise_kernel's epilogue: acc + bias, ReLU) ----
+        {
+            v4f b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b4[g] = *(gptr4)(pb2 + wc * 32 + 8 * g + 4 * fh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rt = wr + 2 * i;
+                if (rt < ROWS) {
+                    float* prow = (ROWS == 1 ? keep : P) + (rt * 32 + frow) * PW + wc * 32 + 4 * fh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        v4f v;
+                        v.x = fmaxf(acc2[i][4 * g + 0] + b4[g].x, 0.0f);
                         v.y = fmaxf(acc2[i][4 * g + 1] + b4[g].y, 0.0f);
                         v.z = fmaxf(acc2[i][4 * g + 2] + b4[g].z, 0.0f);
                         v.w = fmaxf(acc2[i][4 * g + 3] + b4[g].w, 0.0f);
+                        *reinterpret_cast<v4f*>(prow + 8 * g) = v;
+                        if (i == 0) {               // row tile 0 (waves 0, 1) is the row the tile above takes over
+                            acc2[0][4 * g + 0] = v.x;
+                            acc2[0][4 * g + 1] = v.y;
+                            acc2[0][4 * g + 2] = v.z;
+                            acc2[0][4 * g + 3] = v.w;
+                        }
                     }
-                    *reinterpret_cast<v4f*>(prow + 8 * g) = v;
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+    };
 
-    // this lane's layer-3 weights (phase G): channel 32 wave + frow, k = 8 s + 4 fh .. + 3 (in flight during F)
-    v4f w3[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w3[q] = *reinterpret_cast<const v4f*>(W3 + (size_t)(32 * wave + frow) * 64 + 8 * q + 4 * fh);
-    // ---- F: depthwise 3, stride 2: out[o][ow][c] from P rows 2o + kh, columns 2ow + kw (column 32 = padding) -> f32 A3 tile ----
-    const int c16 = tid & 15, ow = (tid >> 4) & 15;
-    const float* const pcol = P + (2 * ow) * PW + c16 * 4;
-    const bool right_edge = ow == 15;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int o = it;
-        v4f acc = d3bias;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                v4f v = *reinterpret_cast<const v4f*>(pcol + ((2 * o + kh) * 32 + kw) * PW);
-                if (kw == 2) {
-                    v.x = right_edge ? 0.0f : v.x;
-                    v.y = right_edge ? 0.0f : v.y;
-                    v.z = right_edge ? 0.0f : v.z;
-                    v.w = right_edge ? 0.0f : v.w;
-                }
-                acc = __builtin_elementwise_fma(v, d3wt[kh * 3 + kw], acc);
+    if (g_begin < g_end && g_begin < total) {
+        {
+            const int win0 = g_begin / 12, ob0 = 11 - g_begin % 12;
+            if (ob0 != 11) {
+                prefetch(win0, 4 * ob0 + 4, 7);
+                rows_to_lds(std::integral_constant<int, 1>{}, 4 * ob0 + 4);           // the run starts inside a window
+            } else {                                                                   // row 48 of a window is the zero padding
+                for (int i = tid; i < 32 * PW / 4; i += 256) reinterpret_cast<float4*>(keep)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        acc.x = fmaxf(acc.x, 0.0f);
-        acc.y = fmaxf(acc.y, 0.0f);
-        acc.z = fmaxf(acc.z, 0.0f);
-        acc.w = fmaxf(acc.w, 0.0f);
-        const int row = o * 16 + ow;
-        *reinterpret_cast<v4f*>(smem + OFF_A3 + row * 256 + ((c16 ^ (row & 15)) << 4)) = acc;
-    }
-    __syncthreads();
-    // ---- G: [32][64] x [64][128], one 32 x 32 tile per wave (activations as the A operand) ----
-    f32x16 acc3;
+            prefetch(win0, 4 * ob0, 13);
+            arrived();                              // (nothing in flight at the head of the tile loop, from either side)
+        }
+        const int g_stop = g_end < total ? g_end : (int)total;
+#pragma unroll 1
+        for (int g = g_begin; g < g_stop; ++g) {
+            asm volatile("" : "+s"(pc1w), "+s"(pc1b), "+s"(pd2w), "+s"(pd2b), "+s"(pw2), "+s"(pb2));
+            asm volatile("" : "+s"(pd3w), "+s"(pd3b), "+s"(pw3), "+s"(pb3));
+            const int win = g / 12, ob = 11 - g % 12;
+            rows_to_lds(std::integral_constant<int, 4>{}, 4 * ob);
+
+            v4f d3wt[9];                                // depthwise-3 taps (channels 4 (tid & 15) ..)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
+            for (int t = 0; t < 9; ++t) d3wt[t] = *(gptr4)(pd3w + t * 64 + (tid & 15) * 4);
+            const v4f d3bias = *(gptr4)(pd3b + (tid & 15) * 4);
+            // this lane's layer-3 weights (phase G): channel 32 wave + frow, k = 8 s + 4 fh .. + 3 (in flight during F)
+            v4f w3[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const v4f a4 = *reinterpret_cast<const v4f*>(smem + OFF_A3 + frow * 256 + (((2 * q + fh) ^ (frow & 15)) << 4));
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, w3[q].x, acc3, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, w3[q].y, acc3, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, w3[q].z, acc3, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, w3[q].w, acc3, 0, 0, 0);
-    }
-    // ---- H: bias + ReLU, [32][128] block of the layer-3 output (rows are consecutive NHWC positions) ----
-    float* dst3 = out + (((size_t)win * 24 + 2 * ob) * 16) * 128;
-    const int n = 32 * wave + frow;
-    const float b = pw3_b[n];
+            for (int q = 0; q < 8; ++q) w3[q] = *(gptr4)(pw3 + (size_t)(32 * wave + frow) * 64 + 8 * q + 4 * fh);
+            // ---- F: depthwise 3, stride 2: out[o][ow][c] from rows 2o + kh (row 4: the kept one), columns 2ow + kw (column 32 =
+            //         padding) -> f32 A3 tile ----
+            const int c16 = tid & 15, ow = (tid >> 4) & 15;
+            const bool right_edge = ow == 15;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = 4 * fh + (r & 3) + 8 * (r >> 2);
-        dst3[(size_t)m * 128 + n] = fmaxf(acc3[r] + b, 0.0f);
+            for (int it = 0; it < 2; ++it) {
+                const int o = it;
+                v4f acc = d3bias;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int pr = 2 * o + kh;
+                        const float* const prow = pr == 4 ? keep : P + pr * 32 * PW;
+                        v4f v = *reinterpret_cast<const v4f*>(prow + (2 * ow + kw) * PW + c16 * 4);
+                        if (kw == 2) {
+                            v.x = right_edge ? 0.0f : v.x;
+                            v.y = right_edge ? 0.0f : v.y;
+                            v.z = right_edge ? 0.0f : v.z;
+                            v.w = right_edge ? 0.0f : v.w;
+                        }
+                        acc = __builtin_elementwise_fma(v, d3wt[kh * 3 + kw], acc);
+                    }
+                acc.x = fmaxf(acc.x, 0.0f);
+                acc.y = fmaxf(acc.y, 0.0f);
+                acc.z = fmaxf(acc.z, 0.0f);
+                acc.w = fmaxf(acc.w, 0.0f);
+                const int row = o * 16 + ow;
+                *reinterpret_cast<v4f*>(smem + OFF_A3 + row * 256 + ((c16 ^ (row & 15)) << 4)) = acc;
+            }
+            __syncthreads();
+            // the row the next tile takes over: this tile's first one (zeros when the next tile is the bottom of a window);
+            // nobody reads the keep row before the next tile's phase F
+            if (wr == 0) {
+                const bool bottom_next = ob == 0;
+                float* krow = keep + frow * PW + wc * 32 + 4 * fh;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    v4f v = {acc2[0][4 * g4 + 0], acc2[0][4 * g4 + 1], acc2[0][4 * g4 + 2], acc2[0][4 * g4 + 3]};
+                    if (bottom_next) v = v4f{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<v4f*>(krow + 8 * g4) = v;
+                }
+            }
+            // the next tile's first loads (the last tile of the run: its own again), in flight behind the matrix instructions
+            const int n = 32 * wave + frow;
+            const float b = pb3[n];
+            {
+                const int gn = g + 1 < g_stop ? g + 1 : g;
+                prefetch(gn / 12, 4 * (11 - gn % 12), 13);
+            }
+            asm volatile("" ::: "memory");                  // issued HERE, not sunk behind the matrix instructions
+            // ---- G: [32][64] x [64][128], one 32 x 32 tile per wave (activations as the A operand) ----
+            f32x16 acc3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const v4f a4 = *reinterpret_cast<const v4f*>(smem + OFF_A3 + frow * 256 + (((2 * q + fh) ^ (frow & 15)) << 4));
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, w3[q].x, acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, w3[q].y, acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, w3[q].z, acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, w3[q].w, acc3, 0, 0, 0);
+            }
+            // The loads are waited for HERE, in front of the stores: vmcnt counts loads and stores together and the two kinds
+            // retire out of order with respect to each other, so a load with stores in flight in front of its first use can only
+            // be waited for with vmcnt(0) - the next tile would open by waiting for this tile's stores to reach memory.
+            arrived();
+            // ---- H: bias + ReLU, [32][128] block of the layer-3 output (rows are consecutive NHWC positions) ----
+            float* dst3 = out + (((size_t)win * 24 + 2 * ob) * 16) * 128;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 4 * fh + (r & 3) + 8 * (r >> 2);
+                dst3[(size_t)m * 128 + n] = fmaxf(acc3[r] + b, 0.0f);
+            }
+            // (no barrier: the next tile's phases A and B write the log-mel and conv bands, which end below A3, and phase C is
+            //  two barriers away)
+        }
     }
 }
 
@@ -806,8 +893,17 @@ bool launch_sep_f32(const float* in, float* out, int windows, const SepLayer& L,
 void launch_stem_f32(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-    hipLaunchKernelGGL(stem3_f32_kernel, dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w, c1_b, L2.dw_w,
-                       L2.dw_b, L2.pw_wt, L2.pw_b, L3.dw_w, L3.dw_b, L3.pw_wt, L3.pw_b, out);
+    // three workgroups per CU, each with a contiguous run of the 12 x windows tiles (BD_STEM_F32_RUN = 2 / 3 / 4 / 6 / 12 in
+    // a developer build: one workgroup per run of that many tiles instead)
+    int run = 0;
+#ifdef BD_KERNEL_TRACE
+    if (const char* ev = getenv("BD_STEM_F32_RUN")) run = atoi(ev);
+    if (run < 0 || (run > 0 && 12 % run)) run = 0;
+#endif
+    long long grid = run > 0 ? 12ll * windows / run : 3ll * cu_count();
+    if (grid > 12ll * windows) grid = 12ll * windows;
+    hipLaunchKernelGGL(stem3_f32_kernel, dim3((unsigned)grid), dim3(256), 0, stream, logmel, patch_step, map, w0, c1_w, c1_b, L2.dw_w,
+                       L2.dw_b, L2.pw_wt, L2.pw_b, L3.dw_w, L3.dw_b, L3.pw_wt, L3.pw_b, out, windows, run);
 }
 
 // Layer 4 + the depthwise of layer 5 in exact f32 as one kernel: in = [windows][24][16][128], out = [windows][12][8][128].
