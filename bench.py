@@ -500,11 +500,12 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the host-resident (H2D-inclusive), analyze() and arithmetic-mode legs")
     ap.add_argument("--per-slot", action="store_true", help="print per-kernel times to stderr")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="analyzer streams per GPU: batches are dealt round-robin, in issue order, to this many engines, each "
-                         "on its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253).  Three, not four: "
-                         "with four streams and four batches per recording every stream sees the same batch of every recording "
-                         "and the streams run in lock-step (1.63 vs 1.66 M windows/s, DESIGN.md 7)")
+                         "on its own HIP stream (the reference's analyzers_gpu knob, src/analyze.py:218-253).  Two since round 5: "
+                         "the on-chip kernels of layers 5-12 hold a whole CU each, so a third stream only adds queueing (same box, "
+                         "alternating: 1.852 / 1.855 / 1.849 M windows/s with two, 1.835 / 1.826 / 1.832 M with three, 1.75 M with "
+                         "four, 1.57 M with one; DESIGN.md 7)")
     ap.add_argument("--sep-variant", type=int, default=None, help="fused separable layers: 9 = 8-wave kernel only, 12 = with the 12-wave kernel (no epilogue fusion; tuning)")
     ap.add_argument("--pointwise-mode", choices=["f16x3", "f32", "f16"], default=None,
                     help="profiling only: run the WHOLE bench in this arithmetic mode (the line then carries mode_override; "
