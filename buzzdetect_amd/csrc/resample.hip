@@ -305,7 +305,7 @@ __device__ __forceinline__ void fir_body(const T* __restrict__ in, long long n_i
     const float unscale = p.unscale[sizeof(T) == 2 ? 0 : 1];
     const int total = p.contiguous ? (ROWS - 1) * (p.D >> 3) + CPR : ROWS * CPR;
     const long long boff = p.boff[pb];
-    FirPrefetch<T, CH, 220 - 8 * KQ - 16 * MT - 28> pf;   // 256 registers at two waves per SIMD: filter, accumulators, ~50 others
+    FirPrefetch<T, CH, 220 - 8 * KQ - 16 * MT - 44> pf;   // 256 registers at two waves per SIMD: filter, accumulators, the fragment ring, ~50 others
     if ((long long)blockIdx.x < n_chunks) pf.template fetch<CPR>(in, n_in, p, (long long)blockIdx.x * ROWS * p.D + boff, total, tid);
     // persistent: the workgroup keeps its share of the filter in registers and walks chunks of ROWS periods
     for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -324,21 +324,36 @@ __device__ __forceinline__ void fir_body(const T* __restrict__ in, long long n_i
     int abase[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) abase[t] = 16 * ((t * 32 + (lane & 31)) * p.RS + (lane >> 5));
-#pragma unroll
-    for (int i = 0; i < KQ; ++i) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
+    // The A fragments run two steps (six MFMAs) ahead of their use in a ring of three (hi, lo) pairs, each request pinned in
+    // front of the MFMAs of the step it follows: left alone the compiler keeps ONE pair and every step opens with
+    // ds_read_b128 -> s_waitcnt lgkmcnt(0), the whole LDS latency in front of three MFMAs (round 5: the matrix pipe ran at
+    // 40 % of its pace inside this loop).
+    {
+        constexpr int NSTEP = KQ * MT;
+        f16x8 ah[3], al[3];
 #if defined(BD_FIR_ABLATE) && BD_FIR_ABLATE == 1      // developer build: no fragment reads (which LDS access conflicts?)
-            f16x8 ah = bh[i], al = bl[i];
-            asm volatile("" : "+v"(ah), "+v"(al));
+#define FIR_LA(N) { ah[(N) % 3] = bh[(N) / MT]; al[(N) % 3] = bl[(N) / MT]; asm volatile("" : "+v"(ah[(N) % 3]), "+v"(al[(N) % 3])); }
 #else
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(a_hi + abase[t] + koff[i]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(a_lo + abase[t] + koff[i]);
+#define FIR_LA(N)                                                                                         \
+    {                                                                                                     \
+        ah[(N) % 3] = *reinterpret_cast<const f16x8*>(a_hi + abase[(N) % MT] + koff[(N) / MT]);           \
+        al[(N) % 3] = *reinterpret_cast<const f16x8*>(a_lo + abase[(N) % MT] + koff[(N) / MT]);           \
+    }
 #endif
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i], acc[t], 0, 0, 0);
+        FIR_LA(0)
+        if constexpr (NSTEP > 1) FIR_LA(1)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NSTEP; ++n) {
+            const int i = n / MT, t = n % MT;
+            if (n + 2 < NSTEP) FIR_LA(n + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n % 3], bh[i], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n % 3], bl[i], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n % 3], bh[i], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef FIR_LA
     }
     __syncthreads();                                       // every wave is done with the staged signal
 
