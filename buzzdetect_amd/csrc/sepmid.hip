@@ -35,6 +35,7 @@ namespace bd {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kF16MaxMid = 65504.0f;
@@ -118,6 +119,15 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
         const auto r_ = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, EV[y][0]), __builtin_bit_cast(unsigned, EV[y][3]), false, false); \
         LH[y] = fh ? __builtin_bit_cast(float, (unsigned)r_[0]) : 0.0f;       /* upper half: the lower half's column 3 */ \
         RH[y] = fh ? 0.0f : __builtin_bit_cast(float, (unsigned)r_[1]);       /* lower half: the upper half's column 4 */ \
+    }
+
+    // ... as row pairs for the packed depthwise
+#define MID_ROW_PAIRS(EV, LH, RH, IN2)                                                                    \
+    _Pragma("unroll") for (int c = 0; c < 6; ++c) {                                                       \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                     \
+            IN2[1 + r][c] = c == 0 ? v2f{LH[r], LH[r + 6]} : c == 5 ? v2f{RH[r], RH[r + 6]} : v2f{EV[r][c - 1], EV[r + 6][c - 1]}; \
+        IN2[0][c] = v2f{0.0f, c == 0 ? LH[5] : c == 5 ? RH[5] : EV[5][c - 1]};                            \
+        IN2[7][c] = v2f{c == 0 ? LH[6] : c == 5 ? RH[6] : EV[6][c - 1], 0.0f};                            \
     }
 
     // this wave's share of a window's input (the depthwise-5 output): stage wc & 3, rows 24 (wc >> 2) .. + 23 of the lane's half.
@@ -204,25 +214,26 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
                 float ev[12][4], lh[12], rh[12];
                 MID_TILE_TO_MAP(acc, u, b, ev)
                 MID_HALO(ev, lh, rh)
+                // two map rows per v_pk_fma_f32: in2[1 + r][1 + c] = (row r, row r + 6) at column 4 fh + c, r = -1 .. 6, c = -1 .. 4;
+                // the rows outside the map are zeros (a tap there adds 0 * w: sepchip.hip on why that is the skipped tap's result)
+                v2f in2[8][6];
+                MID_ROW_PAIRS(ev, lh, rh, in2)
 #pragma unroll
-                for (int y = 0; y < 12; ++y)
+                for (int y = 0; y < 6; ++y)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float sacc = shift;
+                        v2f sacc = {shift, shift};
 #pragma unroll
-                        for (int kh = 0; kh < 3; ++kh) {
-                            const int iy = y + kh - 1;
-                            if (iy < 0 || iy >= 12) continue;
+                        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) {
-                                const int ie = e + kw - 1;                 // -1: left halo, 4: right halo
-                                const float xv = ie < 0 ? lh[iy] : ie > 3 ? rh[iy] : ev[iy][ie];
-                                sacc = fmaf(xv, wt[kh * 3 + kw], sacc);
-                            }
+                            for (int kw = 0; kw < 3; ++kw)
+                                sacc = __builtin_elementwise_fma(in2[y + kh][e + kw], v2f{wt[kh * 3 + kw], wt[kh * 3 + kw]}, sacc);
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const float o = fmaxf(w ? sacc.y : sacc.x, 0.0f);
+                            MID_SPLIT(o, pk)
+                            out6[4 * (y + 6 * w) + e] = pk;
                         }
-                        const float o = fmaxf(sacc, 0.0f);
-                        MID_SPLIT(o, pk)
-                        out6[4 * y + e] = pk;
                     }
             }
             __syncthreads();                      // every wave has read A5: the ring is free for A6
@@ -278,34 +289,34 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             float ev[12][4], lh[12], rh[12];
             MID_TILE_TO_MAP(acc, u, b, ev)
             MID_HALO(ev, lh, rh)
-            (void)lh;
             int wbl = wb7;
             asm volatile("" : "+v"(wbl));
             char* const slot = sm + kOffA7 + wc * kSlot7;
             // output (oy, ox = 2 fh + j) reads map rows 2 oy + kh, columns 2 ox + kw = 4 fh + 2 j + kw; SAME padding of a
             // stride-2 layer: one row / column BEHIND the map (row 12; column 8 = the upper half's right halo = 0)
+            // two output rows (oy, oy + 3) per v_pk_fma_f32: their input rows 2 oy + kh and 2 oy + kh + 6 are one row pair
+            v2f in2[8][6];
+            MID_ROW_PAIRS(ev, lh, rh, in2)
 #pragma unroll
-            for (int oy = 0; oy < 6; ++oy)
+            for (int oy = 0; oy < 3; ++oy)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float sacc = shift;
+                    v2f sacc = {shift, shift};
 #pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {
-                        const int iy = 2 * oy + kh;
-                        if (iy >= 12) continue;
+                    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) {
-                            const int ie = 2 * j + kw;
-                            const float xv = ie > 3 ? rh[iy] : ev[iy][ie];
-                            sacc = fmaf(xv, wt[kh * 3 + kw], sacc);
-                        }
+                        for (int kw = 0; kw < 3; ++kw)
+                            sacc = __builtin_elementwise_fma(in2[1 + 2 * oy + kh][1 + 2 * j + kw], v2f{wt[kh * 3 + kw], wt[kh * 3 + kw]}, sacc);
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const int oyw = oy + 3 * w;
+                        const float o = fmaxf(w ? sacc.y : sacc.x, 0.0f);
+                        MID_SPLIT(o, pk)
+                        // row 24 HALF + 4 oy + 2 fh + j of the 48-row stage: key (row >> 2) & 3 = (6 HALF + oy) & 3
+                        char* const p_ = slot + (wbl ^ (((6 * HALF + oyw) & 3) << 4)) + (24 * HALF + 4 * oyw + j) * 64;
+                        *reinterpret_cast<unsigned short*>(p_) = (unsigned short)pk;
+                        *reinterpret_cast<unsigned short*>(p_ + kHalf7) = (unsigned short)(pk >> 16);
                     }
-                    const float o = fmaxf(sacc, 0.0f);
-                    MID_SPLIT(o, pk)
-                    // row 24 HALF + 4 oy + 2 fh + j of the 48-row stage: key (row >> 2) & 3 = (6 HALF + oy) & 3
-                    char* const p_ = slot + (wbl ^ (((6 * HALF + oy) & 3) << 4)) + (24 * HALF + 4 * oy + j) * 64;
-                    *reinterpret_cast<unsigned short*>(p_) = (unsigned short)pk;
-                    *reinterpret_cast<unsigned short*>(p_ + kHalf7) = (unsigned short)(pk >> 16);
                 }
         }
         __syncthreads();                          // A7's rows of this window published; every wave has read A6
