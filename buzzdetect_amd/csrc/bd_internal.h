@@ -69,6 +69,7 @@ struct SepLayer {
     const void* pw_wlo;  // [cout][cin] f16: f16(pw_wt - high)
     const void* pw_fhi;  // pw_whi in MFMA B-fragment order: [cout/32][cin/16][64 lanes][8]
     const void* pw_flo;  // pw_wlo, same order
+    const float* pw_ffrag;  // pw_wt in the f32 matrix instruction's B-fragment order: [cout/32][cin/8][64 lanes][4] (sepchipf32.hip)
     int pw_variant16;    // tile choice for the split-f16 kernel (0 = by shape)
     int pw_mode;         // 0 = exact f32 MFMA, 1 = split-f16 MFMA (3 products), 2 = plain f16 MFMA (1 product)
     unsigned* range_flag;  // the engine's sticky "an activation left the f16 range" word (modes 1 and 2)
@@ -157,7 +158,9 @@ void launch_stem_f32(const float* logmel, int patch_step, const WindowMap& map, 
 int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,
                          bool on_chip = true);
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
-                           const SepLayer* next = nullptr);   // sepchip.hip
+                           const SepLayer* next = nullptr);
+bool launch_separable_chip_f32(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
+                               const SepLayer* next, bool dw0_done);   // sepchip.hip
 bool launch_separable_mid(const float* in, float* out, int windows, const SepLayer& L5, const SepLayer& L6, const SepLayer& L7,
                           hipStream_t stream);       // sepmid.hip
 int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);

@@ -384,7 +384,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
     };
     const float* p = w->embedder_blob;
     size_t off_conv1_w, off_conv1_b;
-    size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13], off_pw_hi[13], off_pw_lo[13], off_pw_fhi[13], off_pw_flo[13];
+    size_t off_dw_w[13], off_dw_b[13], off_pw_w[13], off_pw_b[13], off_pw_hi[13], off_pw_lo[13], off_pw_fhi[13], off_pw_flo[13], off_pw_ffrag[13];
     size_t off_dw16[13], off_pw_u[13];
     std::vector<int> row_exps[13];
     {
@@ -476,6 +476,20 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
                     flo[dst] = lo[(size_t)n * cin + k];
                 }
         }
+        // the f32 kernel in the fragment order of v_mfma_f32_32x32x2_f32 as the exact-f32 on-chip run reads it (sepchipf32.hip):
+        // for a 32-channel tile t and a super-step S of 8 k, lane l holds W[32 t + l % 32][8 S + 4 (l / 32) .. + 4]
+        off_pw_ffrag[l] = 0;
+        if (cin == 512 && cout == 512) {
+            off_pw_ffrag[l] = reserve(nw);
+            const float* wf = host.data() + off_pw_w[l];
+            float* ff = host.data() + off_pw_ffrag[l];
+            const int ks = cin / 8;
+            for (int n = 0; n < cout; ++n)
+                for (int k = 0; k < cin; ++k) {
+                    const int lane = (n & 31) + 32 * ((k & 7) >> 2);
+                    ff[(((size_t)(n >> 5) * ks + (k >> 3)) * 64 + lane) * 4 + (k & 3)] = wf[(size_t)n * cin + k];
+                }
+        }
         cin = cout;
     }
     if (p - w->embedder_blob != BD_EMBEDDER_BLOB_FLOATS) return fail(BD_EWEIGHTS, "internal: blob walk mismatch");
@@ -548,6 +562,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         L.pw_wlo = e->d_pool + off_pw_lo[l];
         L.pw_fhi = e->d_pool + off_pw_fhi[l];
         L.pw_flo = e->d_pool + off_pw_flo[l];
+        L.pw_ffrag = off_pw_ffrag[l] ? e->d_pool + off_pw_ffrag[l] : nullptr;
         L.pw_variant16 = 0;
         L.pw_mode = e->pointwise_mode;
         L.range_flag = e->d_range_flag;
@@ -1046,6 +1061,21 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 skip_dw_layer = l + 1;
                 last = buf_b;
                 last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * L.cout;
+                continue;
+            }
+            // exact-f32 mode: layers 8-12 + the depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchipf32.hip);
+            // depthwise 8 has been applied by the launch in front (buf_b), layer 13 then starts at its 1x1 convolution
+            if (f32_l4 && !f32_layers && l == 6 && skip_dw_layer == 6 && e->chip_run && e->chip_ndw && stop_stage < 0 &&
+                bd::launch_separable_chip_f32(buf_b, buf_a, gw, &sep[6], 5, stream, &sep[11], true)) {
+                BD_REPEAT_EXTRA(23) (void)bd::launch_separable_chip_f32(buf_b, buf_a, gw, &sep[6], 5, stream, &sep[11], true);
+                l = 10;
+                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                float* t = buf_a;                // the depthwise-13 output is what buf_b holds from here on
+                buf_a = buf_b;
+                buf_b = t;
+                skip_dw_layer = 11;
+                last = buf_b;
+                last_floats = (int64_t)gw * 3 * 2 * 512;
                 continue;
             }
             // exact-f32 mode, behind the f32 stem: layer 4 and layer 5's stride-2 depthwise as one kernel (bit-identical to the

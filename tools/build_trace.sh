@@ -8,6 +8,7 @@ for f in engine frontend resample sepf32 cnn rowfmt stemroll; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -c $f.hip -o $obj/$f.o 2>/dev/null &
 done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepmid.hip -o $obj/sepmid.o &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepchipf32.hip -o $obj/sepchipf32.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepchip.hip -o $obj/sepchip.o
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o libtrace.so $obj/*.o
