@@ -160,7 +160,9 @@ int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
                            const SepLayer* next = nullptr);
 bool launch_separable_chip_f32(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
-                               const SepLayer* next, bool dw0_done);   // sepchip.hip
+                               const SepLayer* next, bool dw0_done);
+bool launch_separable_mid_f32(const float* in, float* out, int windows, const SepLayer& L5, const SepLayer& L6, const SepLayer& L7,
+                              hipStream_t stream);   // sepchip.hip
 bool launch_separable_mid(const float* in, float* out, int windows, const SepLayer& L5, const SepLayer& L6, const SepLayer& L7,
                           hipStream_t stream);       // sepmid.hip
 int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);

@@ -479,7 +479,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         // the f32 kernel in the fragment order of v_mfma_f32_32x32x2_f32 as the exact-f32 on-chip run reads it (sepchipf32.hip):
         // for a 32-channel tile t and a super-step S of 8 k, lane l holds W[32 t + l % 32][8 S + 4 (l / 32) .. + 4]
         off_pw_ffrag[l] = 0;
-        if (cin == 512 && cout == 512) {
+        if (cin >= 128) {                                          // layers 5-14 (what the exact-f32 on-chip runs cover, and room)
             off_pw_ffrag[l] = reserve(nw);
             const float* wf = host.data() + off_pw_w[l];
             float* ff = host.data() + off_pw_ffrag[l];
@@ -1063,20 +1063,38 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * L.cout;
                 continue;
             }
-            // exact-f32 mode: layers 8-12 + the depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchipf32.hip);
-            // depthwise 8 has been applied by the launch in front (buf_b), layer 13 then starts at its 1x1 convolution
-            if (f32_l4 && !f32_layers && l == 6 && skip_dw_layer == 6 && e->chip_run && e->chip_ndw && stop_stage < 0 &&
-                bd::launch_separable_chip_f32(buf_b, buf_a, gw, &sep[6], 5, stream, &sep[11], true)) {
-                BD_REPEAT_EXTRA(23) (void)bd::launch_separable_chip_f32(buf_b, buf_a, gw, &sep[6], 5, stream, &sep[11], true);
-                l = 10;
+            // exact-f32 mode: pointwise 5 + layer 6 + layer 7 as ONE launch (sepmidf32.hip): depthwise 5 has been applied by
+            // l4_f32_kernel (buf_b); the layer-7 output lands in buf_a like any pointwise output
+            if (f32_l4 && !f32_layers && l == 3 && skip_dw_layer == 3 && e->chip_mid && stop_stage < 0 &&
+                bd::launch_separable_mid_f32(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream)) {
+                BD_REPEAT_EXTRA(13) (void)bd::launch_separable_mid_f32(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream);
+                l = 5;
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
-                float* t = buf_a;                // the depthwise-13 output is what buf_b holds from here on
-                buf_a = buf_b;
-                buf_b = t;
-                skip_dw_layer = 11;
-                last = buf_b;
-                last_floats = (int64_t)gw * 3 * 2 * 512;
+                last = buf_a;
+                last_floats = (int64_t)gw * 6 * 4 * 512;
                 continue;
+            }
+            // exact-f32 mode: layers 8-12 + the depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchipf32.hip).
+            // Its input is the layer-7 output (buf_a) or, when the launch in front applied depthwise 8 in its epilogue, that
+            // (buf_b); layer 13 then starts at its 1x1 convolution on the depthwise-13 output in buf_b
+            if (f32_l4 && !f32_layers && l == 6 && e->chip_run && e->chip_ndw && stop_stage < 0) {
+                const bool dw8_done = skip_dw_layer == 6;
+                float* const src = dw8_done ? buf_b : buf_a;
+                float* const dst = dw8_done ? buf_a : buf_b;
+                if (bd::launch_separable_chip_f32(src, dst, gw, &sep[6], 5, stream, &sep[11], dw8_done)) {
+                    BD_REPEAT_EXTRA(23) (void)bd::launch_separable_chip_f32(src, dst, gw, &sep[6], 5, stream, &sep[11], dw8_done);
+                    l = 10;
+                    if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                    if (dw8_done) {
+                        float* t = buf_a;
+                        buf_a = buf_b;
+                        buf_b = t;
+                    }
+                    skip_dw_layer = 11;
+                    last = buf_b;
+                    last_floats = (int64_t)gw * 3 * 2 * 512;
+                    continue;
+                }
             }
             // exact-f32 mode, behind the f32 stem: layer 4 and layer 5's stride-2 depthwise as one kernel (bit-identical to the
             // three it replaces); layer 5 then starts at its 1x1 convolution

@@ -86,6 +86,14 @@ def test_strict_f32_is_measured_like_the_headline():
     assert sum(v[3] for v in plan.values()) == _network_flops()
     assert plan[5][1] == "stem3_f32_kernel" and plan[7][1] == "l4_f32_kernel" and plan[27][0] == "pw14+pool"
     assert all(plan[s][1] == "pointwise_kernel" for s in range(9, 28, 2))
+    # the default launch set since round 5: layers 8-12 + depthwise 13 as ONE launch in layer 12's slot (sepchipf32.hip)
+    launches[:] = 0
+    chip_slots = [0, 5, 7, 9, 11, 13, 23, 25, 27, 28]
+    launches[chip_slots] = 40
+    plan = bench.slot_plan_f32(launches)
+    assert sorted(plan) == chip_slots
+    assert sum(v[3] for v in plan.values()) == _network_flops()
+    assert plan[23][:2] == ("sep8-12+dw13", "sep_chip_f32_kernel") and plan[13][0] == "pw7+dw8" and plan[25][0] == "pw13+dw14"
 
 
 def test_the_line_says_what_was_measured():

@@ -9,6 +9,7 @@ for f in engine frontend resample sepf32 cnn rowfmt stemroll; do
 done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepmid.hip -o $obj/sepmid.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepchipf32.hip -o $obj/sepchipf32.o &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepmidf32.hip -o $obj/sepmidf32.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepchip.hip -o $obj/sepchip.o
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o libtrace.so $obj/*.o
