@@ -158,7 +158,8 @@ def slot_plan_f32(launches):
     algorithmic bytes, per-window flops).  Layers 1-3 are stem3_f32_kernel (slot 5), layer 4 + depthwise 5 l4_f32_kernel
     (slot 7); from layer 5 on every 1x1 convolution is pointwise_kernel with the NEXT layer's depthwise in its epilogue
     (timed in its own pointwise slot: depthwise-L output in, depthwise-(L+1) output out), layer 14 with the average pool; layers
-    8-12 + depthwise 13 are ONE launch (sep_chip_f32_kernel, layer 12's slot) when the on-chip run is on."""
+    8-12 + depthwise 13 are ONE launch (sep_chip_f32_kernel, layer 12's slot) and pointwise 5 + layers 6-7 another
+    (sep_mid_f32_kernel, layer 7's slot) when the on-chip runs are on (the default)."""
     plan = {0: ("frontend", "logmel_kernel", FRONTEND_BYTES_PER_WINDOW, 0)}
     dims = []                      # per layer 2..14: (h_in, w_in, c_in, h_out, w_out, c_out)
     h, w, c = 48, 32, 32
@@ -176,7 +177,10 @@ def slot_plan_f32(launches):
         d4, d5 = dims[2], dims[3]
         plan[7] = ("sep4+dw5", "l4_f32_kernel", (d4[0] * d4[1] * d4[2] + d5[3] * d5[4] * d5[2]) * 4, dw_fl(d4) + pw_fl(d4) + dw_fl(d5))
     # layers 8-12 + depthwise 13 as one launch (sepchipf32.hip), timed in layer 12's slot: depthwise-8 output in, depthwise-13 out
+    # (behind the middle run: layer-7 output in, the run applies depthwise 8 itself)
     chip = launches[23] > 0 and all(launches[s_] == 0 for s_ in (14, 15, 16, 17, 18, 19, 20, 21, 22))
+    # pointwise 5 + layer 6 + layer 7 as one launch (sepmidf32.hip), timed in layer 7's slot: depthwise-5 output in, layer-7 output out
+    mid = launches[13] > 0 and all(launches[s_] == 0 for s_ in (8, 9, 10, 11, 12))
     for layer in range(5, 15):
         d = dims[layer - 2]
         slot = 2 * layer - 1
@@ -185,8 +189,15 @@ def slot_plan_f32(launches):
         rows_in = d[3] * d[4] * d[2] * 4
         if chip and layer == 12:
             d8, n13 = dims[6], dims[11]
-            plan[slot] = ("sep8-12+dw13", "sep_chip_f32_kernel", d8[3] * d8[4] * d8[2] * 4 + n13[3] * n13[4] * n13[2] * 4,
-                          sum(pw_fl(dims[L_ - 2]) for L_ in range(8, 13)) + sum(dw_fl(dims[L_ - 2]) for L_ in range(9, 14)))
+            first_dw = 8 if mid else 9                             # behind the middle run depthwise 8 is this launch's work
+            plan[slot] = ("sep8-12+dw13", "sep_chip_f32_kernel",
+                          (d8[0] * d8[1] if mid else d8[3] * d8[4]) * d8[2] * 4 + n13[3] * n13[4] * n13[2] * 4,
+                          sum(pw_fl(dims[L_ - 2]) for L_ in range(8, 13)) + sum(dw_fl(dims[L_ - 2]) for L_ in range(first_dw, 14)))
+            continue
+        if mid and layer == 7:
+            d5 = dims[3]
+            plan[slot] = ("pw5-pw7", "sep_mid_f32_kernel", d5[3] * d5[4] * d5[2] * 4 + d[3] * d[4] * d[5] * 4,
+                          pw_fl(dims[3]) + dw_fl(dims[4]) + pw_fl(dims[4]) + dw_fl(dims[5]) + pw_fl(dims[5]))
             continue
         if layer == 14:
             plan[slot] = ("pw14+pool", "pointwise_kernel", rows_in + d[5] * 4, pw_fl(d) + d[3] * d[4] * d[5])

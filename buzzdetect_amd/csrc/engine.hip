@@ -479,7 +479,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         // the f32 kernel in the fragment order of v_mfma_f32_32x32x2_f32 as the exact-f32 on-chip run reads it (sepchipf32.hip):
         // for a 32-channel tile t and a super-step S of 8 k, lane l holds W[32 t + l % 32][8 S + 4 (l / 32) .. + 4]
         off_pw_ffrag[l] = 0;
-        if (cin >= 128) {                                          // layers 5-14 (what the exact-f32 on-chip runs cover, and room)
+        if (cin >= 128 && cout <= 512) {                           // layers 5-12: what the exact-f32 on-chip runs cover (5.8 MB)
             off_pw_ffrag[l] = reserve(nw);
             const float* wf = host.data() + off_pw_w[l];
             float* ff = host.data() + off_pw_ffrag[l];

@@ -94,6 +94,14 @@ def test_strict_f32_is_measured_like_the_headline():
     assert sorted(plan) == chip_slots
     assert sum(v[3] for v in plan.values()) == _network_flops()
     assert plan[23][:2] == ("sep8-12+dw13", "sep_chip_f32_kernel") and plan[13][0] == "pw7+dw8" and plan[25][0] == "pw13+dw14"
+    # ... and pointwise 5 + layers 6-7 as ONE launch in layer 7's slot (sepmidf32.hip): depthwise 8 moves into the run behind it
+    launches[:] = 0
+    mid_slots = [0, 5, 7, 13, 23, 25, 27, 28]
+    launches[mid_slots] = 40
+    plan = bench.slot_plan_f32(launches)
+    assert sorted(plan) == mid_slots
+    assert sum(v[3] for v in plan.values()) == _network_flops()
+    assert plan[13][:2] == ("pw5-pw7", "sep_mid_f32_kernel") and plan[23][1] == "sep_chip_f32_kernel"
 
 
 def test_the_line_says_what_was_measured():
