@@ -290,8 +290,10 @@ class PowerWatch:
 
 
 def visible_gpus():
-    """GPUs of this node WITHOUT any HIP call: KFD topology nodes that have SIMDs (CPU nodes report simd_count 0),
-    cut down by a *_VISIBLE_DEVICES list if one is set.  None when the topology cannot be read."""
+    """GPUs this process may use, WITHOUT any HIP call: KFD topology nodes that have SIMDs (CPU nodes report simd_count 0) AND
+    whose DRM render node this process can open - a container that leases one GPU of an eight-GPU host sees all eight in the
+    topology but only its own /dev/dri/renderD* (round 5: `--gpus 8` started eight ranks on a one-GPU box) - cut down by a
+    *_VISIBLE_DEVICES list if one is set.  None when the topology cannot be read."""
     import glob
     count = 0
     files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
@@ -299,10 +301,18 @@ def visible_gpus():
         return None
     for path in files:
         try:
+            simds, minor = 0, None
             with open(path) as f:
                 for line in f:
-                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
-                        count += 1
+                    if line.startswith("simd_count"):
+                        simds = int(line.split()[1])
+                    elif line.startswith("drm_render_minor"):
+                        minor = int(line.split()[1])
+            if simds <= 0:
+                continue
+            node = f"/dev/dri/renderD{minor}" if minor is not None and minor > 0 else None
+            if node is None or not os.path.exists("/dev/dri") or os.access(node, os.R_OK | os.W_OK):
+                count += 1                   # (no render-node information: counted, as before)
         except (OSError, ValueError):
             return None
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
@@ -311,11 +321,25 @@ def visible_gpus():
     return count
 
 
+def runtime_gpu_count():
+    """The HIP runtime's device count, asked of a short-lived CHILD process: the caller (self_launch's parent) must not open a
+    GPU before its ranks exist.  None when the child cannot say."""
+    code = "import torch; print(torch.cuda.device_count())"
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        return None
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` from a plain shell: start N fresh child ranks BEFORE this process touches a
     GPU (no HIP call and no torch import here), let rank 0's JSON line through on stdout, hand back the exit code."""
     rehearsal = os.environ.get("BD_BENCH_REHEARSAL") == "1"
     visible = visible_gpus()
+    if (visible is None or visible >= n) and not rehearsal:
+        counted = runtime_gpu_count()           # second opinion: the runtime's own count, from a short-lived child
+        visible = counted if counted is not None else visible
     if visible is not None and visible < n and not rehearsal:
         log(f"--gpus {n} but only {visible} GPU(s) visible (BD_BENCH_REHEARSAL=1 shares GPU 0 over gloo: control flow only)")
         return 2

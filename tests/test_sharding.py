@@ -169,6 +169,16 @@ def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
     monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
     calls.clear()
     assert bench.main() == 2 and not calls
+    # a container that leases ONE GPU of an eight-GPU host can see all eight in the topology (round 5: eight ranks were started
+    # on a one-GPU box): the runtime's own count, asked of a short-lived child, has the last word
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+    monkeypatch.setattr(bench, "runtime_gpu_count", lambda: 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "1"])
+    assert bench.main() == 2 and not calls
+    monkeypatch.setattr(bench, "runtime_gpu_count", lambda: 8)
+    assert bench.main() == 7 and "--nproc-per-node=8" in calls["cmd"]
+    calls.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
     src = open(os.path.join(os.path.dirname(__file__), "..", "bench.py")).read()
     launch = src[src.index("def self_launch"):src.index("# ---", src.index("def self_launch"))]
     assert "import torch" not in launch and "device_count" not in launch
