@@ -814,9 +814,12 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
         ref = engine.predict(x, 0.96).numpy()
         ref_emb = engine.embed(x, 0.96).numpy()
         ref_half = engine.predict(x[: HOP * 40], 0.48).numpy()
-        # the default: layers 1-3 as stem3_f32_kernel, layer 4 + depthwise 5 as l4_f32_kernel, the rest one kernel per op;
-        # 9 = the stem alone; 6 = layers 4-14 as one kernel each
-        for code in (True, 9):
+        # the default (round 5): layers 1-3 as stem3_f32_kernel, layer 4 + depthwise 5 as l4_f32_kernel, pointwise 5 + layers 6-7
+        # and layers 8-12 + depthwise 13 as the two on-chip runs (sepmidf32.hip, sepchipf32.hip), layers 13 / 14 as 1x1 kernels
+        # with the next depthwise / the pool in their epilogue; 10 = without the middle run (the chip run then takes the
+        # depthwise-8 output), 8 / 7 = without either (a 1x1 kernel per layer); 9 = the stem alone, two kernels per layer;
+        # 6 = layers 4-14 as one kernel each
+        for code in (True, 10, 8, 7, 9):
             engine.set_fusion(True, code)
             assert np.array_equal(engine.predict(x, 0.96).numpy(), ref), code
             assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), code
