@@ -290,7 +290,10 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    with the 12-wave kernel for 512 -> 512 channels (test hook).
                    The exact-f32 mode (bd_set_pointwise_mode 0) with stem == 3: layers 1-3 are one f32-MFMA kernel; with
                    separable 1 .. 5 (default 1) layer 4 + depthwise 5 are another and every later 1x1 convolution applies the
-                   NEXT layer's depthwise in its epilogue (no stand-alone depthwise kernel is left; layer 14 average-pools in its); with 9 / 12 the layers
+                   NEXT layer's depthwise in its epilogue (no stand-alone depthwise kernel is left; layer 14 average-pools in its) -
+                   except that, as in the default mode, pointwise 5 + layers 6-7 and layers 8-12 + depthwise 13 are one on-chip
+                   launch each (sepmidf32.hip, sepchipf32.hip: f32 stage tiles, products on v_mfma_f32_32x32x2_f32; 10 switches
+                   the first off, 7 / 8 both: test hooks); with 9 / 12 the layers
                    behind the stem run depthwise_kernel + pointwise_kernel; with stem == 0 or during calibration / stage taps
                    one kernel per op.
    Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
