@@ -61,7 +61,7 @@ _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 
         (1, 512), (1, 512), (2, 1024), (1, 1024))
 
 
-def slot_plan(launches, pool_fused=True, chip=True):
+def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel"):
     """Map the 29 profile slots to (slot name, kernel family, per-window algorithmic bytes, per-window flops)
     for the launches that actually happened (fused kernels are timed in the pointwise slot of their layer)."""
     plan = {0: ("frontend", "logmel_kernel", FRONTEND_BYTES_PER_WINDOW, 0)}
@@ -109,7 +109,7 @@ def slot_plan(launches, pool_fused=True, chip=True):
                 plan[dw_slot] = (f"dw{layer}", "depthwise_kernel", dw[0], dw[1])
         if layer == 3 and launches[pw_slot] > 0 and launches[dw_slot] == 0 and launches[1] == 0 and launches[3] == 0:
             # layers 1-3 in one kernel (stem3_kernel<true>): log-mel patch in, layer-3 output out
-            plan[pw_slot] = ("stem(1-3)", "stem3_kernel", 96 * 64 * 4 + ho * wo * cout * 4,
+            plan[pw_slot] = ("stem(1-3)", stem_kernel, 96 * 64 * 4 + ho * wo * cout * 4,
                              conv1[1] + stem_flops + dw[1] + pw[1])
         elif launches[pw_slot] > 0:
             if launches[dw_slot] > 0 or (stride == 2 and layer >= 3):
@@ -553,7 +553,8 @@ def main() -> int:
     ap.add_argument("--pointwise-mode", choices=["f16x3", "f32", "f16"], default=None,
                     help="profiling only: run the WHOLE bench in this arithmetic mode (the line then carries mode_override; "
                          "the driver's headline never uses it)")
-    ap.add_argument("--stem", type=int, default=None, help="tuning: bd_set_fusion stem code (3 = block stem, 4 = walking stem)")
+    ap.add_argument("--stem", type=int, default=None,
+                    help="tuning: bd_set_fusion stem code (3 = default: layer-2 tile handed over in registers, 4 = walking stem, 5 = block stem)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     ap.add_argument("--files-per-step", type=int, default=FILES_PER_STEP,
@@ -842,9 +843,10 @@ def main() -> int:
         if power:
             out["power"] = power
             log(f"board power {power['avg_W']} W of {power['cap_W']} W, shader clock {power['sclk_MHz_avg']} MHz")
+        stem_kernel = {None: "stem_reg_kernel", 3: "stem_reg_kernel", 4: "stem_roll_kernel"}.get(args.stem, "stem3_kernel")
         if events_on and launches.sum() > 0 and args.per_slot:
             plan = (slot_plan_f32(launches) if args.pointwise_mode == "f32"
-                    else slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None))
+                    else slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None, stem_kernel=stem_kernel))
             for slot, (nm, fam, nb, fl) in sorted(plan.items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
                 wl = windows_per_file * ev_steps / max(int(launches[slot]), 1)     # windows per launch on average
@@ -854,7 +856,7 @@ def main() -> int:
             out["ms_per_recording_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
             out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * files_per_step), 4)
             fams = {}
-            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None).items():
+            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None, stem_kernel=stem_kernel).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                 f["ms"] += ms[slot]
                 f["launches"] += int(launches[slot])
@@ -864,7 +866,7 @@ def main() -> int:
             total_ms = float(ms.sum())
             # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise (layer 12) or the
             #  average pool (layer 14) in the epilogue)
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "stem3_kernel",
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "stem3_kernel", "stem_reg_kernel", "stem_roll_kernel",
                          "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]

@@ -59,6 +59,7 @@ struct bd_engine {
     bool fuse_stem3 = true;           // (always equal to fuse_stem: the layers 1-2 only kernel is gone)
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
     bool stem_roll = false;           // layers 1-3 by walking thirds of a window (stemroll.hip; bd_set_fusion stem = 4)
+    bool stem_reg = true;             // layers 1-3 with the layer-2 tile handed over in registers (stemreg.hip; bd_set_fusion stem = 3, default)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
     bool chip_run = true;             // ... with the tiles between its layers kept on the CU (sepchip.hip; separable = 7: the
@@ -942,16 +943,17 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         if (fuse_stem3 && e->fuse_stem4) {
             {
                 Scope sc(e, stream, 5);      // timed in the slot of pointwise 3 (slots 1-4 stay empty)
-                if (e->stem_roll && mode != 0 && (stop_stage < 0 || stop_stage == 4))
-                    bd::launch_stem_roll(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
-                else
-                    bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
-                BD_REPEAT_EXTRA(5) {
-                    if (e->stem_roll && mode != 0 && (stop_stage < 0 || stop_stage == 4))
+                const bool alt = mode != 0 && (stop_stage < 0 || stop_stage == 4);
+                auto stem_launch = [&]() {
+                    if (e->stem_reg && alt)
+                        bd::launch_stem_reg(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+                    else if (e->stem_roll && alt)
                         bd::launch_stem_roll(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
                     else
                         bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
-                }
+                };
+                stem_launch();
+                BD_REPEAT_EXTRA(5) stem_launch();
             }
             last = buf_a;
             last_floats = (int64_t)gw * 24 * 16 * 128;
@@ -1465,9 +1467,10 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
-    if (stem != 0 && stem != 2 && stem != 3 && stem != 4) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2, 3 or 4");
+    if (stem != 0 && stem != 2 && stem != 3 && stem != 4 && stem != 5) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2, 3, 4 or 5");
     h->stem_roll = stem == 4;                // 4: as 3 on the kernel that walks thirds of a window (stemroll.hip)
-    if (stem == 4) stem = 3;
+    h->stem_reg = stem == 3;                 // 3 (default): the layer-2 tile handed over in registers (stemreg.hip); 5: through LDS, a
+    if (stem == 4 || stem == 5) stem = 3;    //    workgroup per row block (stem3_kernel<true>, the default until round 5; test hook)
     if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 6 &&
         separable != 7 && separable != 8 && separable != 9 && separable != 10 && separable != 12)
         return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10 or 12");

@@ -333,7 +333,8 @@ class HipEngine:
                                                     self._stream().cuda_stream))
 
     def set_fusion(self, stem=True, separable=True) -> None:
-        """Fused stem kernel (True/3 = layers 1-3 complete, 2 = up to layer 3's depthwise, False = off) and fused
+        """Fused stem kernel (True/3 = layers 1-3 complete, 4 / 5 = the same on the walking / the block kernel, 2 = up to layer 3's
+        depthwise, False = off) and fused
         depthwise+pointwise kernels (True = default path, 2 = the same with layer 4 as band tiles of the generic kernel,
         3 = the same with one launch per layer for layers 8-11 instead of one for the four, 4 / 5 = the same with layer 12 /
         layer 14 on the 8-wave kernel, 6 = as True and the exact-f32 mode on sepf32.hip's per-layer kernels, 9 / 12 = plain fused layers on

@@ -263,8 +263,12 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
    stem == 2       layers 1-2 (conv, depthwise, pointwise) and layer 3's stride-2 depthwise as one kernel that
                    writes only the depthwise output (the 402 MB layer-2 tensor never reaches HBM); profile slot 4;
    stem == 3       (default) ... and layer 3's pointwise convolution: layers 1-3 are one kernel that
-                   reads log-mel patches and writes the [24][16][128] layer-3 output; profile slot 5;
+                   reads log-mel patches and writes the [24][16][128] layer-3 output; profile slot 5.  Since round 5 the
+                   kernel that hands the layer-2 tile to layer 3's depthwise in REGISTERS and carries the row two tiles share
+                   from tile to tile (stemreg.hip): bit-identical, 129-131 vs 139 us per launch under rocprofv3;
                    (in the exact-f32 mode stem != 0 selects the same fusion on v_mfma_f32_32x32x2_f32, sepf32.hip);
+   stem == 5       as 3 on the kernel of rounds 2-4 (a workgroup per row block, the layer-2 tile through LDS:
+                   stem3_kernel<true>; test hook);
    stem == 4       as 3 on the kernel that walks a window top to bottom and carries the rows its steps share in LDS instead of
                    recomputing them per row block (stemroll.hip): bit-identical, a quarter fewer vector instructions and
                    slower (155 vs 130 us per launch, round 5) - a measured alternative, not the default;

@@ -338,7 +338,9 @@ def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
         plain_pw3 = engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy()
         plain = engine.predict(x, 0.96).numpy()
         plain_half = engine.predict(x, 0.48).numpy()      # overlapping windows read shared log-mel rows
-        for mode in (2, 3, 4):             # 4: layers 1-3 by walking thirds of a window (stemroll.hip); the taps use the block kernel
+        for mode in (2, 3, 4, 5):          # 3 (default): the layer-2 tile handed over in registers (stemreg.hip), 4: layers 1-3 by walking
+                                           # a window (stemroll.hip), 5: a workgroup per row block, the tile through LDS (stem3_kernel<true>,
+                                           # the default until round 5); the layer-2 tap uses the block kernel
             engine.set_fusion(mode, False)
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy(), plain_pw2), mode
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy(), plain_pw3), mode
@@ -348,11 +350,18 @@ def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
         y = O.synthetic_audio(HOP * 1050 + 15600, seed=56)      # (1051 windows: more than one pass, under 2^24 samples)
         for pw_mode in ("f16x3", "f16"):
             engine.set_pointwise_mode(pw_mode)
-            engine.set_fusion(3, True)
+            engine.set_fusion(5, True)
             ref, ref_emb = engine.predict(y, 0.96).numpy(), engine.embed(y, 0.96).numpy()
-            engine.set_fusion(4, True)
-            assert np.array_equal(engine.predict(y, 0.96).numpy(), ref), pw_mode
-            assert np.array_equal(engine.embed(y, 0.96).numpy(), ref_emb), pw_mode
+            for alt in (4, 3):
+                engine.set_fusion(alt, True)
+                assert np.array_equal(engine.predict(y, 0.96).numpy(), ref), (pw_mode, alt)
+                assert np.array_equal(engine.embed(y, 0.96).numpy(), ref_emb), (pw_mode, alt)
+            for windows in (1, 2, 13, 300):                 # runs that start inside a window, single tiles, a partial last pass
+                z = y[: HOP * (windows - 1) + 15600]
+                engine.set_fusion(5, True)
+                refz = engine.predict(z, 0.96).numpy()
+                engine.set_fusion(3, True)
+                assert np.array_equal(engine.predict(z, 0.96).numpy(), refz), (pw_mode, windows)
         engine.set_pointwise_mode("f16x3")
     finally:
         engine.set_fusion(True, True)
