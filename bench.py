@@ -153,7 +153,7 @@ def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel
     return plan
 
 
-def slot_plan_f32(launches):
+def slot_plan_f32(launches, stem_kernel="stem_reg_f32_kernel"):
     """The exact-f32 mode's default launch set (bd_set_pointwise_mode 0, bd_set_fusion 3 / 1): slot -> (name, kernel, per-window
     algorithmic bytes, per-window flops).  Layers 1-3 are stem3_f32_kernel (slot 5), layer 4 + depthwise 5 l4_f32_kernel
     (slot 7); from layer 5 on every 1x1 convolution is pointwise_kernel with the NEXT layer's depthwise in its epilogue
@@ -171,7 +171,7 @@ def slot_plan_f32(launches):
     conv1_fl = 2 * 9 * 48 * 32 * 32
     if launches[5] > 0 and launches[1] == 0:
         d2, d3 = dims[0], dims[1]
-        plan[5] = ("stem(1-3)", "stem3_f32_kernel", 96 * 64 * 4 + d3[3] * d3[4] * d3[5] * 4,
+        plan[5] = ("stem(1-3)", stem_kernel, 96 * 64 * 4 + d3[3] * d3[4] * d3[5] * 4,
                    conv1_fl + dw_fl(d2) + pw_fl(d2) + dw_fl(d3) + pw_fl(d3))
     if launches[7] > 0 and launches[6] == 0:
         d4, d5 = dims[2], dims[3]
@@ -845,7 +845,7 @@ def main() -> int:
             log(f"board power {power['avg_W']} W of {power['cap_W']} W, shader clock {power['sclk_MHz_avg']} MHz")
         stem_kernel = {None: "stem_reg_kernel", 3: "stem_reg_kernel", 4: "stem_roll_kernel"}.get(args.stem, "stem3_kernel")
         if events_on and launches.sum() > 0 and args.per_slot:
-            plan = (slot_plan_f32(launches) if args.pointwise_mode == "f32"
+            plan = (slot_plan_f32(launches, "stem_reg_f32_kernel" if args.stem in (None, 3) else "stem3_f32_kernel") if args.pointwise_mode == "f32"
                     else slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None, stem_kernel=stem_kernel))
             for slot, (nm, fam, nb, fl) in sorted(plan.items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
@@ -933,7 +933,7 @@ def main() -> int:
             if "ms" in strict and strict["launches"].sum() > 0:
                 sms, sl = strict["ms"], strict["launches"]
                 sf = {}
-                for slot, (nm, fam, nb, fl) in slot_plan_f32(sl).items():
+                for slot, (nm, fam, nb, fl) in slot_plan_f32(sl, "stem_reg_f32_kernel" if args.stem in (None, 3) else "stem3_f32_kernel").items():
                     f = sf.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                     f["ms"] += sms[slot]
                     f["launches"] += int(sl[slot])

@@ -174,7 +174,9 @@ void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int
 void launch_stem_roll(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                       const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 void launch_stem_reg(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                     const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);   // stemroll.hip
+                     const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
+void launch_stem_reg_f32(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
+                         const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);   // stemroll.hip
 void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);

@@ -973,9 +973,15 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // kernels it replaces (the calibration pass and the stage taps keep one kernel per op)
             {
                 Scope sc(e, stream, 5);
-                bd::launch_stem_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
-                BD_REPEAT_EXTRA(5)
-                    bd::launch_stem_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+                // (stem 3, the default: the layer-2 tile handed over in registers, stemregf32.hip; 4 / 5: stem3_f32_kernel)
+                auto stem_launch = [&]() {
+                    if (e->stem_reg)
+                        bd::launch_stem_reg_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+                    else
+                        bd::launch_stem_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+                };
+                stem_launch();
+                BD_REPEAT_EXTRA(5) stem_launch();
             }
             last = buf_a;
             last_floats = (int64_t)gw * 24 * 16 * 128;

@@ -834,6 +834,9 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
             assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), code
             assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half), code
         assert ref.shape == (windows, 13)
+        engine.set_fusion(5, True)                 # the f32 stem of rounds 4-5 (a tile through LDS) under the default launch set
+        assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)
+        assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half)
         for stem in (True, False, 2):              # stem 0 / 2 with 6: conv1 writes the SMALL buffer and the two swap roles
             engine.set_fusion(stem, 6)
             assert np.array_equal(engine.predict(x, 0.96).numpy(), ref), stem
