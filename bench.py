@@ -175,7 +175,7 @@ def slot_plan_f32(launches, stem_kernel="stem_reg_f32_kernel"):
                    conv1_fl + dw_fl(d2) + pw_fl(d2) + dw_fl(d3) + pw_fl(d3))
     if launches[7] > 0 and launches[6] == 0:
         d4, d5 = dims[2], dims[3]
-        plan[7] = ("sep4+dw5", "l4_f32_kernel", (d4[0] * d4[1] * d4[2] + d5[3] * d5[4] * d5[2]) * 4, dw_fl(d4) + pw_fl(d4) + dw_fl(d5))
+        plan[7] = ("sep4+dw5", "l4_reg_f32_kernel" if stem_kernel == "stem_reg_f32_kernel" else "l4_f32_kernel", (d4[0] * d4[1] * d4[2] + d5[3] * d5[4] * d5[2]) * 4, dw_fl(d4) + pw_fl(d4) + dw_fl(d5))
     # layers 8-12 + depthwise 13 as one launch (sepchipf32.hip), timed in layer 12's slot: depthwise-8 output in, depthwise-13 out
     # (behind the middle run: layer-7 output in, the run applies depthwise 8 itself)
     chip = launches[23] > 0 and all(launches[s_] == 0 for s_ in (14, 15, 16, 17, 18, 19, 20, 21, 22))

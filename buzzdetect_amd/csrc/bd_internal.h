@@ -153,6 +153,7 @@ bool launch_pointwise_next_dw_f32(const float* in, float* out, int windows, cons
                                   hipStream_t stream);
 bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
 bool launch_l4_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
+bool launch_l4_reg_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
 void launch_stem_f32(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,

@@ -1106,8 +1106,12 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // exact-f32 mode, behind the f32 stem: layer 4 and layer 5's stride-2 depthwise as one kernel (bit-identical to the
             // three it replaces); layer 5 then starts at its 1x1 convolution
-            if (f32_l4 && l == 2 && bd::launch_l4_f32(buf_a, buf_b, gw, L, sep[3], stream)) {
-                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_l4_f32(buf_a, buf_b, gw, L, sep[3], stream);
+            // (stem 3, the default: the layer-4 tile handed to depthwise 5 in registers, l4regf32.hip; 4 / 5: l4_f32_kernel)
+            auto l4_launch = [&]() {
+                return e->stem_reg ? bd::launch_l4_reg_f32(buf_a, buf_b, gw, L, sep[3], stream) : bd::launch_l4_f32(buf_a, buf_b, gw, L, sep[3], stream);
+            };
+            if (f32_l4 && l == 2 && l4_launch()) {
+                BD_REPEAT_EXTRA(3 + 2 * l) (void)l4_launch();
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 skip_dw_layer = 3;
                 last = buf_b;

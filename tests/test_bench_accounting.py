@@ -84,7 +84,7 @@ def test_strict_f32_is_measured_like_the_headline():
     plan = bench.slot_plan_f32(launches)
     assert sorted(plan) == f32_slots
     assert sum(v[3] for v in plan.values()) == _network_flops()
-    assert plan[5][1] == "stem_reg_f32_kernel" and plan[7][1] == "l4_f32_kernel" and plan[27][0] == "pw14+pool"
+    assert plan[5][1] == "stem_reg_f32_kernel" and plan[7][1] == "l4_reg_f32_kernel" and plan[27][0] == "pw14+pool"
     assert all(plan[s][1] == "pointwise_kernel" for s in range(9, 28, 2))
     # the default launch set since round 5: layers 8-12 + depthwise 13 as ONE launch in layer 12's slot (sepchipf32.hip)
     launches[:] = 0
