@@ -3,19 +3,24 @@
 // All activations are NHWC float32, exactly the reference's layout.
 // TF "SAME" for an even extent with stride 2 pads 0 before / 1 after; stride 1 pads 1 / 1.
 //
-// Default path (11 launches per pass):
-//   stem3_kernel<true>   layers 1-3: conv 3x3 s2 -> dw 3x3 -> pw 32->64 -> dw 3x3 s2 -> pw 64->128, one kernel
+// Default path (7 launches per pass since round 5): stem_reg_kernel (stemreg.hip: layers 1-3),
+// l4_window_kernel (here), sep_mid_kernel (sepmid.hip: pointwise 5 + layers 6-7), sep_chip_kernel (sepchip.hip: layers 8-12 +
+// depthwise 13), sep_ws_kernel (here: the plain 1x1 of layer 13), sep_w12_kernel<NDW = 2> (here: layer 14 + pool),
+// pool_head_kernel<1>.  The kernels of this file:
+//   stem3_kernel<true>   layers 1-3: conv 3x3 s2 -> dw 3x3 -> pw 32->64 -> dw 3x3 s2 -> pw 64->128, one kernel, a workgroup per
+//                        row block (the default of rounds 2-4; bd_set_fusion stem = 5)
 //   l4_window_kernel     layer 4 (depthwise + pointwise 128 -> 128 on the 24 x 16 map) + depthwise 5: persistent
 //                        workgroups that walk whole windows two map rows at a time, weights in registers
-//   pw_res_kernel        the 1x1 convolutions of layers 5 and 7 (K = 128 / 256): persistent, weights in registers
+//   pw_res_kernel        the 1x1 convolutions of layers 5 and 7 (K = 128 / 256): persistent, weights in registers (round 4's
+//                        path; bd_set_fusion separable = 10)
 //   sep_ws_kernel        fused depthwise + pointwise of a stride-1 layer, wave-specialised (4 producer + 4 MFMA
 //                        waves, slab ring by LDS-DMA, split-f16 MFMA); with PWO the plain 1x1 convolution of layer 13;
-//                        NDW = 1: next layer's stride-2 depthwise in the epilogue (layer 6; NDW = 3: layer 4 as
+//                        NDW = 1: next layer's stride-2 depthwise in the epilogue (layer 6 of round 4's path; NDW = 3: layer 4 as
 //                        overlapping band tiles, the test hook bd_set_fusion(.., 2)); NDW = 2: global average pool in
 //                        the epilogue (layer 14 on the test-hook path)
-//   sep_w12_kernel       the same with 8 MFMA waves and 512 columns per workgroup (the depthwise once per row tile): layers
-//                        8-11 as ONE launch (a workgroup takes its four windows through the four layers); NDW = 1: layer 12
-//                        + depthwise 13; NDW = 2: layer 14 + average pool, two 512-column halves per row tile
+//   sep_w12_kernel       the same with 8 MFMA waves and 512 columns per workgroup (the depthwise once per row tile): NDW = 2:
+//                        layer 14 + average pool, two 512-column halves per row tile (default); layers 8-11 as ONE launch
+//                        through global memory and NDW = 1: layer 12 + depthwise 13 (rounds 3-4; bd_set_fusion separable = 7 / 8)
 //   pool_head_kernel<1>  Dense(1024 -> n_classes) on the pooled embeddings
 // Reference kernels, one per op (the fused ones are tested bit for bit against them; they are also the exact-f32 mode):
 //   conv1_kernel, depthwise_kernel, pointwise_f16x3_kernel (split-f16), pointwise_kernel (exact-f32 MFMA),

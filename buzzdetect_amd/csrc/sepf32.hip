@@ -1,3 +1,6 @@
+// (Round 5: the mode's default launch set is stemregf32.hip, l4regf32.hip, sepmidf32.hip, sepchipf32.hip + pointwise_kernel with
+//  an epilogue for layers 13 / 14; this file's stem3_f32_kernel / l4_f32_kernel run behind bd_set_fusion stem = 5, sepf32_kernel
+//  behind separable = 6.)
 // Exact-f32 mode (bd_set_pointwise_mode 0), fused: one kernel per separable layer (yamnet.py:52-74: depthwise 3x3 + BN +
 // ReLU, 1x1 convolution + BN + ReLU) instead of depthwise_kernel + pointwise_kernel with the depthwise output through HBM.
 //
