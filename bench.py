@@ -554,7 +554,7 @@ def main() -> int:
                     help="profiling only: run the WHOLE bench in this arithmetic mode (the line then carries mode_override; "
                          "the driver's headline never uses it)")
     ap.add_argument("--stem", type=int, default=None,
-                    help="tuning: bd_set_fusion stem code (3 = default: layer-2 tile handed over in registers, 4 = walking stem, 5 = block stem)")
+                    help="tuning: bd_set_fusion stem code (3 = default: layer-2 tile handed over in registers, 5 = block stem)")
     ap.add_argument("--pw-variant", type=int, default=None, help="tuning: kernel variant of the plain 1x1 convolutions (layers 5-14)")
     ap.add_argument("--group-windows", type=int, default=0, help="windows per CNN pass (0 = library default)")
     ap.add_argument("--files-per-step", type=int, default=FILES_PER_STEP,
@@ -843,7 +843,7 @@ def main() -> int:
         if power:
             out["power"] = power
             log(f"board power {power['avg_W']} W of {power['cap_W']} W, shader clock {power['sclk_MHz_avg']} MHz")
-        stem_kernel = {None: "stem_reg_kernel", 3: "stem_reg_kernel", 4: "stem_roll_kernel"}.get(args.stem, "stem3_kernel")
+        stem_kernel = {None: "stem_reg_kernel", 3: "stem_reg_kernel"}.get(args.stem, "stem3_kernel")
         if events_on and launches.sum() > 0 and args.per_slot:
             plan = (slot_plan_f32(launches, "stem_reg_f32_kernel" if args.stem in (None, 3) else "stem3_f32_kernel") if args.pointwise_mode == "f32"
                     else slot_plan(launches, pool_fused=args.sep_variant in (None, 7), chip=args.sep_variant is None, stem_kernel=stem_kernel))
@@ -866,7 +866,7 @@ def main() -> int:
             total_ms = float(ms.sum())
             # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise (layer 12) or the
             #  average pool (layer 14) in the epilogue)
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "stem3_kernel", "stem_reg_kernel", "stem_roll_kernel",
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "stem3_kernel", "stem_reg_kernel",
                          "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
@@ -1077,12 +1077,8 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
         log(f"analyze() {name}: {legs[name]['audio_s_per_s']:.0f} audio-s/s, {legs[name]['windows_per_s']:.0f} windows/s "
             f"(second call: {legs[name]['second_call']['audio_s_per_s']:.0f} audio-s/s, {legs[name]['second_call']['windows_per_s']:.0f} "
             f"windows/s); busy {legs[name]['second_call']['stage_busy_s']}")
-    one, day = legs["config2_1h_hop1.0"], legs["config3_24h_600s_hop1.0"]
-    if day["seconds"] > one["seconds"]:
-        # both calls pay the same fixed cost (threads, planning, the last recording's sorted rewrite): the difference is
-        # the sustained rate of the pipeline
-        legs["sustained_hop1.0"] = {"audio_s_per_s": round(23 * FILE_SECONDS / (day["seconds"] - one["seconds"]), 1),
-                                    "what": "(24 h - 1 h) of audio / (t_24h - t_1h)"}
+    # (round 5's `sustained_hop1.0` - (24 h - 1 h) / (t_24h - t_1h) - was a difference of two FIRST calls and measured the
+    #  page-locking of that round's staging ring; the sustained rate of a leg is its `second_call`)
     out["analyze_audio_s_per_s"] = {"what": "analyze(): 16-bit WAV on tmpfs -> reference-format CSV, wall clock of the whole "
                                             "call (file read, H2D, device conversion, hot path, D2H, CSV) with two prebuilt "
                                             "engines (2 analyzer threads, 6 reader threads)", **legs}
@@ -1181,26 +1177,6 @@ def extras(out, args, engines, streams, device, dev_index, hop, step, framehop_s
                                                           "repeated 1024-window batch, no read-back (value_strict_f32 is the headline loop)"}
         if out.get("value_strict_f32") is None:
             out["value_strict_f32"] = modes["f32"]["value"]
-        # the same mode with every separable layer as one kernel (bd_set_fusion separable = 6, sepf32.hip): bit-identical rows,
-        # the depthwise output never in HBM; selectable, not the default (it loses a few % on three streams)
-        for e in engines:
-            e.set_pointwise_mode("f32")
-            e.set_fusion(True, 6)
-        got6 = engines[0].predict(x, framehop_s).numpy()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(k):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                engines[i % len(engines)].predict(x, framehop_s)
-        torch.cuda.synchronize()
-        sec = time.perf_counter() - t0
-        for e in engines:
-            e.set_fusion(True, True)
-            e.set_pointwise_mode("f16x3")
-        out["value_mode0_f32_fused"] = {"value": round(k * WINDOWS_PER_BATCH / sec, 1), "unit": "windows/s",
-                                        "max_abs_dlogit_vs_default_mode": float(np.abs(got6 - ref).max()),
-                                        "what": "exact-f32 mode, separable layers fused per layer (bd_set_fusion separable = 6)"}
-        log(f"pointwise mode f32, fused per layer: {out['value_mode0_f32_fused']['value']:.0f} windows/s")
         tf = modes["f32"]["value"] * CNN_FLOP_PER_WINDOW / 1e12
         out["roofline_mode0"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),

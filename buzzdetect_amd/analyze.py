@@ -191,7 +191,7 @@ def _analyze(modelname, classes_out, precision, framehop_prop, chunklength, dir_
                   step=patch_step(framehop_s), chunklength=chunklength, framelength_s=framelength_s,
                   digits_time=digits_time, digits_results=digits_results, classes_out=classes_out, threshold=threshold,
                   readers=readers, analyzers=analyzers, stop_event=event_stopanalysis,
-                  stream_buffer_depth=stream_buffer_depth)
+                  stream_buffer_depth=stream_buffer_depth, device=probe.device)
 
     if gather_logits and dist is not None and world_size > 1:
         report = _analyze_gathered(todo, dir_out, rank, world_size, probe, common, classes, framehop_s, chunklength,

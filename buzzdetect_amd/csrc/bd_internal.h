@@ -147,8 +147,6 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 void launch_scale_copy(const float* src, float* dst, int64_t n, float factor, hipStream_t stream);
 bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
                             hipStream_t stream);
-bool launch_sep_f32(const float* in, float* out, int windows, const SepLayer& L, hipStream_t stream);   // sepf32.hip
-bool sep_f32_ok(const SepLayer& L, int windows);
 bool launch_pointwise_next_dw_f32(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& Ln,
                                   hipStream_t stream);
 bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
@@ -172,12 +170,10 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
 void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
-void launch_stem_roll(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 void launch_stem_reg(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 void launch_stem_reg_f32(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                         const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);   // stemroll.hip
+                         const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);   // stemregf32.hip
 void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b,
                   const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);

@@ -55,10 +55,8 @@ struct bd_engine {
     unsigned* d_range_flag = nullptr; // sticky: an activation exceeded the f16 range in mode 1 / 2 (bd_range_flag)
     bool fuse_stem = true;            // layers 1-2 and the depthwise of layer 3 as one kernel (split-f16 mode only)
     bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
-    bool fuse_f32 = false;            // exact-f32 mode: a separable layer as one kernel (bd_set_fusion separable = 6; sepf32.hip)
     bool fuse_stem3 = true;           // (always equal to fuse_stem: the layers 1-2 only kernel is gone)
     bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
-    bool stem_roll = false;           // layers 1-3 by walking thirds of a window (stemroll.hip; bd_set_fusion stem = 4)
     bool stem_reg = true;             // layers 1-3 with the layer-2 tile handed over in registers (stemreg.hip; bd_set_fusion stem = 3, default)
     bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
     bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
@@ -938,7 +936,6 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         const bool fuse_stem3 = fuse_stem && e->fuse_stem3 && (stop_stage < 0 || stop_stage >= 4);
         bool skip_dw3 = false;
         int skip_dw_layer = -1;      // loop index of a layer whose depthwise the previous kernel already applied
-        bool f32_layers = false;     // exact-f32 mode: every separable layer as one kernel (sepf32.hip)
         bool f32_l4 = false;         // exact-f32 mode: layer 4 + the depthwise of layer 5 as one kernel behind the f32 stem
         if (fuse_stem3 && e->fuse_stem4) {
             {
@@ -947,8 +944,6 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 auto stem_launch = [&]() {
                     if (e->stem_reg && alt)
                         bd::launch_stem_reg(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
-                    else if (e->stem_roll && alt)
-                        bd::launch_stem_roll(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
                     else
                         bd::launch_stem4(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
                 };
@@ -987,19 +982,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             last_floats = (int64_t)gw * 24 * 16 * 128;
             first_layer = 2;
             f32_l4 = e->fuse_sep && e->fuse_next_dw;
-            f32_layers = mode == 0 && e->fuse_f32;
-            for (int l = 2; l < 13 && f32_layers; ++l) f32_layers = bd::sep_f32_ok(sep[l], gw);
         } else {
-            // exact-f32 mode with fused separable layers (sepf32.hip): layer 2's output (98 304 floats per window) needs the
-            // larger buffer, so conv1 writes the smaller one and the two swap roles for the pass
-            bool f32_fused = mode == 0 && e->fuse_f32 && !calibrating && stop_stage < 0;
-            for (int l = 0; l < 13 && f32_fused; ++l) f32_fused = bd::sep_f32_ok(sep[l], gw);
-            f32_layers = f32_fused;
-            if (f32_fused) {
-                float* t = buf_a;
-                buf_a = buf_b;
-                buf_b = t;
-            }
             {
                 Scope sc(e, stream, 1);
                 bd::launch_conv1(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, buf_a, stream);
@@ -1073,7 +1056,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // exact-f32 mode: pointwise 5 + layer 6 + layer 7 as ONE launch (sepmidf32.hip): depthwise 5 has been applied by
             // l4_f32_kernel (buf_b); the layer-7 output lands in buf_a like any pointwise output
-            if (f32_l4 && !f32_layers && l == 3 && skip_dw_layer == 3 && e->chip_mid && stop_stage < 0 &&
+            if (f32_l4 && l == 3 && skip_dw_layer == 3 && e->chip_mid && stop_stage < 0 &&
                 bd::launch_separable_mid_f32(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream)) {
                 BD_REPEAT_EXTRA(13) (void)bd::launch_separable_mid_f32(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream);
                 l = 5;
@@ -1085,7 +1068,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // exact-f32 mode: layers 8-12 + the depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchipf32.hip).
             // Its input is the layer-7 output (buf_a) or, when the launch in front applied depthwise 8 in its epilogue, that
             // (buf_b); layer 13 then starts at its 1x1 convolution on the depthwise-13 output in buf_b
-            if (f32_l4 && !f32_layers && l == 6 && e->chip_run && e->chip_ndw && stop_stage < 0) {
+            if (f32_l4 && l == 6 && e->chip_run && e->chip_ndw && stop_stage < 0) {
                 const bool dw8_done = skip_dw_layer == 6;
                 float* const src = dw8_done ? buf_b : buf_a;
                 float* const dst = dw8_done ? buf_a : buf_b;
@@ -1146,22 +1129,6 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 if (stop_stage == 2 * l + 2) stopped = true;
                 continue;
             }
-            // exact-f32 mode: depthwise + 1x1 convolution of the layer as one kernel, the depthwise output never leaves the CU
-            // (the calibration pass and the stage taps keep one kernel per op: they look at the depthwise output)
-            if (f32_layers && skip_dw_layer != l) {
-                // sep_f32_ok said yes for every layer before the buffers were swapped (conv1 wrote the SMALL one): falling
-                // through to depthwise_kernel + pointwise_kernel here would write 98 304 floats per window into it
-                if (!bd::launch_sep_f32(buf_a, buf_b, gw, L, stream))
-                    return fail(BD_EHIP, "exact-f32 fused layer refused a shape that sep_f32_ok accepted");
-                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_sep_f32(buf_a, buf_b, gw, L, stream);
-                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
-                float* t = buf_a;
-                buf_a = buf_b;
-                buf_b = t;
-                last = buf_a;
-                last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
-                continue;
-            }
             if (!(skip_dw3 && l == 1) && skip_dw_layer != l) {
                 Scope sc(e, stream, 2 + 2 * l);
                 bd::launch_depthwise(buf_a, buf_b, gw, L, stream);
@@ -1177,7 +1144,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // layer starts at its own 1x1 convolution.  Timed in this layer's pointwise slot.
             // ... and the last layer average-pools in its epilogue: only [windows][1024] is written (into the caller's embedding
             // buffer if there is one), the head reads that
-            if (f32_l4 && !f32_layers && l == 12) {
+            if (f32_l4 && l == 12) {
                 float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_a;
                 if (bd::launch_pointwise_pool_f32(buf_b, pooled, gw, L, stream)) {
                     BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_pointwise_pool_f32(buf_b, pooled, gw, L, stream);
@@ -1192,7 +1159,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                     break;
                 }
             }
-            if (f32_l4 && !f32_layers && l + 1 < 13 && bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream)) {
+            if (f32_l4 && l + 1 < 13 && bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream)) {
                 BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 float* t = buf_a;                // the next layer's depthwise output is what buf_b holds from here on
@@ -1477,20 +1444,19 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
-    if (stem != 0 && stem != 2 && stem != 3 && stem != 4 && stem != 5) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2, 3, 4 or 5");
-    h->stem_roll = stem == 4;                // 4: as 3 on the kernel that walks thirds of a window (stemroll.hip)
+    // (4 - the walk of stemroll.hip - was measured slower in round 5 and removed in round 6: refused like any unknown code)
+    if (stem != 0 && stem != 2 && stem != 3 && stem != 5) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2, 3 or 5");
     h->stem_reg = stem == 3;                 // 3 (default): the layer-2 tile handed over in registers (stemreg.hip); 5: through LDS, a
-    if (stem == 4 || stem == 5) stem = 3;    //    workgroup per row block (stem3_kernel<true>, the default until round 5; test hook)
-    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 && separable != 6 &&
+    if (stem == 5) stem = 3;                 //    workgroup per row block (stem3_kernel<true>, the default until round 5; test hook)
+    // (6 - one exact-f32 kernel per separable layer, sepf32_kernel - was slower than the mode's default set; removed in round 6)
+    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 &&
         separable != 7 && separable != 8 && separable != 9 && separable != 10 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10 or 12");
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 7, 8, 9, 10 or 12");
     h->chip_mid = separable != 7 && separable != 8 && separable != 10;      // 10: as 1 with layers 5-7 on their four kernels
     if (separable == 10) separable = 1;
     h->chip_run = separable != 7;            // 7: layers 8-11 as one launch that hands its tiles over through global memory
     h->chip_ndw = separable != 7 && separable != 8;      // 8: the on-chip run stops at layer 11; layer 12 + depthwise 13 on their own
     if (separable == 7 || separable == 8) separable = 1;
-    h->fuse_f32 = separable == 6;            // exact-f32 mode: one kernel per separable layer (sepf32.hip); the f16 modes as 1
-    if (separable == 6) separable = 1;
     h->fuse_stem = stem != 0;
     h->fuse_stem3 = stem >= 2;
     h->fuse_stem4 = stem >= 3;

@@ -6,13 +6,16 @@ that consumes ~45 MB/s of 16-bit PCM per 10 k windows/s is not left waiting:
 
     planner     walks the recordings: skip rules, header, chunk list (resume aware) -> read units.
     readers     `readers` threads take read units of ANY recording (a single 24 h file is read by all of them):
-                positioned read straight into a slot of a ring of PINNED host buffers (16-bit PCM as it lies in
-                the file, anything else converted to float32), bounded queue (depth 2 x readers,
-                coordination.py:84-102).  The read releases the GIL.
+                positioned reads in pieces of 8 MB into the reader's OWN pair of small pinned buffers (16-bit PCM as
+                it lies in the file, anything else converted to float32), each piece sent on by an async H2D copy on
+                the reader's own stream while the next piece is read: a chunk is DEVICE-resident (a slot of a pool of
+                device buffers) when it enters the bounded queue (depth 2 x readers, coordination.py:84-102).  Only
+                readers x 16 MB of host memory is ever page-locked, whatever the chunk length (round 6: the ring of
+                chunk-sized pinned slots of round 5 page-locked ~1 GB inside the first call).  Reads release the GIL.
     analyzers   `analyzers` threads per GPU (the reference's analyzers_gpu; docs/source/tuning.rst:111), each
                 constructing and initialising ITS OWN engine in-thread (src/inference/worker.py:21,78) on its own
-                HIP stream: async H2D from the pinned slot, device-side downmix / resample / s16 -> f32, up to 64
-                chunks (~1024 windows) per launch set, async D2H of the logits into pinned memory.
+                HIP stream: wait for the chunk's copy event, device-side downmix / resample / s16 -> f32, up to 64
+                chunks (~4096 windows) per launch set, async D2H of the logits into pinned memory.
     writer      waits for the batch's event, formats rows (fastcsv: the bytes pandas would write), appends to the
                 partial file (resume safety), finalises a recording when its last chunk has been written: a
                 recording started from nothing is written out sorted from the rows kept in memory - what the
@@ -55,6 +58,8 @@ FILE_SIZE_MINIMUM = 5000          # src/config.py:20
 BOTTLENECK_SECONDS = 0.01         # src/inference/worker.py:86
 BAD_READ_ALLOWANCE = 0.01         # src/config.py:18: share of a file's tail that may be unreadable before it is a WARNING
 RESULT_BLOCKS = 6                 # pinned result blocks per analyzer: batches in flight between the GPU and the writer
+STAGE_BYTES = 8 << 20             # a reader's pinned staging buffer: a chunk travels to the device in pieces of this size
+STAGE_BUFFERS = 2                 # ... and the reader fills one while the copy out of the other is in flight
 
 
 class PipelineAborted(Exception):
@@ -93,6 +98,7 @@ class ChunkTask:
     channels: int
     rate: int
     s16: bool
+    ready: object = None          # torch.cuda.Event behind the last host-to-device copy of the chunk (None: host-only stage)
 
 
 @dataclass
@@ -116,24 +122,23 @@ class Report:
     audio_seconds: float = 0.0
     messages: List[str] = field(default_factory=list)
     # wall seconds each stage spent doing its work (summed over the stage's threads; waiting on a queue is not work):
-    # read = file -> pinned buffer, pin = first use of a pinned buffer (page locking), analyze = enqueueing a batch's copies
-    # and kernels, settle = waiting for a batch's range verdict, write_wait = the writer waiting for a batch's event,
+    # read = file -> pinned staging buffer (+ waiting for the copy that still reads it), pin = page-locking the readers'
+    # staging buffers, analyze = enqueueing a batch's kernels, settle = waiting for a batch's range verdict, write_wait = the writer waiting for a batch's event,
     # format = rows -> CSV text, write = appending it to the result files
     busy: Dict[str, float] = field(default_factory=dict)
     end_reason: str = "completed"     # or "interrupted": the caller's stop event ended the run (coordination.py:147-154)
 
 
-class PinnedRing:
-    """A fixed number of pinned host buffers handed out to readers and given back by analyzers once the H2D copy that
-    reads them has completed.  Buffers grow to the largest chunk seen.  The free list is a STACK: the slot given back
-    last goes out first, so only as many buffers are ever pinned as are in flight at once (pinning costs ~0.25 s per GB,
-    and a queue would walk through - and pin - every slot of the ring)."""
+class ChunkPool:
+    """A fixed number of DEVICE buffers, one per chunk in flight: a reader fills a slot piece by piece through its pinned
+    staging pair, the kernels read the chunk where it lies, and the writer gives the slot back once the batch's rows have
+    been read (so an exact-f32 repeat of a batch still finds its audio).  Buffers grow to the largest chunk seen.  The
+    free list is a STACK: the slot given back last goes out first, so only as many buffers exist as are in flight at
+    once.  `device` None: plain host buffers (a reader stage without a device, tests/test_analyze.py)."""
 
-    def __init__(self, slots: int, pin: bool = True):
+    def __init__(self, slots: int, device=None):
         import torch
-        self._torch = torch
-        self._pin = pin               # (False: a reader stage without a device, tests/test_analyze.py)
-        self.pin_seconds = 0.0        # (summed without a lock: a diagnostic)
+        self._torch, self.device = torch, device
         self._free: "queue.LifoQueue[int]" = queue.LifoQueue()
         self._buf: List[Optional["torch.Tensor"]] = [None] * slots
         for i in reversed(range(slots)):
@@ -150,9 +155,8 @@ class PinnedRing:
                 continue
         buf = self._buf[slot]
         if buf is None or buf.numel() < nbytes:
-            t0 = time.perf_counter()
-            self._buf[slot] = buf = self._torch.empty(max(nbytes, 1 << 20), dtype=self._torch.uint8, pin_memory=self._pin)
-            self.pin_seconds += time.perf_counter() - t0
+            # (every kernel that read the old buffer finished before its slot came back: nothing is in flight on it)
+            self._buf[slot] = buf = self._torch.empty(max(nbytes, 1 << 20), dtype=self._torch.uint8, device=self.device)
         return slot, buf
 
     def buffer(self, slot: int):
@@ -160,6 +164,22 @@ class PinnedRing:
 
     def release(self, slot: int) -> None:
         self._free.put(slot)
+
+
+class ReaderStage:
+    """One reader thread's conduit to the device: STAGE_BUFFERS pinned buffers of STAGE_BYTES (ONE allocation: the caching
+    host allocator rounds sizes up to a power of two, this is one) and a HIP stream of its own.  Page-locking costs
+    0.07-0.25 s per GB and is serialised in the driver (tools/pin_probe.py): these 16 MB cost ~1 ms."""
+
+    def __init__(self, torch, device, pin: bool):
+        t0 = time.perf_counter()
+        self.block = torch.empty(STAGE_BUFFERS * STAGE_BYTES, dtype=torch.uint8, pin_memory=pin and device is not None)
+        self.pin_seconds = time.perf_counter() - t0
+        self.halves = [self.block[i * STAGE_BYTES:(i + 1) * STAGE_BYTES] for i in range(STAGE_BUFFERS)]
+        self.host = [h.numpy() for h in self.halves]
+        self.stream = torch.cuda.Stream(device) if device is not None else None
+        self.busy = [None] * STAGE_BUFFERS            # event recorded behind the copy that reads a half
+        self.turn = 0
 
 
 class EventPool:
@@ -212,14 +232,13 @@ class ResultPool:
 
 
 class DeviceArena:
-    """Two grow-only device buffers of one analyzer, used alternately: batch n + 1 is copied in while batch n computes.  A
-    buffer is reused two batches later, behind the event recorded after the kernels that read it - no allocation in the
-    steady state, no caching-allocator bookkeeping across the two streams."""
+    """Two grow-only device buffers of one analyzer, used alternately (the 16 kHz PCM of batch n and of batch n + 1): written
+    and read on the analyzer's one stream only, so a buffer is reused two batches later in stream order - no allocation in
+    the steady state."""
 
     def __init__(self, torch, device, dtype):
         self._torch, self._device, self._dtype = torch, device, dtype
         self._buf = [None, None]
-        self.free = [None, None]                      # event recorded on the compute stream after the last reader of a buffer
 
     def get(self, which: int, count: int, stream):
         buf = self._buf[which]
@@ -236,7 +255,7 @@ class Pipeline:
                  threshold: Optional[float], readers: int = 4, analyzers: int = 2, device=None,
                  file_sink: Optional[Callable[[FileJob, List[Tuple[float, "np.ndarray"]]], None]] = None,
                  ignore_partial: bool = False, stop_event=None, stream_buffer_depth: Optional[int] = None,
-                 pin_memory: bool = True):
+                 pin_memory: bool = True, resample_quality: int = 1):
         import torch
         self.torch = torch
         self.make_engine = make_engine
@@ -245,7 +264,6 @@ class Pipeline:
         self.chunklength, self.framelength_s = chunklength, framelength_s
         self.digits_time, self.digits_results = digits_time, digits_results
         self.n_readers, self.n_analyzers = max(1, readers), max(1, analyzers)
-        self.device = device
         # file_sink: instead of writing result files, hand every finished recording's rows (sorted by chunk start) to this
         # callable from the writer thread (the multi-GPU gather: rank 0 writes what the other ranks computed)
         self.file_sink, self.ignore_partial = file_sink, ignore_partial
@@ -257,8 +275,14 @@ class Pipeline:
         self.q_analyze: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
         self.stop_event = stop_event          # anything with is_set(): threading.Event, multiprocessing.Event
         self.q_write: "queue.Queue" = queue.Queue()
-        # queue + readers' hands + batches being copied
-        self.ring = PinnedRing(max(1, depth) + 2 * self.n_readers + 16 * self.n_analyzers, pin_memory)
+        # chunks in flight: queue + readers' hands + batches between the analyzers and the writer.  They live in DEVICE
+        # memory; `pin_memory` False (no device: reader-stage tests) keeps them in host memory
+        if pin_memory and device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device if pin_memory else None
+        self.pool = ChunkPool(max(1, depth) + 2 * self.n_readers + 16 * self.n_analyzers, self.device)
+        self._stage = threading.local()
+        self.resample_quality, self._rates = resample_quality, {}     # 1: "hq", HipEngine's default (RESAMPLE_QUALITIES)
         self.events = EventPool(torch)
         self.aborted = threading.Event()
         self.error: Optional[BaseException] = None
@@ -314,6 +338,10 @@ class Pipeline:
         except (WavFormatError, OSError) as exc:           # one unreadable recording does not stop the others
             return self._skip("planner", job, f"{exc}; skipping", logging.WARNING,
                               f"unreadable, skipped: {job.shortpath} ({exc})")
+        if track.samplerate != 16000 and not self._rate_supported(track.samplerate):
+            track.close()                                   # (the reference resamples any rate; bd_resample refuses these)
+            return self._skip("planner", job, f"{job.shortpath}: cannot resample {track.samplerate} Hz to 16000 Hz on the device; skipping",
+                              logging.WARNING, f"sample rate {track.samplerate} Hz not supported, skipped: {job.shortpath}")
         job.fresh = not os.path.exists(job.rf.path_partial)
         if self.ignore_partial:
             chunks = framing.gaps_to_chunklist([(0, track.duration)], self.chunklength)
@@ -327,6 +355,13 @@ class Pipeline:
         job.outstanding = len(chunks)                      # known before the first unit is out: no finalisation race
         for chunk in chunks:
             self._put(self.q_units, ReadUnit(job, (float(chunk[0]), float(chunk[1]))))
+
+    def _rate_supported(self, rate: int) -> bool:
+        """bd_resample_supported for the quality the engines run (host only: no handle, no device)."""
+        if rate not in self._rates:
+            from . import _lib
+            self._rates[rate] = _lib.load().bd_resample_supported(int(rate), 16000, int(self.resample_quality)) == 1
+        return self._rates[rate]
 
     def _planner(self) -> None:
         try:
@@ -376,32 +411,63 @@ class Pipeline:
         if have <= 0:                                       # the whole chunk lies behind the end of a file cut short
             self._bad_read(job, track, track.frames)
             return self._drop(job)
-        raw_bytes = have * track.bytes_per_frame
-        out_bytes = raw_bytes if track.is_s16 else have * track.channels * 4
-        slot, buf = self.ring.acquire(max(raw_bytes, out_bytes), self.aborted)
+        bpf = track.bytes_per_frame
+        out_bpf = bpf if track.is_s16 else track.channels * 4          # any other sample format: float32 on the host
+        slot, dev = self.pool.acquire(have * out_bpf, self.aborted)
         try:
-            host = buf.numpy()
-            t0 = time.perf_counter()
-            got = track.read_raw_into(a, have, host)       # the one host copy; releases the GIL
-            self._busy("read", time.perf_counter() - t0)
+            st = getattr(self._stage, "st", None)
+            if st is None:
+                st = self._stage.st = ReaderStage(self.torch, self.device, self.device is not None)
+                self._busy("pin", st.pin_seconds)
+            torch = self.torch
+            piece = max(1, STAGE_BYTES // max(bpf, out_bpf))            # frames per piece
+            got = at = 0
+            t_read = 0.0
+            while got < have:
+                n = min(piece, have - got)
+                k = st.turn
+                st.turn = (k + 1) % STAGE_BUFFERS
+                t0 = time.perf_counter()
+                if st.busy[k] is not None:
+                    st.busy[k].synchronize()                   # the copy that read this half two pieces ago
+                r = track.read_raw_into(a + got, n, st.host[k])    # the one host copy; releases the GIL
+                t_read += time.perf_counter() - t0
+                if r > 0:
+                    if track.is_s16:
+                        nb = r * bpf
+                    else:
+                        f32 = track.convert(st.host[k][: r * bpf].copy())
+                        nb = f32.size * 4
+                        st.host[k][:nb] = f32.reshape(-1).view(np.uint8)
+                    if st.stream is not None:
+                        with torch.cuda.stream(st.stream):
+                            dev[at:at + nb].copy_(st.halves[k][:nb], non_blocking=True)
+                            if st.busy[k] is None:
+                                st.busy[k] = torch.cuda.Event()
+                            st.busy[k].record(st.stream)
+                    else:
+                        dev[at:at + nb].copy_(st.halves[k][:nb])
+                    at += nb
+                    got += r
+                if r < n:
+                    break
+            self._busy("read", t_read)
             if got < want:                                 # short read (src/stream/worker.py:119-127): say it, truncate the
                 self._bad_read(job, track, a + got)        # chunk, and the file ends here
                 chunk = (chunk[0], round(chunk[0] + got / track.samplerate, 1))
             if got == 0:
-                self.ring.release(slot)
+                self.pool.release(slot)
                 return self._drop(job)
-            if track.is_s16:
-                nbytes = got * track.bytes_per_frame
-            else:                                          # any other sample format: float32 on the host
-                f32 = track.convert(host[: got * track.bytes_per_frame].copy())
-                nbytes = f32.size * 4
-                host[:nbytes] = f32.reshape(-1).view(np.uint8)
+            ready = None
+            if st.stream is not None:
+                ready = self.events.take()
+                ready.record(st.stream)
             with self.lock:
                 self.report.chunks += 1
                 self.report.audio_seconds += float(chunk[1] - chunk[0])
-            self._put(self.q_analyze, ChunkTask(job, chunk, slot, nbytes, got, track.channels, track.samplerate, track.is_s16))
+            self._put(self.q_analyze, ChunkTask(job, chunk, slot, at, got, track.channels, track.samplerate, track.is_s16, ready))
         except BaseException:
-            self.ring.release(slot)
+            self.pool.release(slot)
             raise
 
     def _reader(self, rid: int) -> None:
@@ -426,18 +492,14 @@ class Pipeline:
             engine = self.make_engine()                    # per-thread engine, initialised in-thread
             device = engine.device
             stream = torch.cuda.Stream(device)
-            copy_stream = torch.cuda.Stream(device)         # host-to-device copies of batch n + 1 run under the kernels of batch n
-            copied = torch.cuda.Event()
             n_classes = engine.n_classes
             # everything a batch needs is allocated here, once: pinned result blocks sized for the largest batch the
-            # batching rule below can form, and (grow-only) device buffers for the raw bytes and the 16 kHz PCM
+            # batching rule below can form, and (grow-only) device buffers for the 16 kHz PCM; the chunks themselves are
+            # already on the device (ChunkPool), brought there by the readers
             chunk_windows = int(self.chunklength / self.framehop_s) + 2
             results_pool = ResultPool(torch, RESULT_BLOCKS, BATCH_WINDOWS + chunk_windows + 8, n_classes)
-            raw_arena = DeviceArena(torch, device, torch.uint8)
             pcm_arena = DeviceArena(torch, device, torch.float32)
             logit_dev = [torch.empty((results_pool.rows, n_classes), dtype=torch.float32, device=device) for _ in range(2)]
-            arena_free = [torch.cuda.Event(), torch.cuda.Event()]
-            arena_used = [False, False]
             log.info(f"analyzer {aid}: processing on GPU")
             t_wait = time.perf_counter()
             finished = False
@@ -458,6 +520,8 @@ class Pipeline:
                     with torch.cuda.stream(stream):
                         _, whole, _ = engine.launch(pcms, self.hop, self.step, False, True, mode="f32")
                         torch.from_numpy(item.host).copy_(whole, non_blocking=True)
+                        # (chunks that need no resampling are views of their ChunkPool slots, which the WRITER gives back
+                        #  behind this event: the repeat reads the audio of its own batch whatever has been uploaded since)
                         item.done.record(stream)          # (the writer has not seen this item yet: the event is ours)
                     engine.overflow_reruns += 1
                 self._put(self.q_write, item)
@@ -491,26 +555,17 @@ class Pipeline:
                 held = [t.slot for t in batch]
                 which = n_batch & 1
                 n_batch += 1
-                # raw bytes of the batch, back to back (256-byte aligned), in this batch's half of the arena
-                offs, at = [], 0
-                for t in batch:
-                    offs.append(at)
-                    at += (t.nbytes + 255) & ~255
                 outs = [self._out_samples(t) if (t.s16 or t.rate != 16000 or t.channels > 1) else 0 for t in batch]
-                with torch.cuda.stream(copy_stream):
-                    raw = raw_arena.get(which, at, stream)
-                    if arena_used[which]:
-                        copy_stream.wait_event(arena_free[which])      # the kernels of two batches ago have read it
-                    for t, o in zip(batch, offs):
-                        raw[o:o + t.nbytes].copy_(self.ring.buffer(t.slot)[: t.nbytes], non_blocking=True)
-                    copied.record(copy_stream)           # one event per analyzer, recorded again for every batch: the
-                                                         # wait below captures the state it has at this moment
                 with torch.cuda.stream(stream):
-                    stream.wait_event(copied)
                     pcm = pcm_arena.get(which, sum((n + 63) & ~63 for n in outs), stream)
                     pcms, pat = [], 0
-                    for t, o, n_out in zip(batch, offs, outs):
-                        view = raw[o:o + t.nbytes].view(torch.int16 if t.s16 else torch.float32).view(t.frames, t.channels)
+                    for t, n_out in zip(batch, outs):
+                        if t.ready is not None:
+                            stream.wait_event(t.ready)       # the reader's last copy of this chunk (the wait captures the
+                            self.events.give(t.ready)        # event's state now: it may be recorded again at once)
+                            t.ready = None
+                        raw = self.pool.buffer(t.slot)
+                        view = raw[: t.nbytes].view(torch.int16 if t.s16 else torch.float32).view(t.frames, t.channels)
                         if n_out:
                             pcms.append(engine.resample(view, t.rate, 16000, out=pcm[pat:pat + n_out]))   # also s16 -> f32, channel mean
                             pat += (n_out + 63) & ~63
@@ -527,11 +582,9 @@ class Pipeline:
                         host.copy_(whole, non_blocking=True)
                     done = self.events.take()
                     done.record(stream)
-                    arena_free[which].record(stream)
-                    arena_used[which] = True
                 self._busy("analyze", time.perf_counter() - t_start)
-                # the pinned slots go back to the ring when the batch's event has fired (the writer waits for it anyway);
-                # the batch itself goes to the writer one batch later, after its range word has been looked at
+                # the chunks' device slots go back to the pool when the batch's rows have been read (the writer waits for its
+                # event anyway); the batch itself goes to the writer one batch later, after its range word has been looked at
                 item = WriteItem(batch, host.numpy(), counts, done, aid, t_start, (results_pool, block))
                 held = []
                 if pending is not None:
@@ -547,7 +600,7 @@ class Pipeline:
             self.fail(exc, f"analyzer {aid}")
         finally:
             for s in held:
-                self.ring.release(s)
+                self.pool.release(s)
 
     def _out_samples(self, t: ChunkTask) -> int:
         """16 kHz samples the chunk becomes (resample_poly's length)."""
@@ -601,8 +654,8 @@ class Pipeline:
                 item.done.synchronize()
                 self._busy("write_wait", time.perf_counter() - t0)
                 self.events.give(item.done)
-                for t in item.tasks:                       # the H2D copies that read the pinned slots are long done
-                    self.ring.release(t.slot)
+                for t in item.tasks:                       # every kernel that read the chunks has finished
+                    self.pool.release(t.slot)
                 seconds = time.perf_counter() - item.t_start
                 audio = sum(t.chunk[1] - t.chunk[0] for t in item.tasks)
                 rate = audio / seconds if seconds > 0 else float("inf")
@@ -699,7 +752,6 @@ class Pipeline:
         finished.set()
         if watcher is not None:
             watcher.join()
-        self.report.busy["pin"] = self.report.busy.get("pin", 0.0) + self.ring.pin_seconds
         if self.error is not None:
             raise self.error
         return self.report

@@ -56,9 +56,14 @@ class WavTrack:
         self.samplerate, self.channels = int(rate), int(channels)
         self._tag, self._width = tag, width
         self.frames = data_len // block
-        # 0xFFFFFFFF is the "length unknown" convention of streaming writers (and RF64's placeholder): the file's own length
-        # is the only statement there is
-        self.frames_declared = self.frames if data_declared == 0xFFFFFFFF else max(self.frames, data_declared // block)
+        # 0xFFFFFFFF is the "length unknown" convention of streaming writers (and RF64's placeholder), 0x7FFFF000 .. 0x7FFFFFFF
+        # what sox / ffmpeg write into a pipe: no statement about the length at all - the file's own length is the only one
+        # there is.  (Any other count larger than the file is taken as a recorder's promise that was cut short: the reference's
+        # bad-read rule applies, pipeline._bad_read.  libsndfile may clamp such a count to the file for WAV - not verifiable
+        # here, soundfile is absent; what a clamped count changes is the log line and the planned tail chunks, which are
+        # dropped unread, never a row of the results.)
+        placeholder = data_declared >= 0x7FFFF000
+        self.frames_declared = self.frames if placeholder else max(self.frames, data_declared // block)
         self._data_off, self._block = data_off, block
         self._fd = os.open(path, os.O_RDONLY)
         self._pos = 0

@@ -287,6 +287,44 @@ def test_pipeline_two_analyzers_equals_one_and_logs_the_reference_lines(engine, 
 
 
 @pytest.mark.gpu
+def test_overflow_repeat_of_unresampled_float_chunks_reads_its_own_audio(tmp_path, monkeypatch):
+    """float32 mono 16 kHz needs no resampling: the kernels read such chunks straight out of the analyzer's raw arena.
+    When batch n - 1 is repeated in exact f32 (its range word was raised) behind batch n, batch n + 1's upload must not
+    reuse that half of the arena before the repeat has read it.  Every batch is driven out of range here, many
+    small batches are in flight, and each row must equal what the exact-f32 mode gives for ITS chunk."""
+    import struct
+    from buzzdetect_amd import pipeline as P
+    from buzzdetect_amd.analyze import analyze
+    from buzzdetect_amd.engine import HipEngine
+    audio = tmp_path / "audio"
+    audio.mkdir()
+    # distinct content per chunk, so that rows computed from another chunk's audio cannot pass
+    x = O.synthetic_audio(16000 * 400, seed=91).astype("<f4")
+    x *= np.repeat(np.linspace(0.2, 1.0, 400, dtype=np.float32), 16000)
+    fmt = struct.pack("<HHIIHH", 3, 1, 16000, 16000 * 4, 4, 32)
+    (audio / "f32mono.wav").write_bytes(_riff(fmt, x.tobytes()))
+    monkeypatch.setattr(P, "BATCH_WINDOWS", 12)                 # a batch = two 9.6 s chunks: ~ 21 batches back to back
+    eng = HipEngine()
+    try:
+        exps, _ = eng.scales()
+        bad = exps.copy()
+        bad[6 - 2] += 14
+        eng.set_pointwise_mode("f32")
+        ref = analyze("model_general_v3", chunklength=9.6, dir_audio=str(audio), dir_out=str(tmp_path / "exact"), engine=eng)
+        assert eng.overflow_reruns == 0 and ref.chunks == 42
+        eng.set_pointwise_mode("f16x3")
+        eng.set_activation_exponents(bad)
+        rep = analyze("model_general_v3", chunklength=9.6, dir_audio=str(audio), dir_out=str(tmp_path / "repeated"), engine=eng)
+        assert rep.chunks == ref.chunks and rep.windows == ref.windows == 42 * 10 - 10 + 7
+        assert eng.overflow_reruns >= 10                        # (one per batch; the batching depends on the readers' pace)
+        a = (tmp_path / "exact" / "f32mono_buzzdetect.csv").read_bytes()
+        b = (tmp_path / "repeated" / "f32mono_buzzdetect.csv").read_bytes()
+        assert a == b and a.count(b"\n") == rep.windows + 1
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
 def test_pipeline_failure_in_any_stage_stops_everything(engine, tmp_path, monkeypatch):
     """A stage that raises poisons the pipeline: analyze() re-raises the first exception instead of hanging with the other
     stages blocked on their queues (the reference's known hole); an unreadable recording is skipped, not fatal."""

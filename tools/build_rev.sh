@@ -9,7 +9,7 @@ cd "$root/buzzdetect_amd/csrc"
 obj=$(mktemp -d)
 git -C "$root" show "$rev:buzzdetect_amd/csrc/$file" > "$obj/$file"
 cp bd_internal.h "$obj/"; mkdir -p "$obj/../../include" 2>/dev/null || true
-for f in engine frontend resample sepf32 sepchip sepchipf32 sepmid sepmidf32 stemroll stemreg stemregf32 l4regf32 cnn rowfmt; do
+for f in engine frontend resample sepf32 sepchip sepchipf32 sepmid sepmidf32 stemreg stemregf32 l4regf32 cnn rowfmt; do
   src=$f.hip; [ "$f.hip" = "$file" ] && src="$obj/$file"
   flags=""; case $f in sepchip|sepmid|sepchipf32|sepmidf32) flags="-mllvm -amdgpu-sched-strategy=iterative-maxocc";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I"$root/buzzdetect_amd/csrc" $flags -c "$src" -o "$obj/$f.o" 2>/dev/null &

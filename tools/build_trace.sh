@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../buzzdetect_amd/csrc"
 obj=$(mktemp -d)
-for f in engine frontend resample sepf32 cnn rowfmt stemroll stemreg stemregf32 l4regf32; do
+for f in engine frontend resample sepf32 cnn rowfmt stemreg stemregf32 l4regf32; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -c $f.hip -o $obj/$f.o 2>/dev/null &
 done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DBD_KERNEL_TRACE -mllvm -amdgpu-sched-strategy=iterative-maxocc -c sepmid.hip -o $obj/sepmid.o &
