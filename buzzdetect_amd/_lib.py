@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 EMBEDDER_BLOB_FLOATS = 3_217_344
 EMBEDDING_SIZE = 1024
 MEL_BANDS = 64
@@ -88,6 +88,11 @@ PROTOTYPES = {
     "bd_set_fusion": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "bd_debug_pointwise_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "bd_stager_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32]),
+    "bd_stager_destroy": (C.c_int, [C.c_void_p]),
+    "bd_stager_read": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bd_stager_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "bd_stager_submit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "bd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "bd_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <memory>
 #include <string>
 #include <vector>
@@ -1537,6 +1538,92 @@ int bd_profile_read(bd_handle h, double* ms, int64_t* launches, int32_t slots) {
         h->launches[i] = 0;
     }
     return BD_PROFILE_SLOTS;
+}
+
+// ---- the streamer's way onto the device: pread -> small pinned buffers -> hipMemcpyAsync (header: bd_stager_*) ----
+struct bd_stager {
+    int device = 0, n = 0, turn = 0;
+    int64_t bytes = 0;
+    char* base = nullptr;
+    hipEvent_t busy[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool used[4] = {false, false, false, false};
+};
+
+int bd_stager_create(bd_stager_t* out, int32_t device, int64_t stage_bytes, int32_t n_stage) {
+    if (!out || stage_bytes < 4096 || stage_bytes % 4096 || n_stage < 1 || n_stage > 4)
+        return fail(BD_EINVAL, "bd_stager_create: stage_bytes must be a multiple of 4096, n_stage 1..4");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(BD_ENODEVICE, "bd_stager_create: no such HIP device (there is no CPU path)");
+    BD_HIP(hipSetDevice(device));
+    std::unique_ptr<bd_stager> st(new bd_stager);
+    st->device = device;
+    st->n = n_stage;
+    st->bytes = stage_bytes;
+    BD_HIP(hipHostMalloc(reinterpret_cast<void**>(&st->base), (size_t)(stage_bytes * n_stage), hipHostMallocDefault));
+    for (int i = 0; i < n_stage; ++i) {
+        if (hipEventCreateWithFlags(&st->busy[i], hipEventDisableTiming) != hipSuccess) {
+            bd_stager_destroy(st.release());
+            return fail(BD_EHIP, "bd_stager_create: hipEventCreate failed");
+        }
+    }
+    *out = st.release();
+    return BD_OK;
+}
+
+int bd_stager_destroy(bd_stager_t st) {
+    if (!st) return BD_OK;
+    (void)hipSetDevice(st->device);
+    for (int i = 0; i < 4; ++i) {
+        if (!st->busy[i]) continue;
+        if (st->used[i]) (void)hipEventSynchronize(st->busy[i]);
+        (void)hipEventDestroy(st->busy[i]);
+    }
+    if (st->base) (void)hipHostFree(st->base);
+    delete st;
+    return BD_OK;
+}
+
+int bd_stager_acquire(bd_stager_t st, int32_t* index, void** host) {
+    if (!st || !index || !host) return fail(BD_EINVAL, "bd_stager_acquire: null argument");
+    const int i = st->turn;
+    st->turn = (i + 1) % st->n;
+    if (st->used[i]) BD_HIP(hipEventSynchronize(st->busy[i]));      // the copy that last read this buffer
+    *index = i;
+    *host = st->base + (size_t)i * st->bytes;
+    return BD_OK;
+}
+
+int bd_stager_submit(bd_stager_t st, int32_t index, int64_t nbytes, void* dev, void* stream) {
+    if (!st || index < 0 || index >= st->n || nbytes < 0 || nbytes > st->bytes || (!dev && nbytes))
+        return fail(BD_EINVAL, "bd_stager_submit: bad argument");
+    if (nbytes == 0) return BD_OK;
+    BD_HIP(hipSetDevice(st->device));
+    BD_HIP(hipMemcpyAsync(dev, st->base + (size_t)index * st->bytes, (size_t)nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    BD_HIP(hipEventRecord(st->busy[index], (hipStream_t)stream));
+    st->used[index] = true;
+    return BD_OK;
+}
+
+int64_t bd_stager_read(bd_stager_t st, int32_t fd, int64_t offset, int64_t nbytes, void* dev, void* stream) {
+    if (!st || fd < 0 || offset < 0 || nbytes < 0 || (!dev && nbytes)) return fail(BD_EINVAL, "bd_stager_read: bad argument");
+    int64_t done = 0;
+    while (done < nbytes) {
+        int32_t i = 0;
+        void* host = nullptr;
+        if (bd_stager_acquire(st, &i, &host) != BD_OK) return BD_EHIP;
+        const int64_t want = nbytes - done < st->bytes ? nbytes - done : st->bytes;
+        int64_t got = 0;
+        while (got < want) {
+            const ssize_t r = pread(fd, static_cast<char*>(host) + got, (size_t)(want - got), (off_t)(offset + done + got));
+            if (r <= 0) break;                                      // the end of the file (or an error: what was read stands)
+            got += r;
+        }
+        if (bd_stager_submit(st, i, got, static_cast<char*>(dev) + done, stream) != BD_OK) return BD_EHIP;
+        done += got;
+        if (got < want) break;
+    }
+    return done;
 }
 
 }  // extern "C"

@@ -59,7 +59,7 @@ BOTTLENECK_SECONDS = 0.01         # src/inference/worker.py:86
 BAD_READ_ALLOWANCE = 0.01         # src/config.py:18: share of a file's tail that may be unreadable before it is a WARNING
 RESULT_BLOCKS = 6                 # pinned result blocks per analyzer: batches in flight between the GPU and the writer
 STAGE_BYTES = 8 << 20             # a reader's pinned staging buffer: a chunk travels to the device in pieces of this size
-STAGE_BUFFERS = 2                 # ... and the reader fills one while the copy out of the other is in flight
+STAGE_BUFFERS = 2                 # ... and the reader fills one while the copy out of the other is in flight (bd_stager_*)
 
 
 class PipelineAborted(Exception):
@@ -167,19 +167,41 @@ class ChunkPool:
 
 
 class ReaderStage:
-    """One reader thread's conduit to the device: STAGE_BUFFERS pinned buffers of STAGE_BYTES (ONE allocation: the caching
-    host allocator rounds sizes up to a power of two, this is one) and a HIP stream of its own.  Page-locking costs
-    0.07-0.25 s per GB and is serialised in the driver (tools/pin_probe.py): these 16 MB cost ~1 ms."""
+    """One reader thread's conduit to the device: a native stager (bd_stager_*: STAGE_BUFFERS page-locked buffers of
+    STAGE_BYTES, pread -> hipMemcpyAsync piece by piece with the interpreter lock released for the whole chunk) and a HIP
+    stream of its own.  Page-locking costs 0.07-0.25 s per GB and is serialised in the driver (tools/pin_probe.py): these
+    16 MB cost ~1 ms."""
 
-    def __init__(self, torch, device, pin: bool):
+    def __init__(self, torch, device):
+        import ctypes
+        from . import _lib
+        self._lib = _lib.load()
         t0 = time.perf_counter()
-        self.block = torch.empty(STAGE_BUFFERS * STAGE_BYTES, dtype=torch.uint8, pin_memory=pin and device is not None)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self._lib.bd_stager_create(ctypes.byref(self.handle), device.index or 0, STAGE_BYTES, STAGE_BUFFERS))
         self.pin_seconds = time.perf_counter() - t0
-        self.halves = [self.block[i * STAGE_BYTES:(i + 1) * STAGE_BYTES] for i in range(STAGE_BUFFERS)]
-        self.host = [h.numpy() for h in self.halves]
-        self.stream = torch.cuda.Stream(device) if device is not None else None
-        self.busy = [None] * STAGE_BUFFERS            # event recorded behind the copy that reads a half
-        self.turn = 0
+        self.stream = torch.cuda.Stream(device)
+
+    def read(self, fd: int, offset: int, nbytes: int, dev) -> int:
+        """File bytes -> device tensor `dev` (uint8) on this stage's stream; returns the bytes read and enqueued."""
+        from . import _lib
+        return _lib.check(self._lib.bd_stager_read(self.handle, fd, offset, nbytes, dev.data_ptr(), self.stream.cuda_stream))
+
+    def send(self, fill: Callable[["np.ndarray"], int], dev_ptr: int) -> int:
+        """One piece through the next free buffer: `fill(buffer)` writes it and returns its byte count."""
+        import ctypes
+        from . import _lib
+        index, host = ctypes.c_int32(), ctypes.c_void_p()
+        _lib.check(self._lib.bd_stager_acquire(self.handle, ctypes.byref(index), ctypes.byref(host)))
+        buf = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(STAGE_BYTES,))
+        n = fill(buf)
+        _lib.check(self._lib.bd_stager_submit(self.handle, index.value, n, dev_ptr, self.stream.cuda_stream))
+        return n
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.bd_stager_destroy(self.handle)
+            self.handle = None
 
 
 class EventPool:
@@ -282,6 +304,7 @@ class Pipeline:
         self.device = device if pin_memory else None
         self.pool = ChunkPool(max(1, depth) + 2 * self.n_readers + 16 * self.n_analyzers, self.device)
         self._stage = threading.local()
+        self._stages: List[ReaderStage] = []             # every reader's stage, closed when the run has ended
         self.resample_quality, self._rates = resample_quality, {}     # 1: "hq", HipEngine's default (RESAMPLE_QUALITIES)
         self.events = EventPool(torch)
         self.aborted = threading.Event()
@@ -415,43 +438,47 @@ class Pipeline:
         out_bpf = bpf if track.is_s16 else track.channels * 4          # any other sample format: float32 on the host
         slot, dev = self.pool.acquire(have * out_bpf, self.aborted)
         try:
-            st = getattr(self._stage, "st", None)
-            if st is None:
-                st = self._stage.st = ReaderStage(self.torch, self.device, self.device is not None)
-                self._busy("pin", st.pin_seconds)
-            torch = self.torch
-            piece = max(1, STAGE_BYTES // max(bpf, out_bpf))            # frames per piece
-            got = at = 0
-            t_read = 0.0
-            while got < have:
-                n = min(piece, have - got)
-                k = st.turn
-                st.turn = (k + 1) % STAGE_BUFFERS
-                t0 = time.perf_counter()
-                if st.busy[k] is not None:
-                    st.busy[k].synchronize()                   # the copy that read this half two pieces ago
-                r = track.read_raw_into(a + got, n, st.host[k])    # the one host copy; releases the GIL
-                t_read += time.perf_counter() - t0
-                if r > 0:
-                    if track.is_s16:
-                        nb = r * bpf
-                    else:
-                        f32 = track.convert(st.host[k][: r * bpf].copy())
-                        nb = f32.size * 4
-                        st.host[k][:nb] = f32.reshape(-1).view(np.uint8)
-                    if st.stream is not None:
-                        with torch.cuda.stream(st.stream):
-                            dev[at:at + nb].copy_(st.halves[k][:nb], non_blocking=True)
-                            if st.busy[k] is None:
-                                st.busy[k] = torch.cuda.Event()
-                            st.busy[k].record(st.stream)
-                    else:
-                        dev[at:at + nb].copy_(st.halves[k][:nb])
-                    at += nb
-                    got += r
-                if r < n:
-                    break
-            self._busy("read", t_read)
+            t0 = time.perf_counter()
+            if self.device is None:                        # host-only stage (tests): straight into the pool's host buffer
+                host = dev.numpy()
+                got = track.read_raw_into(a, have, host)
+                at = got * bpf
+                if got and not track.is_s16:
+                    f32 = track.convert(host[:at].copy())
+                    at = f32.size * 4
+                    host[:at] = f32.reshape(-1).view(np.uint8)
+                st = None
+            else:
+                st = getattr(self._stage, "st", None)
+                if st is None:
+                    st = self._stage.st = ReaderStage(self.torch, self.device)
+                    with self.lock:
+                        self._stages.append(st)
+                    self._busy("pin", st.pin_seconds)
+                    t0 = time.perf_counter()
+                if track.is_s16:                           # the file's bytes as they lie: one native call, no interpreter lock
+                    fd, off, nb = track.file_range(a, have)
+                    at = st.read(fd, off, nb, dev)
+                    got = at // bpf
+                else:                                      # converted to float32 on the host, piece by piece
+                    piece = max(1, STAGE_BYTES // max(bpf, out_bpf))
+                    got = at = 0
+                    while got < have:
+                        n = min(piece, have - got)
+                        box = {}
+
+                        def fill(buf, n=n, first=a + got):
+                            r = box["frames"] = track.read_raw_into(first, n, buf)
+                            if r == 0:
+                                return 0
+                            f32 = track.convert(buf[: r * bpf].copy())
+                            buf[: f32.size * 4] = f32.reshape(-1).view(np.uint8)
+                            return f32.size * 4
+                        at += st.send(fill, dev.data_ptr() + at)
+                        got += box["frames"]
+                        if box["frames"] < n:
+                            break
+            self._busy("read", time.perf_counter() - t0)
             if got < want:                                 # short read (src/stream/worker.py:119-127): say it, truncate the
                 self._bad_read(job, track, a + got)        # chunk, and the file ends here
                 chunk = (chunk[0], round(chunk[0] + got / track.samplerate, 1))
@@ -459,7 +486,7 @@ class Pipeline:
                 self.pool.release(slot)
                 return self._drop(job)
             ready = None
-            if st.stream is not None:
+            if st is not None:
                 ready = self.events.take()
                 ready.record(st.stream)
             with self.lock:
@@ -752,6 +779,9 @@ class Pipeline:
         finished.set()
         if watcher is not None:
             watcher.join()
+        for st in self._stages:                           # (every copy has long completed: the writer waited for each batch)
+            st.close()
+        self._stages = []
         if self.error is not None:
             raise self.error
         return self.report

@@ -122,6 +122,13 @@ class WavTrack:
     def bytes_per_frame(self) -> int:
         return self._block
 
+    def file_range(self, frame: int, n: int):
+        """(file descriptor, byte offset, byte count) of ``n`` frames from ``frame`` on, clipped to what the file holds:
+        for readers that do their own positioned reads (bd_stager_read)."""
+        frame = min(max(int(frame), 0), self.frames)
+        n = max(0, min(int(n), self.frames - frame))
+        return self._fd, self._data_off + frame * self._block, n * self._block
+
     def read(self, n: int, keep_s16: bool = False) -> np.ndarray:
         """[frames, channels] float32 in [-1, 1) (libsndfile's scaling); with ``keep_s16`` 16-bit files come back as the
         int16 view instead (the device stage scales by 1/32768 itself, halving the host-to-device bytes)."""

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BD_ABI_VERSION 4
+#define BD_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define BD_API __attribute__((visibility("default")))
@@ -166,6 +166,26 @@ BD_API int bd_resample_s16(bd_handle h, const int16_t* in_dev, int64_t n_in, int
    huge - the caller then formats that chunk the slow way, as buzzdetect_amd/fastcsv.py does); BD_EWORKSPACE / BD_EINVAL. */
 BD_API int64_t bd_format_rows(const float* values, int64_t n_rows, int32_t n_cols, int64_t row_stride, const int32_t* keep,
                               int32_t n_keep, const double* starts, char* out, int64_t capacity);
+
+/* ---- the streamer's way onto the device (round 6; ABI 5) ----
+   The reference's streamer reads a chunk with soundfile and hands the analyzer a host array (src/stream/worker.py:109-135);
+   here a chunk travels file -> device in pieces through a few small page-locked buffers, so that a process page-locks
+   n_stage * stage_bytes per reader thread once (16 MB) instead of one chunk-sized buffer per chunk in flight (~1 GB at
+   0.07-0.25 s per GB inside the first analyze() call) and the reader thread holds no interpreter lock
+   while it works.  One stager per reader thread; not thread-safe.
+     bd_stager_create   page-locks n_stage (1..4) buffers of stage_bytes on `device`, one event per buffer
+     bd_stager_read     nbytes from file descriptor fd at `offset` (pread; short at the end of the file) -> dev[0 .. n), each
+                        piece copied by hipMemcpyAsync on `stream` behind the read of the next; returns the bytes read and
+                        enqueued.  The caller orders its kernels behind the copies with an event recorded on `stream`.
+     bd_stager_acquire  the next buffer, once the copy that last read it has completed: index and host pointer (for sample
+                        formats that are converted on the host before they travel)
+     bd_stager_submit   copy the first nbytes of buffer `index` to dev on `stream` */
+typedef struct bd_stager* bd_stager_t;
+BD_API int bd_stager_create(bd_stager_t* out, int32_t device, int64_t stage_bytes, int32_t n_stage);
+BD_API int bd_stager_destroy(bd_stager_t st);
+BD_API int64_t bd_stager_read(bd_stager_t st, int32_t fd, int64_t offset, int64_t nbytes, void* dev, void* stream);
+BD_API int bd_stager_acquire(bd_stager_t st, int32_t* index, void** host);
+BD_API int bd_stager_submit(bd_stager_t st, int32_t index, int64_t nbytes, void* dev, void* stream);
 
 /* logmel_dev[n_frames][64] -> patches_dev[W][96][64], W = 1 + (n_frames - 96) / patch_step. */
 BD_API int bd_patches(bd_handle h, const float* logmel_dev, int64_t n_frames, int32_t patch_step,

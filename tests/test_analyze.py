@@ -263,9 +263,9 @@ def test_pipeline_two_analyzers_equals_one_and_logs_the_reference_lines(engine, 
     ref = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "one"), engine=engine)
     # slow readers (as decoding compressed audio is for the reference): the analyzers must report that they starve
     import time
-    from buzzdetect_amd import wavio
-    fast_read = wavio.WavTrack.read_raw_into
-    monkeypatch.setattr(wavio.WavTrack, "read_raw_into", lambda self, a, n, out: (time.sleep(0.05), fast_read(self, a, n, out))[1])
+    from buzzdetect_amd import pipeline as P
+    fast_read = P.ReaderStage.read                      # (16-bit PCM goes file -> device through the native stager)
+    monkeypatch.setattr(P.ReaderStage, "read", lambda self, fd, off, n, dev: (time.sleep(0.05), fast_read(self, fd, off, n, dev))[1])
     with caplog.at_level(logging.DEBUG, logger="buzzdetect"):
         rep = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "two"),
                       analyzers_gpu=2, n_streamers=4)

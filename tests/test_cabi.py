@@ -26,14 +26,14 @@ def declared_symbols():
 
 def test_header_and_binding_list_the_same_functions():
     assert declared_symbols() == sorted(_lib.PROTOTYPES)
-    assert len(declared_symbols()) == 39
+    assert len(declared_symbols()) == 44
 
 
 def test_library_exports_every_declared_symbol(lib):
     raw = C.CDLL(_lib.library_path())
     for name in declared_symbols():
         assert hasattr(raw, name), f"{name} not exported"
-    assert lib.bd_abi_version() == 4
+    assert lib.bd_abi_version() == 5
 
 
 def test_header_constants_match_binding():
@@ -156,3 +156,57 @@ def test_predict_chunks_argument_errors_on_device(engine):
     assert lib_.bd_set_activation_exponents(engine._handle, bad) == -1
     exps, _ = engine.scales()
     assert np.all(np.abs(exps) < 60)
+
+
+def test_stager_rejects_bad_arguments_without_a_device(lib):
+    """bd_stager_* (the streamer's way onto the device): argument errors before any device call; no device, no stager."""
+    st = C.c_void_p()
+    assert lib.bd_stager_create(None, 0, 1 << 20, 2) == -1
+    assert lib.bd_stager_create(C.byref(st), 0, 1000, 2) == -1 and b"4096" in lib.bd_last_error()
+    assert lib.bd_stager_create(C.byref(st), 0, 1 << 20, 5) == -1
+    assert lib.bd_stager_read(None, 0, 0, 16, None, None) == -1
+    assert lib.bd_stager_acquire(None, None, None) == -1 and lib.bd_stager_submit(None, 0, 0, None, None) == -1
+    assert lib.bd_stager_destroy(None) == 0
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.bd_stager_create(C.byref(st), 0, 1 << 20, 2) == -2 and b"no CPU path" in lib.bd_last_error()
+
+
+@pytest.mark.gpu
+def test_stager_moves_a_file_to_the_device_piece_by_piece(lib, tmp_path):
+    """bd_stager_read: file bytes -> device memory through two 64 KB page-locked buffers (dozens of pieces, a ragged last
+    one, a read that runs past the end of the file); bd_stager_acquire / bd_stager_submit: the same by hand."""
+    import torch
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, 64 * 1024 * 37 + 12345, dtype=np.uint8)
+    path = tmp_path / "blob.bin"
+    path.write_bytes(b"HEAD" * 11 + data.tobytes())
+    st = C.c_void_p()
+    _lib.check(lib.bd_stager_create(C.byref(st), 0, 64 * 1024, 2))
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        stream = torch.cuda.Stream()
+        dev = torch.zeros(data.size + 999, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        got = lib.bd_stager_read(st, fd, 44, data.size + 5000, dev.data_ptr(), stream.cuda_stream)
+        assert got == data.size                                            # short at the end of the file
+        stream.synchronize()
+        assert np.array_equal(dev[: data.size].cpu().numpy(), data) and int(dev[data.size:].sum()) == 0
+        assert lib.bd_stager_read(st, fd, 44 + data.size, 10, dev.data_ptr(), stream.cuda_stream) == 0
+        # by hand: three pieces written by the caller
+        dev.zero_()
+        torch.cuda.synchronize()
+        at = 0
+        for n in (64 * 1024, 1000, 64 * 1024):
+            index, host = C.c_int32(), C.c_void_p()
+            _lib.check(lib.bd_stager_acquire(st, C.byref(index), C.byref(host)))
+            buf = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint8)), shape=(64 * 1024,))
+            buf[:n] = data[at:at + n]
+            _lib.check(lib.bd_stager_submit(st, index.value, n, dev.data_ptr() + at, stream.cuda_stream))
+            at += n
+        stream.synchronize()
+        assert np.array_equal(dev[:at].cpu().numpy(), data[:at])
+        assert lib.bd_stager_submit(st, 0, 64 * 1024 + 1, dev.data_ptr(), stream.cuda_stream) == -1
+    finally:
+        os.close(fd)
+        assert lib.bd_stager_destroy(st) == 0
