@@ -2,7 +2,9 @@
 // REGISTERS: stemreg.hip's kernel with f32 A tiles ([rows][32 or 64 k] f32, 16-byte chunks XOR-swizzled as in stem3_f32_kernel)
 // and the two 1x1 convolutions on v_mfma_f32_32x32x2_f32 (round 5).  Everything else - the runs of tiles walked bottom-up, the
 // row order of layer 2's A operand that leaves a lane with two rows x 16 columns of its channel, the third row by one
-// v_permlane32_swap per column, the carried row, the halo column through LDS - is stemreg.hip's; read that file's header first.
+// v_permlane32_swap per column, the carried row, the halo column through LDS, and round 6's four conv1 rows per tile (the two
+// kept rows copied inside the band), even-columns-first accumulators with the depthwise of layer 3 on register pairs
+// (v_pk_fma_f32) and the taps of depthwise 2 in LDS - is stemreg.hip's; read that file's header first.
 // Arithmetic per element is stem3_f32_kernel's, i.e. conv1_kernel / depthwise_kernel / pointwise_kernel's (k pairs {8 s + j,
 // 8 s + 4 + j}, j = 0..3, of super-step s in ascending order; epilogue acc + shift, ReLU): bit-identical
 // (tests/test_gpu_parity.py::test_fused_f32_mode_equals_one_kernel_per_op).
@@ -16,14 +18,16 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// ---- LDS map (bytes): 52 224, three workgroups per CU ----
+// ---- LDS map (bytes): 53 504, three workgroups per CU ----
 constexpr int OFF_C1 = 0;                        // conv1 band [6][34][32] f32
 constexpr int OFF_A2 = 6 * 34 * 32 * 4;          // 26112: A tile of layer 2 [128 rows][32 k] f32 (128-byte rows, chunk ^ ((row >> 1) & 7));
                                                  //        the log-mel band [13][68] f32 before it
 constexpr int OFF_A3 = OFF_A2 + 128 * 128;       // 42496: A tile of layer 3 [32 rows][64 k] f32 (256-byte rows, chunk ^ (row & 15))
 constexpr int OFF_HALO = OFF_A3 + 32 * 256;      // 50688: column 16 of the three input rows of a half, [column tile][half][3][32 channels] f32
-constexpr int kRegF32Lds = OFF_HALO + 2 * 2 * 3 * 32 * 4;   // 52224
+constexpr int OFF_D2W = OFF_HALO + 2 * 2 * 3 * 32 * 4;   // 52224: taps and shift of depthwise 2, [10][32] f32, for the whole run
+constexpr int kRegF32Lds = OFF_D2W + 10 * 32 * 4;        // 53504
 
 __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __restrict__ logmel, int patch_step, const WindowMap map, int w0,
                                                               const float* __restrict__ c1_w, const float* __restrict__ c1_b,
@@ -37,6 +41,7 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
     float (*s_c1)[34][32] = reinterpret_cast<float (*)[34][32]>(smem + OFF_C1);
     char* const s_a2 = smem + OFF_A2;
     float* const s_halo = reinterpret_cast<float*>(smem + OFF_HALO);
+    const float* const s_d2 = reinterpret_cast<const float*>(smem + OFF_D2W);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, col = tid >> 3;               // vector phases: channel quad, map column
@@ -59,40 +64,38 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
     bool lm_ok = false;
     auto prefetch = [&](int win, int r_first) {
         const float* patch = logmel + window_frame(map, w0 + win, patch_step) * BD_MEL_BANDS;
-        const int j = tid / 17, q = tid % 17;
+        const int j = tid >> 4, q = tid & 15;              // band row, float4 of the row (rows 13 .. 15: nobody's)
         const int ih = 2 * r_first - 2 + j;
-        lm_ok = j < 13 && q < 16 && ih >= 0 && ih < BD_PATCH_FRAMES;
+        lm_ok = j < 13 && ih >= 0 && ih < BD_PATCH_FRAMES;
         const int ihc = ih < 0 ? 0 : ih >= BD_PATCH_FRAMES ? BD_PATCH_FRAMES - 1 : ih;
-        lmv = reinterpret_cast<const float4*>(patch + ihc * BD_MEL_BANDS)[q < 16 ? q : 15];
+        lmv = reinterpret_cast<const float4*>(patch + ihc * BD_MEL_BANDS)[q];
     };
 
-    // ---- layer-2 rows r_first .. r_first + 3 of a window -> ev[t][r]: this lane's channel (32 wc + frow) at row 2 fh + t,
-    //      column 16 g + r (phases A - D and the 1x1 convolution's epilogue)
-    float ev[2][16];
-    auto front = [&](auto rows_c, int r_first) {
+    // ---- layer-2 rows r_first .. r_first + 3 of a window -> ev[t][k]: this lane's channel (32 wc + frow) at row 2 fh + t, as
+    //      PAIRS of columns: k < 4: columns 16 g + 4 k, + 4 k + 2 (the even ones), k >= 4: 16 g + 4 (k - 4) + 1, + 3 (the odd ones)
+    //      (phases A - D and the 1x1 convolution's epilogue).  c1_new: how many of the C1R conv1 rows are computed here - 4 when
+    //      the tile below left rows r_first + 3, r_first + 4 in band rows 4, 5, else all
+    v2f ev[2][8];
+    auto front = [&](auto rows_c, int r_first, int c1_new) {
         constexpr int ROWS = decltype(rows_c)::value;      // 4, or 1: only row r_first (what a run that starts inside a window needs)
         constexpr int C1R = ROWS + 2, LMR = 2 * C1R + 1;
         v4f c1wt[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) c1wt[t] = *(gptr4)(pc1w + t * 32 + c4 * 4);
         const v4f c1bias = *(gptr4)(pc1b + c4 * 4);
-        // ---- A: log-mel rows 2 (r_first - 1) .. + 12 (prefetched), zero halo columns of the conv1 band ----
-        if (tid < LMR * 17) {
+        // ---- A: log-mel rows 2 (r_first - 1) .. + 12 (prefetched) ----
+        if (tid < LMR * 16) {
             float4 v = lmv;
             if (!lm_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&s_lm[tid / 17][(tid % 17) * 4]) = v;
+            *reinterpret_cast<float4*>(&s_lm[tid >> 4][(tid & 15) * 4]) = v;
+        } else if (tid >= 256 - LMR) {                     // mel band 64 of every row: the zero to the right of the patch (the band
+            float z;                                       // shares its bytes with the A tile; the zero is made here: stemreg.hip)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            *reinterpret_cast<float4*>(&s_lm[255 - tid][64]) = make_float4(z, z, z, z);
         }
-        if (tid < C1R * 2 * 8) {
-            const int r = tid / 16, side = (tid >> 3) & 1, cc = tid & 7;
-            *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][cc * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
+        __syncthreads();                                   // (the halo columns of the conv1 band were zeroed once, before the run)
         // ---- B: conv1 rows r_first - 1 .. r_first + 4 (conv1_kernel's chain: taps in (kh, kw) order, a tap row past the patch
         //         skipped; a conv1 row outside the map is the depthwise's zero padding) ----
-        v4f d2wt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) d2wt[t] = *(gptr4)(pd2w + t * 32 + c4 * 4);
-        const v4f d2bias = *(gptr4)(pd2b + c4 * 4);
         {
             float lm[3][3];
             const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
             for (int kw = 0; kw < 3; ++kw) lm[0][kw] = s_lm[0][2 * col + kw];
 #pragma unroll
             for (int i = 0; i < C1R; ++i) {
+                if (i >= c1_new) break;              // (uniform) rows r_first + 3, r_first + 4 are the tile below's rows -1, 0
                 const int c1r = r_first - 1 + i;
 #pragma unroll
                 for (int kh = 1; kh < 3; ++kh)
@@ -130,15 +134,20 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
             }
         }
         __syncthreads();
-        // ---- C: depthwise 2, four rows -> f32 A tile; position (y, x) at row 32 (2 (x >> 4) + (y & 1)) + 8 ((x & 15) >> 2)
-        //         + 4 (y >> 1) + (x & 3) ----
+        // ---- C: depthwise 2, four rows -> f32 A tile; position (y, x) at row 32 (2 (x >> 4) + (y & 1)) + 8 (r >> 2)
+        //         + 4 (y >> 1) + (r & 3), r = the accumulator register of column x & 15 (even columns in r = 0 .. 7) ----
         {
+            v4f d2wt[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) d2wt[t] = *reinterpret_cast<const v4f*>(s_d2 + t * 32 + c4 * 4);
+            const v4f d2bias = *reinterpret_cast<const v4f*>(s_d2 + 9 * 32 + c4 * 4);
             v4f cv[3][3];
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) cv[kh][kw] = *reinterpret_cast<const v4f*>(&s_c1[kh][col + kw][c4 * 4]);
-            const int rbase = 64 * (col >> 4) + 8 * ((col & 15) >> 2) + (col & 3);
+            const int racc = ((col & 1) << 3) + ((col & 15) >> 1);            // accumulator register of this column: evens first
+            const int rbase = 64 * (col >> 4) + 8 * (racc >> 2) + (racc & 3);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
@@ -166,6 +175,14 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < 4; ++q) w2[q] = *(gptr4)(pw2 + (size_t)(wc * 32 + frow) * 32 + 8 * q + 4 * fh);
         __syncthreads();
+        if constexpr (ROWS == 4) {
+            // conv1 rows r_first - 1, r_first are rows r_first' + 3, r_first' + 4 of the tile above: into band rows 4, 5 (every
+            // thread moves the two values it wrote in phase B; the next reader is the tile above's phase C, two barriers on)
+            const v4f k0 = *reinterpret_cast<const v4f*>(&s_c1[0][col + 1][c4 * 4]);
+            const v4f k1 = *reinterpret_cast<const v4f*>(&s_c1[1][col + 1][c4 * 4]);
+            *reinterpret_cast<v4f*>(&s_c1[4][col + 1][c4 * 4]) = k0;
+            *reinterpret_cast<v4f*>(&s_c1[5][col + 1][c4 * 4]) = k1;
+        }
         // ---- D: [128][32] x [32][64]: wave (g, wc) = row tiles 2 g, 2 g + 1 against column tile wc; lane = output channel ----
         const float b2 = pb2[wc * 32 + frow];
         f32x16 acc2[2];
@@ -183,26 +200,38 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
                 acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, w2[q].w, acc2[t], 0, 0, 0);
             }
         }
-        // epilogue: accumulator (t, r, half fh) is row 32 (2 g + t) + 8 (r >> 2) + 4 fh + (r & 3) = position (2 fh + t, 16 g + r)
+        // epilogue: accumulator (t, r, half fh) is row 32 (2 g + t) + 8 (r >> 2) + 4 fh + (r & 3) = position (2 fh + t, 16 g + column
+        // of register r)
 #pragma unroll
         for (int t = 0; t < (ROWS == 1 ? 1 : 2); ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ev[t][r] = fmaxf(acc2[t][r] + b2, 0.0f);
+            for (int k = 0; k < 8; ++k) {
+                const v2f v = v2f{acc2[t][2 * k], acc2[t][2 * k + 1]} + v2f{b2, b2};
+                ev[t][k] = v2f{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
+            }
     };
 
-    float carry[16];                                       // half 0: row 0 of the tile below (= row 4 of this one), column 16 g + r
+    v2f carry[8];                                          // half 0: row 0 of the tile below (= row 4 of this one), in ev's pairs
     if (t_begin < t_end) {
+        if (tid >= 128 && tid < 128 + 80) {                // depthwise 2's taps [9][32] and shift [32] into LDS for the whole run
+            const int row = (tid - 128) >> 3, cc = tid & 7;
+            *reinterpret_cast<v4f*>(smem + OFF_D2W + (row * 32 + cc * 4) * 4) = row < 9 ? *(gptr4)(pd2w + row * 32 + cc * 4) : *(gptr4)(pd2b + cc * 4);
+        }
+        if (tid < 6 * 2 * 8) {                             // columns -1 and 32 of the conv1 band: zero for the whole run
+            const int r = tid / 16, side = (tid >> 3) & 1, cc = tid & 7;
+            *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][cc * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         {
             const int win0 = t_begin / 12, ob0 = 11 - t_begin % 12;
             if (ob0 != 11) {                               // the run starts inside a window: the front half of the tile below
                 prefetch(win0, 4 * ob0 + 4);
-                front(std::integral_constant<int, 1>{}, 4 * ob0 + 4);
+                front(std::integral_constant<int, 1>{}, 4 * ob0 + 4, 3);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) carry[r] = ev[0][r];
+                for (int k = 0; k < 8; ++k) carry[k] = ev[0][k];
                 __syncthreads();                           // (its A tile has been read: the next front pass may write the band)
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) carry[r] = 0.0f;      // row 48 of a window is the zero padding
+                for (int k = 0; k < 8; ++k) carry[k] = v2f{0.0f, 0.0f};      // row 48 of a window is the zero padding
             }
             prefetch(win0, 4 * ob0);
         }
@@ -211,24 +240,29 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
             asm volatile("" : "+s"(pc1w), "+s"(pc1b), "+s"(pd2w), "+s"(pd2b), "+s"(pw2), "+s"(pb2));
             asm volatile("" : "+s"(pd3w), "+s"(pd3b), "+s"(pw3), "+s"(pb3));
             const int win = t / 12, ob = 11 - t % 12;
-            front(std::integral_constant<int, 4>{}, 4 * ob);
+            // (the tile below - same window, same run - has left conv1 rows 4 ob + 3, 4 ob + 4 in band rows 4, 5)
+            front(std::integral_constant<int, 4>{}, 4 * ob, (t == t_begin || ob == 11) ? 6 : 4);
 
             // ---- the third input row of each half: row 2 (the other half's first row) for half 0, the carried row 4 for half 1:
             //      v_permlane32_swap vdst, src trades lanes 32-63 of vdst against lanes 0-31 of src ----
-            float x2[16];
+            v2f x2[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ev[0][r]), __builtin_bit_cast(unsigned, carry[r]),
-                                                                 false, false);
-                x2[r] = __builtin_bit_cast(float, fh ? (unsigned)sw[0] : (unsigned)sw[1]);
-                carry[r] = ob == 0 ? 0.0f : ev[0][r];      // what the tile above takes over (the next window's bottom tile: zeros)
+            for (int k = 0; k < 8; ++k) {
+                // (the operands go through an empty asm: stemreg.hip - with the two elements of a vector as operands this compiler
+                //  merges the two swaps into one)
+                float e0 = ev[0][k].x, e1 = ev[0][k].y, c0 = carry[k].x, c1 = carry[k].y;
+                asm("" : "+v"(e0), "+v"(e1), "+v"(c0), "+v"(c1));
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, c0), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, e1), __builtin_bit_cast(unsigned, c1), false, false);
+                x2[k] = v2f{__builtin_bit_cast(float, fh ? (unsigned)s0[0] : (unsigned)s0[1]),
+                            __builtin_bit_cast(float, fh ? (unsigned)s1[0] : (unsigned)s1[1])};
             }
             // column 16 of the three rows goes from group 1 to group 0 through LDS
             if (g == 1) {
                 float* const hw = s_halo + ((wc * 2 + fh) * 3) * 32 + frow;
-                hw[0] = ev[0][0];
-                hw[32] = ev[1][0];
-                hw[64] = x2[0];
+                hw[0] = ev[0][0].x;
+                hw[32] = ev[1][0].x;
+                hw[64] = x2[0].x;
             }
             // this lane's layer-3 taps (channel 32 wc + frow), in flight behind the barrier
             float d3w[9];
@@ -243,22 +277,28 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
                 hal[1] = hr[32];
                 hal[2] = hr[64];
             }
-            // ---- F: depthwise 3, stride 2, in registers: output (row fh, column 8 g + j) from rows 2 fh + kh, columns
-            //         16 g + 2 j + kw -> f32 A tile of layer 3 ----
+            // ---- F: depthwise 3, stride 2, in registers: outputs (row fh, columns 8 g + 2 k, + 2 k + 1) from rows 2 fh + kh, columns
+            //         16 g + 4 k + kw and 16 g + 4 k + 2 + kw (stemreg.hip) -> f32 A tile of layer 3 ----
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float a = d3b;
+            for (int k = 0; k < 4; ++k) {
+                v2f a = v2f{d3b, d3b};
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh) {
+                    const v2f* const row = kh == 0 ? ev[0] : kh == 1 ? ev[1] : x2;
+                    const v2f shifted = v2f{row[k].y, k < 3 ? row[k < 3 ? k + 1 : 0].x : hal[kh]};
+                    a = __builtin_elementwise_fma(row[k], v2f{d3w[kh * 3], d3w[kh * 3]}, a);
+                    a = __builtin_elementwise_fma(row[4 + k], v2f{d3w[kh * 3 + 1], d3w[kh * 3 + 1]}, a);
+                    a = __builtin_elementwise_fma(shifted, v2f{d3w[kh * 3 + 2], d3w[kh * 3 + 2]}, a);
+                }
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int ix = 2 * j + kw;
-                        const float v = ix < 16 ? (kh == 0 ? ev[0][ix < 16 ? ix : 0] : kh == 1 ? ev[1][ix < 16 ? ix : 0] : x2[ix < 16 ? ix : 0]) : hal[kh];
-                        a = fmaf(v, d3w[kh * 3 + kw], a);
-                    }
-                const int pos = fh * 16 + 8 * g + j, k3 = 32 * wc + frow;
-                *reinterpret_cast<float*>(smem + OFF_A3 + pos * 256 + (((k3 >> 2) ^ (pos & 15)) << 4) + (k3 & 3) * 4) = fmaxf(a, 0.0f);
+                for (int e = 0; e < 2; ++e) {
+                    const int pos = fh * 16 + 8 * g + 2 * k + e, k3 = 32 * wc + frow;
+                    *reinterpret_cast<float*>(smem + OFF_A3 + pos * 256 + (((k3 >> 2) ^ (pos & 15)) << 4) + (k3 & 3) * 4) = fmaxf(e ? a.y : a.x, 0.0f);
+                }
             }
+            // what the tile above takes over: this tile's first row (the next window's bottom tile: zeros, its padding row)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) carry[k] = ob == 0 ? v2f{0.0f, 0.0f} : ev[0][k];
             // the next tile's log-mel band (the last tile of the run: its own again), in flight behind the matrix phase
             {
                 const int tn = t + 1 < t_end ? t + 1 : t;

@@ -178,7 +178,8 @@ class ReaderStage:
         self._lib = _lib.load()
         t0 = time.perf_counter()
         self.handle = ctypes.c_void_p()
-        _lib.check(self._lib.bd_stager_create(ctypes.byref(self.handle), device.index or 0, STAGE_BYTES, STAGE_BUFFERS))
+        self.device_index = device.index or 0
+        _lib.check(self._lib.bd_stager_create(ctypes.byref(self.handle), self.device_index, STAGE_BYTES, STAGE_BUFFERS))
         self.pin_seconds = time.perf_counter() - t0
         self.stream = torch.cuda.Stream(device)
 
@@ -202,6 +203,26 @@ class ReaderStage:
         if self.handle:
             self._lib.bd_stager_destroy(self.handle)
             self.handle = None
+
+    # Stages outlive a run: page-locking and un-locking their buffers costs a few milliseconds each, serialised in the driver,
+    # which a process that analyses folder after folder would pay at both ends of every call.  A finished run hands its stages
+    # back (every copy out of them has completed by then); the next run's readers take them from here.
+    _idle: "Dict[int, List[ReaderStage]]" = {}
+    _idle_lock = threading.Lock()
+
+    @classmethod
+    def take(cls, torch, device) -> "ReaderStage":
+        with cls._idle_lock:
+            idle = cls._idle.get(device.index or 0)
+            if idle:
+                st = idle.pop()
+                st.pin_seconds = 0.0
+                return st
+        return cls(torch, device)
+
+    def give_back(self) -> None:
+        with ReaderStage._idle_lock:
+            ReaderStage._idle.setdefault(self.device_index, []).append(self)
 
 
 class EventPool:
@@ -451,7 +472,7 @@ class Pipeline:
             else:
                 st = getattr(self._stage, "st", None)
                 if st is None:
-                    st = self._stage.st = ReaderStage(self.torch, self.device)
+                    st = self._stage.st = ReaderStage.take(self.torch, self.device)
                     with self.lock:
                         self._stages.append(st)
                     self._busy("pin", st.pin_seconds)
@@ -779,8 +800,9 @@ class Pipeline:
         finished.set()
         if watcher is not None:
             watcher.join()
-        for st in self._stages:                           # (every copy has long completed: the writer waited for each batch)
-            st.close()
+        for st in self._stages:                           # (an aborted run may have left copies in flight: they end before the
+            st.stream.synchronize()                        #  stage is used again)
+            st.give_back()
         self._stages = []
         if self.error is not None:
             raise self.error

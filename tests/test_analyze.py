@@ -438,10 +438,10 @@ def test_stop_event_ends_the_run_and_a_rerun_completes_it(engine, tmp_path, monk
         if written["n"] == 2:
             stop.set()                                  # "after the second chunk"
 
-    fast_read = wavio.WavTrack.read_raw_into
+    from buzzdetect_amd import pipeline as P
+    fast_read = P.ReaderStage.read                      # (16-bit PCM goes file -> device through the native stager)
     monkeypatch.setattr(R.ResultFile, "append_text", counting_append)
-    monkeypatch.setattr(wavio.WavTrack, "read_raw_into",
-                        lambda self, a, n, out: (time.sleep(0.1), fast_read(self, a, n, out))[1])
+    monkeypatch.setattr(P.ReaderStage, "read", lambda self, fd, off, n, dev: (time.sleep(0.1), fast_read(self, fd, off, n, dev))[1])
     out = {}
 
     def run():
@@ -462,7 +462,7 @@ def test_stop_event_ends_the_run_and_a_rerun_completes_it(engine, tmp_path, monk
     parts = [p for p in (tmp_path / "cut").rglob("*_buzzpart.csv")]
     assert parts, "nothing left to resume from"
     monkeypatch.setattr(R.ResultFile, "append_text", real_append)
-    monkeypatch.setattr(wavio.WavTrack, "read_raw_into", fast_read)
+    monkeypatch.setattr(P.ReaderStage, "read", fast_read)
     again = analyze("model_general_v3", chunklength=5, dir_audio=str(audio), dir_out=str(tmp_path / "cut"), engine=engine)
     assert again.end_reason == "completed" and again.chunks == 12 - written["n"]
     for rel in ("a/one", "two", "three32k"):
