@@ -194,6 +194,17 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
     for (int li = 0; li < nl; ++li) {
         const _Float16* const Wfhi = chain_ptr<_Float16>(2, li);
         const _Float16* const Wflo = chain_ptr<_Float16>(3, li);
+        // B fragments: column tile (wc, wc + 8), k16 step q -> ((tile * KQ + q) * 64 + lane) * 16 bytes: resource + lane * 16 in
+        // one register + a scalar offset.  The first k16 step's are requested in FRONT of the barrier that publishes the A
+        // operand (round 6): behind it all eight waves would wait out the same L2 round trip at once
+        const __amdgpu_buffer_rsrc_t bhr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wfhi), 0, K * K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t blr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wflo), 0, K * K * 2, 0x00020000);
+        const int btile = wc * (KQ * 1024);       // bytes of a column tile's fragments: KQ k16 steps of 1 KB
+        constexpr int jstep = 8 * KQ * 1024;      // bytes between column tiles wc and wc + 8
+        f16x8 bh0[2], bl0[2], bh1[2], bl1[2];
+#define CHIP_LB(R, B, Q, J) B[J] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(R, lane16, btile + (J) * jstep + (Q) * 1024, 0));
+#define CHIP_BLOAD(BH, BL, Q) { CHIP_LB(bhr, BH, Q, 0) CHIP_LB(blr, BL, Q, 0) CHIP_LB(bhr, BH, Q, 1) CHIP_LB(blr, BL, Q, 1) }
+        CHIP_BLOAD(bh0, bl0, 0)
         __syncthreads();                          // stages 0 .. NSLOT - 1 of layer li published
         CHIP_TS()
 
@@ -208,13 +219,6 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = zero;
-        // B fragments: column tile (wc, wc + 8), k16 step q -> ((tile * KQ + q) * 64 + lane) * 16 bytes: resource + lane * 16 in
-        // one register + a scalar offset
-        const __amdgpu_buffer_rsrc_t bhr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wfhi), 0, K * K * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t blr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Wflo), 0, K * K * 2, 0x00020000);
-        const int btile = wc * (KQ * 1024);       // bytes of a column tile's fragments: KQ k16 steps of 1 KB
-        constexpr int jstep = 8 * KQ * 1024;      // bytes between column tiles wc and wc + 8
-        f16x8 bh0[2], bl0[2], bh1[2], bl1[2];
         // ---- the K loop.  One stage = 6 steps (k16 step s = 0, 1 x row tile i = 0..2) of 6 MFMAs (2 in the plain-f16 mode).
         // Every memory request sits in its own MFMA gap, pinned there by a scheduling barrier (left alone the compiler
         // bunches the four B loads of a k16 step at the top of the stage - an in-order wave then issues no MFMA while they
@@ -223,7 +227,6 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
         //                 step t - 1 has finished with): two steps = 12 MFMAs between request and use, across stages too;
         //   B fragments   two sets (k16 step 0 / 1 of a stage); a register is requested again in the gap after the last MFMA
         //                 that reads it, three steps = 18 MFMAs before its next use.
-#define CHIP_LB(R, B, Q, J) B[J] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(R, lane16, btile + (J) * jstep + (Q) * 1024, 0));
 #define CHIP_LAH(A, S, I) A = *reinterpret_cast<const f16x8*>(abase + (((I) == 1 ? ra1 : ra0) ^ ((S) << 5)) + ((I) == 2 ? 4096 + 64 : 0));
 #define CHIP_LAL(A, S, I) A = *reinterpret_cast<const f16x8*>(abase + (((I) == 1 ? ra1 : ra0) ^ ((S) << 5)) + ((I) == 2 ? 4096 + 64 : 0) + kChipHalfBytes);
 #define CHIP_MF(I, J, A, B) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[I][J], 0, 0, 0);
@@ -264,8 +267,6 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
             CHIP_STEP(2, ah2, al2, bh1, bl1, CHIP_LAH(ah1, 0, 1), CHIP_LAL(al1, 0, 1), CHIP_NOP, CHIP_NOP, CHIP_NOP, CHIP_NOP) \
         }                                                                                                 \
     }
-#define CHIP_BLOAD(BH, BL, Q) { CHIP_LB(bhr, BH, Q, 0) CHIP_LB(blr, BL, Q, 0) CHIP_LB(bhr, BH, Q, 1) CHIP_LB(blr, BL, Q, 1) }
-        CHIP_BLOAD(bh0, bl0, 0)
         CHIP_STAGES(0, NPEND)
         CHIP_TS()
         if constexpr (NPEND > 0) {

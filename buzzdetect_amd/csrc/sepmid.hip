@@ -143,9 +143,14 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             vin[t] = MID_LD32(xr, vo, ((8 * (rl >> 2) + (rl & 3)) * 128 + 32 * st) * 4);
         }
     };
+    // layer 7's B fragments (column tiles wc, wc + 8), a ring of three k16 steps; the first two are requested by the window that
+    // completes A7, in front of its last barrier
+    f16x8 b7h[3][2], b7l[3][2];
+    const __amdgpu_buffer_rsrc_t r7h = MID_RSRC(a.w7h, 256 * 512 * 2), r7l = MID_RSRC(a.w7l, 256 * 512 * 2);
     // one window through pointwise 5, layer 6 and depthwise 7; its 24 depthwise-7 rows land at rows 24 HALF .. of A7
-    auto window_to_a7 = [&](auto half_c, int win, int win_next) {
+    auto window_to_a7 = [&](auto half_c, auto last_c, int win, int win_next) {
         constexpr int HALF = decltype(half_c)::value;
+        constexpr bool LAST = decltype(last_c)::value;     // layer 7 runs behind this window
         // ---- A5: split, stage wc & 3 of the ring
         {
             const int st = wc & 3;
@@ -166,6 +171,15 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
                 }
             }
         }
+        // (the B fragments of a K loop's first two k16 steps are requested in FRONT of the barrier that publishes its A operand:
+        //  behind it every wave of the workgroup would wait out the same L2 round trip at once - round 6)
+        f16x8 bh[3], bl[3];                       // B fragments two k16 steps (18 MFMAs) ahead of their use
+        const __amdgpu_buffer_rsrc_t r5h = MID_RSRC(a.w5h, 128 * 256 * 2), r5l = MID_RSRC(a.w5l, 128 * 256 * 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bh[q] = MID_LD128(r5h, lane16, (wc * 8 + q) * 1024);
+            bl[q] = MID_LD128(r5l, lane16, (wc * 8 + q) * 1024);
+        }
         __syncthreads();                          // A5 published
         MID_TS()
         // ---- pointwise 5: [96][128] x [128][256], column tile wc
@@ -178,13 +192,6 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             for (int r = 0; r < 16; ++r) acc[i][r] = zero;
         {
             constexpr int KQ = 8;
-            const __amdgpu_buffer_rsrc_t r5h = MID_RSRC(a.w5h, 128 * 256 * 2), r5l = MID_RSRC(a.w5l, 128 * 256 * 2);
-            f16x8 bh[3], bl[3];                   // B fragments two k16 steps (18 MFMAs) ahead of their use
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                bh[q] = MID_LD128(r5h, lane16, (wc * KQ + q) * 1024);
-                bl[q] = MID_LD128(r5l, lane16, (wc * KQ + q) * 1024);
-            }
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 if (q + 2 < KQ) {
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
         }
         MID_TS()
         // ---- depthwise 6 in registers; its outputs wait (packed) for the ring: A6 takes the slots A5 is still read from
+        const __amdgpu_buffer_rsrc_t r6h = MID_RSRC(a.w6h, 256 * 256 * 2), r6l = MID_RSRC(a.w6l, 256 * 256 * 2);
         {
             unsigned out6[48];
             {
@@ -238,6 +246,11 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             }
             __syncthreads();                      // every wave has read A5: the ring is free for A6
             MID_TS()
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {         // layer 6's first B fragments, in flight behind the publication and its barrier
+                bh[q] = MID_LD128(r6h, lane16, (wc * 16 + q) * 1024);
+                bl[q] = MID_LD128(r6l, lane16, (wc * 16 + q) * 1024);
+            }
             int wbl = wb0;
             asm volatile("" : "+v"(wbl));
             char* const slot = sm + wc * kSlotA;
@@ -254,13 +267,6 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
             for (int r = 0; r < 16; ++r) acc[i][r] = zero;
         {
             constexpr int KQ = 16;
-            const __amdgpu_buffer_rsrc_t r6h = MID_RSRC(a.w6h, 256 * 256 * 2), r6l = MID_RSRC(a.w6l, 256 * 256 * 2);
-            f16x8 bh[3], bl[3];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                bh[q] = MID_LD128(r6h, lane16, (wc * KQ + q) * 1024);
-                bl[q] = MID_LD128(r6l, lane16, (wc * KQ + q) * 1024);
-            }
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 if (q + 2 < KQ) {
@@ -319,6 +325,15 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
                     }
                 }
         }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    b7h[q][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * 16 + q) * 1024);
+                    b7l[q][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * 16 + q) * 1024);
+                }
+        }
         __syncthreads();                          // A7's rows of this window published; every wave has read A6
         MID_TS()
     };
@@ -335,23 +350,14 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c7[i][j][r] = zero;
         constexpr int KQ = 16;
-        const __amdgpu_buffer_rsrc_t r7h = MID_RSRC(a.w7h, 256 * 512 * 2), r7l = MID_RSRC(a.w7l, 256 * 512 * 2);
-        f16x8 bh[3][2], bl[3][2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[q][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * KQ + q) * 1024);
-                bl[q][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * KQ + q) * 1024);
-            }
         const int ra7 = frow * 64 + ((fh ^ ((frow >> 2) & 3)) << 4);          // row frow (+ 32): key (row >> 2) & 3
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             if (q + 2 < KQ) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    bh[(q + 2) % 3][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * KQ + q + 2) * 1024);
-                    bl[(q + 2) % 3][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * KQ + q + 2) * 1024);
+                    b7h[(q + 2) % 3][j] = MID_LD128(r7h, lane16, ((wc + 8 * j) * KQ + q + 2) * 1024);
+                    b7l[(q + 2) % 3][j] = MID_LD128(r7l, lane16, ((wc + 8 * j) * KQ + q + 2) * 1024);
                 }
             }
 #pragma unroll
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
                 const char* const ap = sm + kOffA7 + (q >> 1) * kSlot7 + (ra7 ^ ((q & 1) << 5)) + i * 2048;
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(ap), al = *reinterpret_cast<const f16x8*>(ap + kHalf7);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { MID_MMA(c7[i][j], ah, al, bh[q % 3][j], bl[q % 3][j]) }
+                for (int j = 0; j < 2; ++j) { MID_MMA(c7[i][j], ah, al, b7h[q % 3][j], b7l[q % 3][j]) }
             }
         }
         MID_TS()
@@ -388,11 +394,12 @@ __global__ __launch_bounds__(512, 2) void sep_mid_kernel(const MidArgs a, const 
     if (w_begin < w_end) fetch_window(w_begin);
     for (int win = w_begin; win < w_end; win += 2) {
         const bool two = win + 1 < w_end;
-        window_to_a7(std::integral_constant<int, 0>{}, win, win + 1 < w_end ? win + 1 : -1);
         if (two) {
-            window_to_a7(std::integral_constant<int, 1>{}, win + 1, win + 2 < w_end ? win + 2 : -1);
+            window_to_a7(std::integral_constant<int, 0>{}, std::false_type{}, win, win + 1);
+            window_to_a7(std::integral_constant<int, 1>{}, std::true_type{}, win + 1, win + 2 < w_end ? win + 2 : -1);
             layer7(std::integral_constant<int, 2>{}, win);
         } else {
+            window_to_a7(std::integral_constant<int, 0>{}, std::true_type{}, win, -1);
             layer7(std::integral_constant<int, 1>{}, win);
         }
     }

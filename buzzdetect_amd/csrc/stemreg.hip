@@ -17,7 +17,7 @@
 //     (h = 1) - ONE v_permlane32_swap per column delivers both - and the one column a wave group lacks (column 16, for g = 0)
 //     crosses through 1.5 KB of LDS;
 //   * its outputs go straight into the split-f16 A tile of layer 3's 1x1 convolution, which runs as in stem3_kernel.
-// No f32 tile in LDS, no kept row in LDS, five barriers per tile instead of eight, 1.5 x fewer conv1 / 1.25 x fewer layer-2
+// No f32 tile in LDS, no kept row in LDS, five (round 6: four) barriers per tile instead of eight, 1.5 x fewer conv1 / 1.25 x fewer layer-2
 // rows than stem3_kernel.
 // Round 6 (VERDICT r5 next #1b: fewer vector instructions):
 //   * a tile's depthwise needs conv1 rows 4 ob - 1 .. 4 ob + 4, of which rows 4 ob + 3, 4 ob + 4 are rows -1, 0 of the tile
@@ -126,6 +126,21 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
         lmv = reinterpret_cast<const float4*>(patch + ihc * BD_MEL_BANDS)[q];
     };
 
+    // ---- A: the prefetched log-mel rows 2 (r_first - 1) .. + 12 of a tile into LDS.  The band shares its bytes with the A tile of
+    //      layer 2, so it is written when that tile has been read - behind the FOURTH barrier of the tile before - and the fifth
+    //      barrier of that tile makes it visible: a tile costs four barriers, not five (round 6)
+    auto band_to_lds = [&](int lmr) {
+        if (tid < lmr * 16) {
+            float4 v = lmv;
+            if (!lm_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&s_lm[tid >> 4][(tid & 15) * 4]) = v;
+        } else if (tid >= 256 - lmr) {                     // mel band 64 of every row: the zero to the right of the patch (the band
+            float z;                                       // shares its bytes with the A tile).  (A zero made HERE: hoisted out of
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));     // the tile loop, four registers of zeros end up as a spill)
+            *reinterpret_cast<float4*>(&s_lm[255 - tid][64]) = make_float4(z, z, z, z);
+        }
+    };
+
     // ---- layer-2 rows r_first .. r_first + 3 of a window -> ev[t][k]: this lane's channel (32 wc + frow) at row 2 fh + t, as
     //      PAIRS of columns: k < 4: columns 16 g + 4 k, + 4 k + 2 (the even ones), k >= 4: 16 g + 4 (k - 4) + 1, + 3 (the odd ones)
     //      (phases A - D and the 1x1 convolution's epilogue)
@@ -134,22 +149,12 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
     // rows 4, 5, else all
     auto front = [&](auto rows_c, int r_first, int c1_new) {
         constexpr int ROWS = decltype(rows_c)::value;      // 4, or 1: only row r_first (what a run that starts inside a window needs)
-        constexpr int C1R = ROWS + 2, LMR = 2 * C1R + 1;
+        constexpr int C1R = ROWS + 2;
         v4f c1wt[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) c1wt[t] = *(gptr4)(pc1w + t * 32 + c4 * 4);
         const v4f c1bias = *(gptr4)(pc1b + c4 * 4);
-        // ---- A: log-mel rows 2 (r_first - 1) .. + 12 (prefetched) ----
-        if (tid < LMR * 16) {
-            float4 v = lmv;
-            if (!lm_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&s_lm[tid >> 4][(tid & 15) * 4]) = v;
-        } else if (tid >= 256 - LMR) {                     // mel band 64 of every row: the zero to the right of the patch (the band
-            float z;                                       // shares its bytes with the A tile).  (A zero made HERE: hoisted out of
-            asm volatile("v_mov_b32 %0, 0" : "=v"(z));     // the tile loop, four registers of zeros end up as a spill)
-            *reinterpret_cast<float4*>(&s_lm[255 - tid][64]) = make_float4(z, z, z, z);
-        }
-        __syncthreads();                                   // (the halo columns of the conv1 ring were zeroed once, before the run)
+        // (phase A - the tile's log-mel band into LDS - has happened a tile earlier: band_to_lds below)
         // ---- B: conv1 rows r_first - 1 .. r_first + 4 (conv1_kernel's chain: taps in (kh, kw) order, a tap row past the patch
         //         skipped; a conv1 row outside the map is the depthwise's zero padding) ----
         {
@@ -293,21 +298,33 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
             const int win0 = t_begin / 12, ob0 = 11 - t_begin % 12;
             if (ob0 != 11) {                               // the run starts inside a window: the front half of the tile below
                 prefetch(win0, 4 * ob0 + 4);
+                band_to_lds(7);
+                __syncthreads();
                 front(std::integral_constant<int, 1>{}, 4 * ob0 + 4, 3);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) carry[k] = ev[0][k];
-                __syncthreads();                           // (its A tile has been read: the next front pass may write the band)
+                __syncthreads();                           // (its A tile has been read: the band of the first tile may be written)
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) carry[k] = v2f{0.0f, 0.0f};      // row 48 of a window is the zero padding
             }
             prefetch(win0, 4 * ob0);
+            band_to_lds(13);
+            __syncthreads();                               // the first tile's band (and the tables above) are in LDS
         }
 #pragma unroll 1
         for (int t = t_begin; t < t_end; ++t) {
             asm volatile("" : "+s"(pc1w), "+s"(pc1b), "+s"(pd2w), "+s"(pd2b), "+s"(pu2), "+s"(pb2), "+s"(pwh), "+s"(pwl));
             asm volatile("" : "+s"(pd3w), "+s"(pd3b), "+s"(pu3), "+s"(pb3), "+s"(pw3h), "+s"(pw3l));
             const int win = t / 12, ob = 11 - t % 12;
+            {   // the next tile's log-mel band (the last tile of the run: its own again): consumed behind this tile's fourth barrier
+                const int tn = t + 1 < t_end ? t + 1 : t;
+                prefetch(tn / 12, 4 * (11 - tn % 12));
+            }
+            if (ob == 11 && t != t_begin) {                // a new window: below its bottom tile lies the zero padding, not the
+#pragma unroll                                             // window before (uniform branch, one tile in twelve)
+                for (int k = 0; k < 8; ++k) carry[k] = v2f{0.0f, 0.0f};
+            }
             // (the tile below - same window, same run - has left conv1 rows 4 ob + 3, 4 ob + 4 in band rows 4, 5)
             front(std::integral_constant<int, 4>{}, 4 * ob, (t == t_begin || ob == 11) ? 6 : 4);
 
@@ -341,6 +358,7 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) w3h[q] = *(gptrh)(pw3h + ((size_t)(wave * 4 + q) * 64 + lane) * 8);
             __syncthreads();                               // halo column written; every wave has read the A tile of layer 2
+            band_to_lds(13);                               // ... whose bytes take the next tile's log-mel band
             float hal[3] = {0.0f, 0.0f, 0.0f};             // column 16 g + 16: the zero padding for g = 1
             if (g == 0) {
                 const float* const hr = s_halo + ((wc * 2 + fh) * 3) * 32 + frow;
@@ -374,14 +392,9 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
                     *reinterpret_cast<unsigned short*>(smem + OFF_A3L + off) = (unsigned short)(pk >> 16);
                 }
             }
-            // what the tile above takes over: this tile's first row (the next window's bottom tile: zeros, its padding row)
+            // what the tile above takes over: this tile's first row
 #pragma unroll
-            for (int k = 0; k < 8; ++k) carry[k] = ob == 0 ? v2f{0.0f, 0.0f} : ev[0][k];
-            // the next tile's log-mel band (the last tile of the run: its own again), in flight behind the matrix phase
-            {
-                const int tn = t + 1 < t_end ? t + 1 : t;
-                prefetch(tn / 12, 4 * (11 - tn % 12));
-            }
+            for (int k = 0; k < 8; ++k) carry[k] = ev[0][k];
             // (the low halves of the weight fragments only now: with them in flight across phase F the kernel needs more than
             //  the 168 registers three workgroups per CU leave a lane)
             if constexpr (!PLAIN) {
@@ -406,8 +419,6 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
                 }
                 acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3h[q], acc3, 0, 0, 0);
             }
-            // the loads are waited for HERE, in front of the stores (sepf32.hip: vmcnt counts both kinds, out of order)
-            asm volatile("" : "+v"(lmv.x), "+v"(lmv.y), "+v"(lmv.z), "+v"(lmv.w));
             // ---- H: bias + ReLU, [32][128] block of the layer-3 output (rows are consecutive NHWC positions) ----
             float* dst3 = out + (((size_t)win * 24 + 2 * ob) * 16) * 128;
 #pragma unroll
@@ -416,8 +427,8 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
                 const v2f t2v = __builtin_elementwise_fma(v2f{acc3[r & ~1], acc3[r | 1]}, v2f{u3, u3}, v2f{b3, b3});
                 dst3[(size_t)m * 128 + n3] = fmaxf((r & 1) ? t2v.y : t2v.x, 0.0f);
             }
-            // (no barrier: the next tile's phases A and B write the log-mel band and the conv band, which lie below the A tile
-            //  of layer 3; its phase C - the layer-2 A tile - and the halo words are one / three barriers away)
+            // (no barrier: the next tile's phase B writes the conv band, which lies below the A tile of layer 3; its phase C - the
+            //  layer-2 A tile - and the halo words are one / three barriers away)
         }
     }
     if (range_flag && !(rmax <= kF16MaxReg)) *range_flag = 1u;
