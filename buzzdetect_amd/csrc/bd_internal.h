@@ -145,17 +145,11 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
                                    float* C, long long M, int N, int K, int variant, hipStream_t stream, bool plain = false,
                                    unsigned* range_flag = nullptr);
 void launch_scale_copy(const float* src, float* dst, int64_t n, float factor, hipStream_t stream);
-bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
-                            hipStream_t stream);
 bool launch_pointwise_next_dw_f32(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& Ln,
                                   hipStream_t stream);
 bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
-bool launch_l4_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
 bool launch_l4_reg_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
-void launch_stem_f32(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                     const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
-int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,
-                         bool on_chip = true);
+int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
                            const SepLayer* next = nullptr);
 bool launch_separable_chip_f32(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
@@ -166,10 +160,7 @@ bool launch_separable_mid(const float* in, float* out, int windows, const SepLay
                           hipStream_t stream);       // sepmid.hip
 int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
-                                    bool band_tiles, hipStream_t stream, bool twelve_waves = true);
-void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                  const float* c1_b,
-                  const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
+                                    hipStream_t stream);
 void launch_stem_reg(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                      const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream);
 void launch_stem_reg_f32(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
@@ -181,7 +172,6 @@ void launch_pool_head(const float* act, int windows, const float* head_wt, const
                       int n_classes, float* emb, float* logits, hipStream_t stream);
 void launch_head(const float* pooled, int windows, const float* head_wt, const float* head_b, int n_classes,
                  float* logits, hipStream_t stream);
-bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream,
-                                 bool twelve_waves = false);
+bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
 
 }  // namespace bd

@@ -801,17 +801,7 @@ void launch_pw(const float* A, const float* Wt, const float* bias, float* C, lon
 // b+2 / b+4 apart and 32.6 MiB when they are 8, 16, 32 or 64 apart), each XCD has its own L2, and the column tiles
 // of one row tile read the same input slab.  IDs b and b + 8 - same XCD, dispatched together - are therefore made
 // the column tiles of one row tile, so the second read of the slab is an L2 hit instead of an HBM fetch.
-// BAND (row tiles are bands of one window that overlap their neighbours by halo rows, a single column tile): every
-// XCD takes a contiguous run of row tiles instead, so IDs b and b + 8 are ADJACENT bands and the halo rows they
-// both read are fetched once.
-template <bool BAND>
 __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned tn, unsigned& tile_m, unsigned& tile_n) {
-    if (BAND && tn == 1) {
-        const unsigned per = tiles_m >> 3;
-        tile_n = 0;
-        tile_m = b < per * 8 ? (b & 7) * per + (b >> 3) : b;
-        return;
-    }
     const unsigned full = tiles_m & ~7u;                         // row tiles covered by whole groups of 8
     if (tn > 1 && b < full * tn) {
         tile_n = (b >> 3) % tn;
@@ -823,32 +813,22 @@ __device__ __forceinline__ void tile_of(unsigned b, unsigned tiles_m, unsigned t
     }
 }
 
-// --------------------------------------------------------------------------- fused separable layer, wave-specialised
-// Depthwise inside the pointwise GEMM, laid out for the CU: a workgroup is 8 waves; waves 4-7 are
-// PRODUCERS (stage the f32 input slab, run the depthwise on the VALU, write the split-f16 A tile of
-// stage k+1) and waves 0-3 are CONSUMERS (stage the split-f16 weights, run the MFMAs of stage k).
-// Waves w and w+4 share a SIMD, so every SIMD has one matrix wave and one vector wave and the two
-// pipes overlap inside the workgroup; there is one barrier per 32-channel stage.
-//   stage k   consumers: B[(k+1)&1] <- regs (stage k+1), issue loads of stage k+2, MFMA(A[k&1], B[k&1])
-//             producers: Xs[k&1] <- regs (stage k+2), issue loads of stage k+3, depthwise(Xs[(k+1)&1]) -> A[(k+1)&1]
-// BM = 96 output positions (3 MFMA row tiles; 4 / 1 / 16 whole windows for the 6x4 / 12x8 / 3x2 maps, a
-// band of 6 rows for the 24x16 map), BN = 128 or 256 output channels.  Arithmetic order is that of the
-// unfused kernels: results are bit-identical.
-// (ABL = 1 is the clock-trace instantiation of the developer build, -DBD_KERNEL_TRACE; the shipped library only has 0.)
-// NDW = 3: band tiles of the 24x16 map that OVERLAP: a tile computes 6 rows (BM = 96) but advances 4, so it holds the
-// five rows its two output rows of the next layer's stride-2 depthwise need; that depthwise is applied in the
-// epilogue and only its [2][8][N] result is written (the 24x16 output and the stand-alone depthwise disappear,
-// at the price of computing every other row pair twice).
-// NDW = 2: the tile is not written either; its windows are average-pooled and only [windows][N] goes to out2.
-// NDW = 1: the tile (whole windows) is not written; the NEXT layer's stride-2 depthwise (taps ndw_w, shift
-// ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS and only that result goes to out2.
-// BDIR = 1: the consumers do not stage the weights through LDS at all.  With the 1 x 4 consumer layout every
-// wave owns its own WN output columns, so a weight fragment is used by exactly one wave: each lane loads its
-// MFMA B fragments (16 bytes of hi, 16 of lo per k-step and column tile) straight from global/L2 into a
-// double-buffered register set, one stage ahead.  The engine keeps a copy of the split weights in fragment
-// order, so each of those loads is one contiguous KiB per wave.
-template <int BN, int XPMAX, int ABL, int NDW, int BM, int BDIR, int VS, int KS, int XD, int PWO, bool PLAIN>
-__global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2) void sep_ws_kernel(
+// --------------------------------------------------------------------------- wave-specialised 96 x 256 tile kernel
+// Round 1-2's fused separable kernel, reduced in round 6 to the two forms the tree still runs (every option of its tuning
+// history - weights staged through LDS, register-staged slabs, 64-channel stages, 64-row tiles, band tiles, the pool
+// epilogue, the clock trace - is in git history and DESIGN_HISTORY.md 4.3 / 4.4):
+//   PWO = 1           pointwise only (the 1 x 1 convolution of a layer whose depthwise has been applied elsewhere): the default
+//                     path's pointwise 13, and the wide layers of the one-kernel-per-op path
+//   NDW = 1           depthwise inside the GEMM + the NEXT layer's stride-2 depthwise in the epilogue (layer 6 + depthwise 7
+//                     behind bd_set_fusion separable = 7 / 10; whole windows per tile)
+// A workgroup is 8 waves; waves 4-7 are PRODUCERS (the f32 input slab arrives by LDS-DMA into a ring of three, they run
+// the depthwise on the VALU - or just split the slab - and write the split-f16 A tile of stage k + 1) and waves 0-3 are
+// CONSUMERS (weight fragments straight from the fragment-ordered copy into registers, one stage ahead; the MFMAs of
+// stage k).  Waves w and w + 4 share a SIMD; one barrier per 32-channel stage.  BM = 96 output positions (3 MFMA row
+// tiles: 4 / 1 / 16 whole windows of the 6 x 4 / 12 x 8 / 3 x 2 maps), BN = 256 output channels.  Arithmetic order is that
+// of the unfused kernels: bit-identical.
+template <int NDW, int PWO, bool PLAIN>
+__global__ __launch_bounds__(512, 2) void sep_ws_kernel(
     const float* __restrict__ X, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, const float* __restrict__ pw_u,
     const float* __restrict__ pw_b,
@@ -856,71 +836,37 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
     const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out2,
     unsigned* __restrict__ range_flag) {
     float rmax = 0.0f;                        // largest |activation| this thread has split into f16 halves (producers)
-    static_assert(BM == 96 || BM == 64, "tile height");
-    static_assert(KS == 1 || (KS == 2 && BDIR == 1), "64-channel stages need the weights out of LDS");
-    static_assert(XD == 0 || (BDIR == 1 && KS == 1 && XPMAX % 32 == 0), "slab DMA is issued by the fragment-loading consumers");
-    static_assert(PWO == 0 || (XD == 1 && NDW == 0 && XPMAX == BM), "pointwise-only tiles use the DMA pipeline");
-    static_assert(NDW != 3 || (BM == 96 && XPMAX == 128 && BN == 128), "overlapping band tiles: 6 rows of 16, 128 channels");
-    constexpr int TSTEP = NDW == 3 ? 64 : BM; // rows a tile advances (NDW = 3: 4 of its 6 rows)
-    constexpr int NX = XD ? 3 : 2 * KS;      // slab / tap buffers: a ring of three when the producers fill it by DMA
-    constexpr int WS_FLOATS = XD ? 0 : 320;   // depthwise taps + shift of a 32-channel block (XD: all K at once, in Wall)
+    static_assert((NDW == 0 || NDW == 1) && (PWO == 0 || NDW == 0), "pointwise only, or a fused layer with the next depthwise");
+    constexpr int BN = 256, XPMAX = 96, BM = 96;
+    constexpr int NX = 3;                    // slab buffers: a ring of three, filled by DMA
     constexpr int WN = BN / 4;               // consumer wave tile: BM x WN
     constexpr int TM = BM / 32, TN = WN / 32;
     constexpr int LA = BM / 32;              // depthwise outputs (x4 channels) per producer thread per stage
-    constexpr int XL = (XPMAX + 31) / 32;    // float4 slab loads per producer thread per stage
-    constexpr int BCH = BN * 4 / 256;        // 16-byte weight chunks per consumer thread per stage (each of hi / lo)
     constexpr int XS_FLOATS = (XPMAX + 1) * 32;   // + the zero row
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+    constexpr int A_BYTES = BM * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* const Xs = reinterpret_cast<float*>(smem_raw);             // [2][KS][XS_FLOATS]: a stage is KS blocks of 32 channels
-    float* const Ws = Xs + NX * XS_FLOATS;                             // [NX][10 or 16][32]
-    char* const Ah = reinterpret_cast<char*>(Ws + NX * WS_FLOATS);     // [2][KS][A_BYTES]
-    char* const Al = Ah + 2 * KS * A_BYTES;
-    char* const Bh = Al + 2 * KS * A_BYTES;                            // [2][B_BYTES]
-    float* const Wall = reinterpret_cast<float*>(Bh);                  // XD (weights not in LDS): [10][K] taps + shift
-    char* const Bl = Bh + 2 * B_BYTES;
+    float* const Xs = reinterpret_cast<float*>(smem_raw);             // [3][XS_FLOATS]
+    char* const Ah = reinterpret_cast<char*>(Xs + NX * XS_FLOATS);     // [2][A_BYTES]
+    char* const Al = Ah + 2 * A_BYTES;
+    float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K] depthwise taps + shift of all K channels
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned tile_m, tile_n;
-    tile_of<(BM == 64 || NDW == 3)>(blockIdx.x, (unsigned)((M + TSTEP - 1) / TSTEP), (unsigned)tiles_n, tile_m, tile_n);
-    const long long m0 = (long long)tile_m * TSTEP;
+    tile_of(blockIdx.x, (unsigned)((M + BM - 1) / BM), (unsigned)tiles_n, tile_m, tile_n);
+    const long long m0 = (long long)tile_m * BM;
     const int n0 = (int)tile_n * BN;
-    const int nk = K / (32 * KS);             // stages; >= 4 (launcher)
+    const int nk = K / 32;                    // stages; >= 4 (launcher)
 
-    constexpr size_t TS_PIPE = (size_t)NX * (XPMAX + 1) * 128 + (size_t)NX * WS_FLOATS * 4 + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
-    constexpr size_t TS_TILE = (size_t)BM * (BN + 4) * 4;
-    const size_t ts_pipe_ = TS_PIPE + (XD && !PWO ? (size_t)40 * K : 0);
-    unsigned* const ts = reinterpret_cast<unsigned*>(smem_raw + (ts_pipe_ > TS_TILE ? ts_pipe_ : TS_TILE));
-    int tsn = 0;
-    const unsigned ts_wall0 = ABL == 1 ? (unsigned)wall_clock64() : 0u;
-    (void)ts_wall0;
-#define BD_TS(W)                                                                                          \
-    if constexpr (ABL == 1) {                                                                             \
-        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))                                     \
-            ts[((wave >> 2) * 64 + tsn) * 2 + (W)] = (unsigned)__builtin_readcyclecounter();              \
-        if (W) ++tsn;                                                                                     \
-    }
-#define BD_SYNC() { BD_TS(0) __syncthreads(); BD_TS(1) }
-#define BD_PROBE2(I)                                                                                      \
-    if constexpr (ABL == 1) {                                                                             \
-        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))                                     \
-            ts[200 + (I)] = (unsigned)__builtin_readcyclecounter();                                       \
-    }
-#define BD_PROBE(I)                                                                                       \
-    if constexpr (ABL == 1) {                                                                             \
-        if (blockIdx.x == 0 && lane == 0 && wave == 4 && k == 6)                                          \
-            ts[192 + (I)] = (unsigned)__builtin_readcyclecounter();                                       \
-    }
     // input slab of this tile: rows [x_lo, x_lo + x_cnt) of X (whole windows, or a band of rows plus its halo rows)
     const int P = H * W;
     long long x_lo;
     int x_cnt;
-    if (PWO) {                                // no depthwise: the slab is the tile's own rows
+    if (PWO || P < BM) {                      // no depthwise, or whole windows: the slab is the tile's own rows
         x_lo = m0;
         x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
-    } else if (P >= BM) {
+    } else {
         // (32-bit arithmetic: the launcher guarantees M < 2^31, and 64-bit division is a ~1000-cycle routine)
         const unsigned m0u = (unsigned)m0;
         const long long n = m0u / (unsigned)P;
@@ -930,26 +876,14 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
         const int r1 = oh_b < H ? oh_b + 1 : H;
         x_lo = (n * H + r0) * W;
         x_cnt = (r1 - r0) * W;
-    } else {
-        x_lo = m0;
-        x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
     }
     if (wave >= 4) {
         // ================================================================= producers
-        BD_PROBE2(0)
         const int pt = tid - 256;
         const int lrow = pt >> 3, lc4 = pt & 7;
-        const float* xp[XL];
-#pragma unroll
-        for (int j = 0; j < XL; ++j) {
-            int r = lrow + 32 * j;
-            r = r < x_cnt ? r : x_cnt - 1;
-            xp[j] = X + (size_t)(x_lo + r) * K + lc4 * 4;
-        }
-        int xtap[LA][9];
         int xt[(LA + 2) * 3];
         int a_st[LA];
-        if constexpr (VS) {
+        {
             // a thread owns LA vertically adjacent outputs (same column, rows oh0 .. oh0+LA-1) of 4 channels: the
             // 3 x 3 neighbourhoods overlap, so it reads (LA+2) x 3 slab values instead of LA x 9
             // (W and the groups per window G = P / LA are powers of two - checked by the launcher - so this index
@@ -976,87 +910,39 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
                 }
 #pragma unroll
             for (int i = 0; i < LA; ++i) a_st[i] = swz64(ml0 + i * W, lc4 >> 1) + (lc4 & 1) * 8;
-        } else
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int ml = lrow + 32 * i;
-            long long m = m0 + ml;
-            m = m < M ? m : M - 1;
-            const int q = (int)((unsigned)m % (unsigned)P);
-            const int oh = q / W, ow = q % W;
-            const int xc = (int)(m - x_lo);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ih = oh + kh - 1, iw = ow + kw - 1;
-                    const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
-                    xtap[i][kh * 3 + kw] = (ok ? xc + (kh - 1) * W + (kw - 1) : XPMAX) * 32 + lc4 * 4;
-                }
-            a_st[i] = swz64(ml, lc4 >> 1) + (lc4 & 1) * 8;
         }
         if (pt < 8 * NX) *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
-        const float* wsrc = pt < 72 ? dw_w + (size_t)(pt >> 3) * K + lc4 * 4 : dw_b + lc4 * 4;
 
-        int kch_ = 0;                         // XD: first channel of the block the depthwise works on
+        int kch_ = 0;                         // first channel of the block the depthwise works on
         (void)kch_;
-        v4f rx[KS][XL];
-        v4f rw[KS];
-#pragma unroll
-        for (int u = 0; u < KS; ++u) rw[u] = v4f{0.f, 0.f, 0.f, 0.f};
-#define BD_P_LOAD(KOFF)                                                                                   \
-    {                                                                                                     \
-        _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                  \
-            _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                \
-                rx[u][j] = *reinterpret_cast<const v4f*>(xp[j] + (KOFF) + 32 * u);                        \
-            if (pt < 80) rw[u] = *reinterpret_cast<const v4f*>(wsrc + (KOFF) + 32 * u);                   \
-        }                                                                                                 \
-    }
-#define BD_P_STORE(XB)                                                                                    \
-    {                                                                                                     \
-        _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                  \
-            _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                \
-                if (lrow + 32 * j < XPMAX)                                                                \
-                    *reinterpret_cast<v4f*>(Xs + ((XB) * KS + u) * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = rx[u][j]; \
-            if (pt < 80) *reinterpret_cast<v4f*>(Ws + ((XB) * KS + u) * WS_FLOATS + pt * 4) = rw[u];            \
-        }                                                                                                 \
-    }
 #define BD_P_DW(XB, AB)                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                      \
-        const float* xs_ = Xs + ((XB) * KS + u) * XS_FLOATS;                                              \
-        const float* ws_ = XD ? Wall + kch_ + lc4 * 4 : Ws + ((XB) * KS + u) * WS_FLOATS + lc4 * 4;       \
-        const int wrow_ = XD ? K : 32;                                                                    \
+    {                                                                                                     \
+        const float* xs_ = Xs + (XB) * XS_FLOATS;                                                         \
+        const float* ws_ = Wall + kch_ + lc4 * 4;                                                         \
         v4f wt[9];                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * wrow_); \
-        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * wrow_);                                 \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * K); \
+        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * K);                                     \
         v4f xv[(LA + 2) * 3];                                                                             \
-        if constexpr (VS) {                                                                               \
-            _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t)                                      \
-                xv[t] = *reinterpret_cast<const v4f*>(xs_ + xt[t]);                                       \
-        }                                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t)                                          \
+            xv[t] = *reinterpret_cast<const v4f*>(xs_ + xt[t]);                                           \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
             v4f a4 = bias4;                                                                               \
-            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                               \
-                v4f v;                                                                                    \
-                if constexpr (VS) v = xv[i * 3 + t];                                                      \
-                else v = *reinterpret_cast<const v4f*>(xs_ + xtap[i][t]);                                 \
-                a4 = __builtin_elementwise_fma(v, wt[t], a4);      /* v_pk_fma_f32: two IEEE fmas per issue */ \
-            }                                                                                             \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                 \
+                a4 = __builtin_elementwise_fma(xv[i * 3 + t], wt[t], a4);   /* v_pk_fma_f32: two IEEE fmas per issue */ \
             a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
             rmax = range_of(rmax, a4);                                                                    \
             f16x4 hi, lo;                                                                                 \
             split_f16(a4.x, a4.y, a4.z, a4.w, hi, lo);                                                  \
-            *reinterpret_cast<f16x4*>(Ah + ((AB) * KS + u) * A_BYTES + a_st[i]) = hi;                     \
-            *reinterpret_cast<f16x4*>(Al + ((AB) * KS + u) * A_BYTES + a_st[i]) = lo;                     \
+            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
+            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
         }                                                                                                 \
     }
-        if constexpr (XD) {
+        {
             // ---- slabs and taps by LDS-DMA into a ring of three, three stages ahead.  One global_load_lds_dwordx4
             // moves 8 slab rows (lane l -> row l >> 3, 16-byte chunk l & 7; LDS address = base + 16 l, exactly the
-            // [row][32] layout); the 4 producer waves take the 8-row groups round-robin and a quarter each of the
-            // 16-row tap block (9 taps, the shift, 6 unused).  No VGPRs, no ds_write, and - the point - the slab
-            // has two full stages to arrive: the barrier waits with a COUNTED vmcnt (everything but the newest
-            // stage's DMA), where __syncthreads() would drain to 0 and expose the ~3000-cycle memory latency.
+            // [row][32] layout); the 4 producer waves take the 8-row groups round-robin.  No VGPRs, no ds_write, and -
+            // the point - the slab has two full stages to arrive: the barrier waits with a COUNTED vmcnt (everything but
+            // the newest stage's DMA), where __syncthreads() would drain to 0 and expose the ~3000-cycle memory latency.
             // Producers issue no other vector-memory operation, so the count is exact.
             constexpr int NG = XPMAX / 8, GPW = NG / 4, ND = GPW;
             const int pw = wave - 4;
@@ -1085,12 +971,10 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
     }
 #define BD_P_SYNC(KEEP)                                                                                   \
     {                                                                                                     \
-        BD_TS(0)                                                                                          \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
         __builtin_amdgcn_s_barrier();                                                                     \
         asm volatile("" ::: "memory");                                                                    \
-        BD_TS(1)                                                                                          \
     }
             // PWO: the A tile is the slab itself, split into f16 hi + lo (rows lrow + 32 i, channels 4 lc4 ..)
 #define BD_P_CVT(XB, AB)                                                                                  \
@@ -1105,14 +989,12 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
     }
 #define BD_P_WORK(XB, AB)                                                                                 \
     if constexpr (PWO) { BD_P_CVT(XB, AB) } else { BD_P_DW(XB, AB) }
-            BD_PROBE2(1)
             // first the three slab requests, then the taps + shift of all K channels ([10][K] floats, ordinary loads):
             // the compiler drains vmcnt before the first tap is written to LDS, which also covers the slabs - one
             // memory round trip for the whole prologue instead of two
             if constexpr (NDW == 1) {
                 // the NEXT layer's taps + shift of this tile's BN columns for the epilogue, [10][BN] behind the f32 tile: ten 1 KB
                 // rows by LDS-DMA, issued before the slabs so that the counted waits below cover them
-                static_assert(BN == 256, "one DMA instruction per row of taps");
                 float* const Nw = reinterpret_cast<float*>(smem_raw + (size_t)BM * (BN + 4) * 4);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -1127,7 +1009,6 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             BD_X_DMA(0, 0)
             BD_X_DMA(32, 1)
             BD_X_DMA(64, 2)
-            BD_PROBE2(2)
             if constexpr (!PWO) {
                 // dw_w is [9][K] contiguous, dw_b [K]: as float4 items i < 9 K / 4 resp. the rest, Wall has the same
                 // flat layout.  All loads are issued before the first write (a plain loop made five serial round trips).
@@ -1145,23 +1026,16 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
                     if (i < n_all) *reinterpret_cast<v4f*>(Wall + 4 * (size_t)i) = tw_[j];
                 }
             }
-            BD_PROBE2(3)
             BD_P_SYNC(2 * ND)                 // slab 0 has landed, the taps are written
-            BD_PROBE2(4)
             BD_P_WORK(0, 0)
-            BD_PROBE2(5)
             BD_P_SYNC(ND)                     // A[0] written; slab 1 has landed
             int rs = 1;                       // ring slot of slab k+1
             int k = 0;
             for (; k + 3 < nk; ++k) {         // stage k: slab k+3 replaces slab k (consumed during stage k-1)
                 const int r3 = rs == 0 ? 2 : rs - 1;
-                BD_PROBE(0)
                 BD_X_DMA((k + 3) * 32, r3)
-                BD_PROBE(1)
-                BD_PROBE(2)
                 kch_ = (k + 1) * 32;
                 BD_P_WORK(rs, (k + 1) & 1)
-                BD_PROBE(3)
                 BD_P_SYNC(ND)                 // slab k+2 has landed, slab k+3 stays in flight
                 rs = rs == 2 ? 0 : rs + 1;
             }
@@ -1177,71 +1051,10 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
 #undef BD_P_SYNC
 #undef BD_P_WORK
 #undef BD_P_CVT
-        } else {
-        // prologue: slabs 0 and 1 resident, slab 2 in flight, A[0] computed.  All three loads are issued
-        // before the first store so the workgroup pays the HBM latency once, not three times.
-        {
-            v4f r0[KS][XL], r1[KS][XL];
-            v4f w0[KS], w1[KS];
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                w0[u] = v4f{0.f, 0.f, 0.f, 0.f};
-                w1[u] = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < XL; ++j) r0[u][j] = *reinterpret_cast<const v4f*>(xp[j] + 32 * u);
-                if (pt < 80) w0[u] = *reinterpret_cast<const v4f*>(wsrc + 32 * u);
-            }
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-#pragma unroll
-                for (int j = 0; j < XL; ++j) r1[u][j] = *reinterpret_cast<const v4f*>(xp[j] + 32 * KS + 32 * u);
-                if (pt < 80) w1[u] = *reinterpret_cast<const v4f*>(wsrc + 32 * KS + 32 * u);
-            }
-            BD_P_LOAD(64 * KS)
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-#pragma unroll
-                for (int j = 0; j < XL; ++j)
-                    if (lrow + 32 * j < XPMAX) {
-                        *reinterpret_cast<v4f*>(Xs + u * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = r0[u][j];
-                        *reinterpret_cast<v4f*>(Xs + (KS + u) * XS_FLOATS + (lrow + 32 * j) * 32 + lc4 * 4) = r1[u][j];
-                    }
-                if (pt < 80) {
-                    *reinterpret_cast<v4f*>(Ws + u * WS_FLOATS + pt * 4) = w0[u];
-                    *reinterpret_cast<v4f*>(Ws + (KS + u) * WS_FLOATS + pt * 4) = w1[u];
-                }
-            }
         }
-        BD_SYNC()
-        BD_P_DW(0, 0)
-        BD_SYNC()
-        int k = 0;
-        for (; k + 3 < nk; ++k) {             // stage k: everything in range
-            BD_PROBE(0)
-            BD_P_STORE(k & 1)                 // slab k+2 (loaded during stage k-1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            BD_PROBE(1)
-            BD_P_LOAD((k + 3) * 32 * KS)
-            BD_PROBE(2)
-            BD_P_DW((k + 1) & 1, (k + 1) & 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            BD_PROBE(3)
-            BD_SYNC()
-        }
-        BD_P_STORE(k & 1)                     // k = nk-3: last slab (nk-1) goes in, nothing left to load
-        BD_P_DW((k + 1) & 1, (k + 1) & 1)
-        BD_SYNC()
-        ++k;                                  // k = nk-2: depthwise of the last slab
-        BD_P_DW((k + 1) & 1, (k + 1) & 1)
-        BD_SYNC()
-        BD_SYNC()                      // k = nk-1: consumers' last MFMA stage
-        }
-#undef BD_P_LOAD
-#undef BD_P_STORE
 #undef BD_P_DW
     } else {
     // ===================================================================== consumers
-    BD_PROBE2(8)
     const int wc = wave;                      // column block of this wave
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1252,12 +1065,16 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int frow = lane & 31;
     const int fh = lane >> 5;
-    if constexpr (BDIR) {
+    {
+        // The consumers do not stage the weights through LDS: with the 1 x 4 consumer layout every wave owns its own WN
+        // output columns, so a weight fragment is used by exactly one wave: each lane loads its MFMA B fragments (16 bytes of
+        // hi, 16 of lo per k-step and column tile) straight from global/L2 into a double-buffered register set, one stage
+        // ahead.  Whi / Wlo are the fragment-order copies (SepLayer::pw_fhi / pw_flo): a load is one contiguous KiB per wave.
         // fragment pointers: column tile j -> row n0 + wc*WN + 32 j + frow of W^T, k offset 8 (2 s + fh)
         const _Float16* wph[TN];
         const _Float16* wpl[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {        // Whi / Wlo are the fragment-order copies (SepLayer::pw_fhi / pw_flo)
+        for (int j = 0; j < TN; ++j) {
             const size_t frag = ((size_t)((n0 + wc * WN) / 32 + j) * (K / 16) * 64 + lane) * 8;
             wph[j] = Whi + frag;
             wpl[j] = Wlo + frag;
@@ -1270,7 +1087,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             BL[j][s] = *reinterpret_cast<const f16x8*>(wpl[j] + (KOFF) * 32 + 512 * s);                   \
         }                                                                                                 \
     }
-        // one sub-stage = 2 TM steps (k16 step s x row tile i) of 3 TN MFMAs; the A fragments of step n+1 are requested
+        // one stage = 2 TM steps (k16 step s x row tile i) of 3 TN MFMAs; the A fragments of step n+1 are requested
         // before the MFMAs of step n are issued (reading all TM pairs of a k16 step and then waiting exposed two
         // LDS latencies per stage)
 #define BD_W_AFRAG(AH, AL, BUF, N)                                                                        \
@@ -1294,114 +1111,29 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
             }                                                                                             \
         }                                                                                                 \
     }
-        // sub-stage t = 32 channels; its A block is ring slot t % (2 KS), its fragments b0 (t even) / b1 (t odd);
-        // the workgroup barrier closes a stage, i.e. every KS sub-stages
-        const int T = K / 32;                 // even, >= 4 KS
+        // stage t = 32 channels; its A block is ring slot t & 1, its fragments b0 (t even) / b1 (t odd)
+        const int T = K / 32;                 // even, >= 4
         BD_W_LOAD(b0h, b0l, 0)
         BD_W_LOAD(b1h, b1l, 32)
-        BD_SYNC()
-        BD_SYNC()
+        __syncthreads();
+        __syncthreads();
         int t = 0;
         for (; t + 2 < T; t += 2) {
-            BD_W_MFMA(t & (2 * KS - 1), b0h, b0l)
+            BD_W_MFMA(t & 1, b0h, b0l)
             BD_W_LOAD(b0h, b0l, (t + 2) * 32)
-            if constexpr (KS == 1) BD_SYNC()
-            BD_W_MFMA((t + 1) & (2 * KS - 1), b1h, b1l)
+            __syncthreads();
+            BD_W_MFMA((t + 1) & 1, b1h, b1l)
             BD_W_LOAD(b1h, b1l, (t + 3) * 32)
-            BD_SYNC()
+            __syncthreads();
         }
-        BD_W_MFMA(t & (2 * KS - 1), b0h, b0l)
-        if constexpr (KS == 1) BD_SYNC()
-        BD_W_MFMA((t + 1) & (2 * KS - 1), b1h, b1l)
-        BD_SYNC()
+        BD_W_MFMA(t & 1, b0h, b0l)
+        __syncthreads();
+        BD_W_MFMA((t + 1) & 1, b1h, b1l)
+        __syncthreads();
 #undef BD_W_AFRAG
 #undef BD_W_LOAD
 #undef BD_W_MFMA
-    } else {
-    const _Float16* bph[BCH];
-    const _Float16* bpl[BCH];
-    int b_st[BCH];
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-        const int id = tid + 256 * i;
-        const int row = id >> 2, slot = id & 3;
-        bph[i] = Whi + (size_t)(n0 + row) * K + slot * 8;
-        bpl[i] = Wlo + (size_t)(n0 + row) * K + slot * 8;
-        b_st[i] = swz64(row, slot);
     }
-    v4u rbh[BCH], rbl[BCH];
-#define BD_C_LOAD(KOFF)                                                                                   \
-    {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
-            rbh[i] = *reinterpret_cast<const v4u*>(bph[i] + (KOFF));                                      \
-            rbl[i] = *reinterpret_cast<const v4u*>(bpl[i] + (KOFF));                                      \
-        }                                                                                                 \
-    }
-#define BD_C_STORE(BB)                                                                                    \
-    {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
-            *reinterpret_cast<v4u*>(Bh + (BB) * B_BYTES + b_st[i]) = rbh[i];                              \
-            *reinterpret_cast<v4u*>(Bl + (BB) * B_BYTES + b_st[i]) = rbl[i];                              \
-        }                                                                                                 \
-    }
-#define BD_C_MFMA(BUF)                                                                                    \
-    {                                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
-            f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                         \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                              \
-                const int off = (BUF) * A_BYTES + swz64(i * 32 + frow, 2 * s + fh);                       \
-                ah[i] = *reinterpret_cast<const f16x8*>(Ah + off);                                        \
-                al[i] = *reinterpret_cast<const f16x8*>(Al + off);                                        \
-            }                                                                                             \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
-                const int off = (BUF) * B_BYTES + swz64(wc * WN + j * 32 + frow, 2 * s + fh);             \
-                bh[j] = *reinterpret_cast<const f16x8*>(Bh + off);                                        \
-                bl[j] = *reinterpret_cast<const f16x8*>(Bl + off);                                        \
-            }                                                                                             \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                if constexpr (!PLAIN) {                                                                   \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-                }                                                                                         \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);     \
-            }                                                                                             \
-        }                                                                                                 \
-    }
-    // prologue: weights of stage 0 resident, stage 1 in flight (both loads issued before the store)
-    {
-        v4u h0[BCH], l0[BCH];
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            h0[i] = *reinterpret_cast<const v4u*>(bph[i]);
-            l0[i] = *reinterpret_cast<const v4u*>(bpl[i]);
-        }
-        BD_C_LOAD(32)
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            *reinterpret_cast<v4u*>(Bh + b_st[i]) = h0[i];
-            *reinterpret_cast<v4u*>(Bl + b_st[i]) = l0[i];
-        }
-    }
-    __syncthreads();
-    __syncthreads();
-    int k = 0;
-    for (; k + 2 < nk; ++k) {
-        BD_C_STORE((k + 1) & 1)               // weights of stage k+1 (loaded during stage k-1)
-        BD_C_LOAD((k + 2) * 32)
-        BD_C_MFMA(k & 1)
-        __syncthreads();
-    }
-    BD_C_STORE((k + 1) & 1)                   // k = nk-2
-    BD_C_MFMA(k & 1)
-    __syncthreads();
-    ++k;
-    BD_C_MFMA(k & 1)                          // k = nk-1
-    __syncthreads();
-#undef BD_C_LOAD
-#undef BD_C_STORE
-#undef BD_C_MFMA
-
-    }   // staged weights
 
     // bias + ReLU into an f32 tile in LDS (every stage buffer is dead after the last barrier)
     float* const Ct = reinterpret_cast<float*>(smem_raw);          // [BM][BN + 4]
@@ -1422,54 +1154,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
     }   // consumers
 
     __syncthreads();
-    if constexpr (NDW == 3) {
-        // ---- next layer's depthwise (stride 2, SAME = pad 0 before / 1 after) on rows oh_a .. oh_a+4 of the tile:
-        // output rows oh_a/2 and oh_a/2 + 1, 8 columns, C4 channel quads = 512 tasks, one per thread; taps in
-        // (kh, kw) order with zeros outside the map, exactly as depthwise_kernel does ----
-        const float* Ct = reinterpret_cast<const float*>(smem_raw);
-        constexpr int C4 = BN / 4;
-        static_assert(2 * 8 * C4 == 512, "one task per thread");
-        const unsigned m0u = (unsigned)m0;
-        const unsigned n_ = m0u / (unsigned)P;
-        const int oh_a = (int)(m0u % (unsigned)P) / W;
-        const int c4 = tid % C4, q = tid / C4;
-        const int ow2 = q & 7, ol = q >> 3;
-        v4f acc = *reinterpret_cast<const v4f*>(ndw_b + n0 + c4 * 4);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ihl = 2 * ol + kh, iw = 2 * ow2 + kw;
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (oh_a + ihl < H && iw < W) v = *reinterpret_cast<const v4f*>(Ct + (ihl * W + iw) * (BN + 4) + c4 * 4);
-                const v4f w = *reinterpret_cast<const v4f*>(ndw_w + (size_t)(kh * 3 + kw) * N + n0 + c4 * 4);
-                acc.x = fmaf(v.x, w.x, acc.x);
-                acc.y = fmaf(v.y, w.y, acc.y);
-                acc.z = fmaf(v.z, w.z, acc.z);
-                acc.w = fmaf(v.w, w.w, acc.w);
-            }
-        acc.x = fmaxf(acc.x, 0.0f);
-        acc.y = fmaxf(acc.y, 0.0f);
-        acc.z = fmaxf(acc.z, 0.0f);
-        acc.w = fmaxf(acc.w, 0.0f);
-        const size_t row2 = ((size_t)n_ * (H / 2) + oh_a / 2 + ol) * (W / 2) + ow2;
-        *reinterpret_cast<v4f*>(out2 + row2 * N + n0 + c4 * 4) = acc;
-    } else if constexpr (NDW == 2) {
-        // ---- global average pool (yamnet.py:104): mean over the P positions of every whole window of the tile, summed
-        // in position order and divided by P exactly as pool_head_kernel does; out2 = [windows][N] ----
-        const float* Ct = reinterpret_cast<const float*>(smem_raw);
-        constexpr int C4 = BN / 4;
-        const int wins = BM / P;
-        for (int id = tid; id < wins * C4; id += 512) {
-            const int c4 = id % C4, wl = id / C4;
-            if (m0 + (long long)wl * P >= M) continue;
-            v4f s4 = *reinterpret_cast<const v4f*>(Ct + (wl * P) * (BN + 4) + c4 * 4);
-            for (int q = 1; q < P; ++q) s4 += *reinterpret_cast<const v4f*>(Ct + (wl * P + q) * (BN + 4) + c4 * 4);
-            const float fp = (float)P;
-            s4.x /= fp; s4.y /= fp; s4.z /= fp; s4.w /= fp;
-            *reinterpret_cast<v4f*>(out2 + (size_t)((unsigned)m0 / (unsigned)P + wl) * N + n0 + c4 * 4) = s4;
-        }
-    } else if constexpr (NDW == 1) {
+    if constexpr (NDW == 1) {
         // ---- next layer's depthwise (stride 2) on the tile: windows are whole, so every tap is in LDS ----
         // A wave's 64 lanes are the 64 channel quads of ONE output position (8 waves x 3 positions = the tile's 24), so the
         // position, its padding tests and its row arithmetic are scalar; the two maps this runs on (12 x 8: layer 6, 6 x 4:
@@ -1478,7 +1163,7 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
         // padding branches - was a third of a layer-6 tile's time.)
         const float* Ct = reinterpret_cast<const float*>(smem_raw);
         constexpr int C4 = BN / 4, CTW = BN + 4;
-        static_assert(C4 == 64 && XD == 1, "a wave per output position; taps by the DMA prologue");
+        static_assert(C4 == 64, "a wave per output position");
         const float* Nw = reinterpret_cast<const float*>(smem_raw + (size_t)BM * (BN + 4) * 4);
         const int c4 = tid & 63;
         const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1532,96 +1217,27 @@ __global__ __launch_bounds__(512, ((BM == 64 || NDW == 3) && BN == 128) ? 4 : 2)
         }
     }
     range_report(rmax, range_flag);
-    if constexpr (ABL == 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's stores have left the wave
-        BD_PROBE2(9)
-        __syncthreads();
-        if (blockIdx.x == 0 && tid < 256) reinterpret_cast<unsigned*>(out2)[tid] = ts[tid];
-        if (tid == 0 && blockIdx.x < 1024) {       // wall clock (100 MHz) at block start / end
-            reinterpret_cast<unsigned*>(out2)[256 + 2 * blockIdx.x] = ts_wall0;
-            reinterpret_cast<unsigned*>(out2)[257 + 2 * blockIdx.x] = (unsigned)wall_clock64();
-        }
-    }
 }
 
-template <int BN, int XPMAX, int ABL = 0, int NDW = 0, int BM = 96, int BDIR = 0, int VS = 0, int KS = 1, int XD = 0, int PWO = 0,
-          bool PLAIN = false>
+template <int NDW, int PWO, bool PLAIN = false>
 void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, hipStream_t stream,
                    const SepLayer* next = nullptr) {
-    if constexpr (!PLAIN && ABL == 0) {       // mode 2: the same kernel with one MFMA per product
-        if (L.pw_mode == 2) return launch_sep_ws<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, true>(X, L, out, M, stream, next);
+    if constexpr (!PLAIN) {                   // mode 2: the same kernel with one MFMA per product
+        if (L.pw_mode == 2) return launch_sep_ws<NDW, PWO, true>(X, L, out, M, stream, next);
     }
-    constexpr size_t lds_pipe0 = (XD ? 3u : 2u * KS) * (XPMAX + 1) * 128 + (XD ? 0u : 2u * KS * 1280) + 2u * 2u * (KS * BM + (BDIR ? 0 : BN)) * 64;
-    const size_t lds_pipe = lds_pipe0 + (XD && !PWO ? (size_t)40 * L.cin : 0);   // XD: + taps and shift of all input channels
+    constexpr int BN = 256, XPMAX = 96, BM = 96;
+    constexpr size_t lds_pipe0 = 3u * (XPMAX + 1) * 128 + 2u * 2u * BM * 64;
+    const size_t lds_pipe = lds_pipe0 + (!PWO ? (size_t)40 * L.cin : 0);   // + taps and shift of all input channels
     constexpr size_t lds_tile = (size_t)BM * (BN + 4) * 4 + (NDW == 1 ? 40u * BN : 0u);   // NDW = 1: + the next layer's taps and shift
     const size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
-    constexpr size_t lds_pipe_max = lds_pipe0 + (XD && !PWO ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
+    constexpr size_t lds_pipe_max = lds_pipe0 + (!PWO ? 40u * 1024u : 0u);          // the widest layer has 1024 input channels
     constexpr size_t lds_max = lds_pipe_max > lds_tile ? lds_pipe_max : lds_tile;
     static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>, (int)lds_max + (ABL == 1 ? 1024 : 0), lds_once);
-    constexpr int TSTEP = NDW == 3 ? 64 : BM;
+    allow_dynamic_lds(&sep_ws_kernel<NDW, PWO, PLAIN>, (int)lds_max, lds_once);
     const int tiles_n = L.cout / BN;
-    const long long tiles = ((M + TSTEP - 1) / TSTEP) * tiles_n;
-#ifdef BD_KERNEL_TRACE      // developer build only (-DBD_KERNEL_TRACE): per-barrier clock trace of one workgroup, selected by BD_WS_TRACE
-    if constexpr (ABL == 0 && BDIR == 1 && VS == 1 && NDW == 0 && BM == 96) {
-        // developer aid: BD_WS_TRACE=1 traces a 512-channel fused layer, =2 the 256-channel pointwise of layer 7
-        const char* tr = getenv("BD_WS_TRACE");
-        if (tr && ((tr[0] == '1' && !PWO && L.cin == 512) || (tr[0] == '2' && PWO && L.cin == 256))) {
-            launch_sep_ws<BN, XPMAX, 1, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>(X, L, out, M, stream, next);
-            return;
-        }
-    }
-    if constexpr (ABL == 1) {
-        static unsigned* dbg = nullptr;
-        static int shots = 0;
-        if (!dbg) (void)hipMalloc(&dbg, 1024 + 8192);
-        (void)hipMemsetAsync(dbg, 0, 1024 + 8192, stream);
-        hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds + 1024, stream, X, dw_w_of(L),
-                       dw_b_of(L), static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
-                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_u, L.pw_b,
-                       out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, nullptr, nullptr, reinterpret_cast<float*>(dbg), L.range_flag);
-        (void)hipStreamSynchronize(stream);
-        static unsigned h[256 + 2048];
-        (void)hipMemcpy(h, dbg, 1024 + 8192, hipMemcpyDeviceToHost);
-        if (++shots == (PWO ? 3 : 10)) {
-            for (int role = 0; role < 2; ++role) {
-                fprintf(stderr, "[trace] %s: work / wait cycles per barrier:", role ? "producer" : "consumer");
-                for (int i = 0; i < 24; ++i) {
-                    const unsigned arr = h[(role * 64 + i) * 2], lv = h[(role * 64 + i) * 2 + 1];
-                    const unsigned prev = i ? h[(role * 64 + i - 1) * 2 + 1] : arr;
-                    if (!arr && !lv) break;
-                    fprintf(stderr, " %u/%u", arr - prev, lv - arr);
-                }
-                fprintf(stderr, "\n");
-            }
-            {
-                const int nb = tiles < 1024 ? (int)tiles : 1024;
-                unsigned t0 = ~0u, t1 = 0, dmin = ~0u, dmax = 0, smax = 0;
-                double dsum = 0;
-                for (int b = 0; b < nb; ++b) t0 = h[256 + 2 * b] < t0 ? h[256 + 2 * b] : t0;
-                for (int b = 0; b < nb; ++b) {
-                    const unsigned st = h[256 + 2 * b] - t0, en = h[257 + 2 * b] - t0, d = en - st;
-                    t1 = en > t1 ? en : t1;
-                    dmin = d < dmin ? d : dmin;
-                    dmax = d > dmax ? d : dmax;
-                    smax = st > smax ? st : smax;
-                    dsum += d;
-                }
-                fprintf(stderr, "[trace] %d blocks (10 ns ticks): last start %u, kernel span %u, block duration min %u avg %.0f max %u; block 0: start %u dur %u\n",
-                        nb, smax, t1, dmin, dsum / nb, dmax, h[256] - t0, h[257] - h[256]);
-            }
-            fprintf(stderr, "[trace] producer prologue (cycles since entry): tables %u, DMA issued %u, taps written %u, barrier passed %u, first depthwise done %u; consumer entry offset %d\n",
-                    h[201] - h[200], h[202] - h[200], h[203] - h[200], h[204] - h[200], h[205] - h[200], (int)(h[208] - h[200]));
-            fprintf(stderr, "[trace] consumer wave: entry -> end of its stores %u cycles (block 0 wall clock %u x 10 ns => %.2f GHz)\n",
-                    h[209] - h[208], h[257] - h[256], (h[209] - h[208]) / (10.0 * (h[257] - h[256])));
-            fprintf(stderr, "[trace] producer stage 6: store %u, load-issue %u, depthwise %u\n", h[193] - h[192], h[194] - h[193], h[195] - h[194]);
-        }
-        return;
-    }
-#endif
-    hipLaunchKernelGGL((sep_ws_kernel<BN, XPMAX, ABL, NDW, BM, BDIR, VS, KS, XD, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds, stream, X, dw_w_of(L),
-                       dw_b_of(L), static_cast<const _Float16*>(BDIR ? L.pw_fhi : L.pw_whi),
-                       static_cast<const _Float16*>(BDIR ? L.pw_flo : L.pw_wlo), L.pw_u, L.pw_b,
+    const long long tiles = ((M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL((sep_ws_kernel<NDW, PWO, PLAIN>), dim3((unsigned)tiles), dim3(512), lds, stream, X, dw_w_of(L),
+                       dw_b_of(L), static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b,
                        out, M, L.cout, L.cin, L.h_out, L.w_out, tiles_n, next ? dw_w_of(*next) : nullptr,
                        next ? dw_b_of(*next) : nullptr, out, L.range_flag);
 }
@@ -2495,16 +2111,7 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
     const _Float16* __restrict__ Wfhi, const _Float16* __restrict__ Wflo, const float* __restrict__ pw_u,
     const float* __restrict__ pw_b,
     const float* __restrict__ ndw_w, const float* __restrict__ ndw_b, float* __restrict__ out, int windows,
-    unsigned* __restrict__ range_flag
-#ifdef BD_KERNEL_TRACE
-    , unsigned* __restrict__ dbg          // developer build: clock of block 0's waves 0 and 4 at every barrier (arrive, leave)
-#define BD_L4_TS(SIDE, SLOT)                                                                              \
-    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && k < 32)                                \
-        dbg[((SIDE) * 32 + k) * 2 + (SLOT)] = (unsigned)__builtin_readcyclecounter();
-#else
-#define BD_L4_TS(SIDE, SLOT)
-#endif
-) {
+    unsigned* __restrict__ range_flag) {
     constexpr int H = 24, W = 16, C = 128, K16 = 8, STEPS = H / 2;
     constexpr int COL_B = C * 4;                       // bytes of one map position, f32
     constexpr int ROW_B = (W + 1) * COL_B;             // ring slot of a map row: 16 columns + a zero column
@@ -2622,9 +2229,7 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
                     yb[((m >> 4) * (W + 1) + (m & 15)) * (C + 4)] = fmaxf(fmaf(acc[e], ucol, bcol), 0.0f);
                 }
             }
-            BD_L4_TS(0, 0)
             __syncthreads();
-            BD_L4_TS(0, 1)
         };
         for (int k = 0; k < NT + 2; k += 2) {
             step(std::integral_constant<int, 0>{}, k);
@@ -2711,7 +2316,6 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
                 }
                 s4 = s4 + 1 == STEPS ? 0 : s4 + 1;
             }
-            BD_L4_TS(2, 0)
             if (v < 4 && k >= 2) {
                 // ---- depthwise 5 on layer-4 rows 2 s5, 2 s5 + 1 (tile k - 2, buffer p): finishes output row s5 - 1 (its
                 // kh = 2 row is 2 s5), starts output row s5 (kh = 0, 1); row 11's third row is the zero padding
@@ -2741,9 +2345,7 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
                     ++s5;
                 }
             }
-            BD_L4_TS(1, 0)
             __syncthreads();
-            BD_L4_TS(1, 1)
         };
         for (int k = 0; k < NT + 2; k += 2) {
             step(std::integral_constant<int, 0>{}, k);
@@ -2751,7 +2353,6 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
         }
     }
     range_report(rmax, range_flag);
-#undef BD_L4_TS
 }
 
 template <bool PLAIN = false>
@@ -2763,36 +2364,9 @@ void launch_l4_window(const float* X, const SepLayer& L, const SepLayer& next, f
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&l4_window_kernel<PLAIN>, lds, lds_once);
     const int grid = windows < 256 ? windows : 256;           // one persistent workgroup per CU
-#ifdef BD_KERNEL_TRACE      // developer build only: per-barrier clock trace of workgroup 0 (matrix wave 0, vector wave 4)
-    static unsigned* dbg = nullptr;
-    static int shots = 0;
-    if (!dbg) (void)hipMalloc(&dbg, 1024);
-    (void)hipMemsetAsync(dbg, 0, 1024, stream);
-    hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
-                       static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, dw_w_of(next),
-                       dw_b_of(next), out, windows, L.range_flag, dbg);
-    if (getenv("BD_L4_TRACE") && ++shots == 6) {
-        (void)hipStreamSynchronize(stream);
-        unsigned h[256];
-        (void)hipMemcpy(h, dbg, 1024, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[trace] layer-4 kernel, vector side: cycles of the depthwise-4 part of each step:");
-        for (int k = 1; k < 32 && h[(64 + k) * 2]; ++k) fprintf(stderr, " %u", h[(64 + k) * 2] - h[(32 + k - 1) * 2 + 1]);
-        fprintf(stderr, "\n");
-        for (int side = 0; side < 2; ++side) {
-            fprintf(stderr, "[trace] layer-4 kernel, %s side: work / wait cycles per step:", side ? "vector" : "matrix");
-            for (int k = 1; k < 32; ++k) {
-                const unsigned arr = h[(side * 32 + k) * 2], lv = h[(side * 32 + k) * 2 + 1], prev = h[(side * 32 + k - 1) * 2 + 1];
-                if (!arr && !lv) break;
-                fprintf(stderr, " %u/%u", arr - prev, lv - arr);
-            }
-            fprintf(stderr, "\n");
-        }
-    }
-#else
     hipLaunchKernelGGL((l4_window_kernel<PLAIN>), dim3((unsigned)grid), dim3(768), lds, stream, X, dw_w_of(L), dw_b_of(L),
                        static_cast<const _Float16*>(L.pw_fhi), static_cast<const _Float16*>(L.pw_flo), L.pw_u, L.pw_b, dw_w_of(next),
                        dw_b_of(next), out, windows, L.range_flag);
-#endif
 }
 
 // --------------------------------------------------------------------------- fused stem + layer-3 depthwise
@@ -2804,13 +2378,11 @@ void launch_l4_window(const float* X, const SepLayer& L, const SepLayer& next, f
 //   A  log-mel band -> LDS                       B  conv1 band (7 rows)  -> LDS
 //   C  depthwise 2 (5 rows) -> split-f16 A tile   D  [160][32] x [32][64] on the matrix cores
 //   E  bias + ReLU -> f32 tile P[160][64] in LDS (rows past the map's edge are the zero padding)
-//   F  depthwise 3 (stride 2, SAME = pad 0 before / 1 after) on P -> HBM, [2][16][64] per workgroup
-//   PW3 = true additionally runs layer 3's pointwise convolution on the two depthwise rows, so neither the
-//   layer-2 output nor the layer-3 depthwise output (100 MB per 1024 windows, written and read back) touch HBM:
-//   F' depthwise 3 -> split-f16 A tile [32][64] in LDS   G  [32][64] x [64][128] on the matrix cores (wave w:
+//   F  depthwise 3 (stride 2, SAME = pad 0 before / 1 after) on P -> split-f16 A tile [32][64] in LDS: neither the layer-2
+//   output nor the layer-3 depthwise output (100 MB per 1024 windows) touch HBM   G  [32][64] x [64][128] on the matrix cores (wave w:
 //   columns 32 w .. 32 w + 31, weights as register fragments from the fragment-order copy)   H  bias + ReLU -> HBM
 // Arithmetic order per element equals conv1_kernel / depthwise_kernel / pointwise_f16x3_kernel.
-template <bool PW3, bool PLAIN>
+template <bool PLAIN>
 __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__ logmel, int patch_step,
                                                     const WindowMap map, int w0,
                                                     const float* __restrict__ c1_w, const float* __restrict__ c1_b,
@@ -2821,11 +2393,8 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
                                                     const float* __restrict__ dw3_b, float* __restrict__ out,
                                                     const _Float16* __restrict__ W3fhi, const _Float16* __restrict__ W3flo,
                                                     const float* __restrict__ pw3_u, const float* __restrict__ pw3_b,
-                                                    unsigned* __restrict__ dbg,
                                                     unsigned* __restrict__ range_flag) {
     float rmax = 0.0f;
-#define ST_TS(I) if (dbg && blockIdx.x == 5 && blockIdx.y == 7 && threadIdx.x == 0) dbg[I] = (unsigned)__builtin_readcyclecounter();
-    ST_TS(0)
     constexpr int R2 = 5;                       // layer-2 rows in the tile
     constexpr int C1R = R2 + 2;                 // conv1 rows incl. halo: 7
     constexpr int LMR = 2 * C1R + 1;            // log-mel rows: 15
@@ -2839,7 +2408,7 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
     constexpr int P_BYTES = BM * PW * 4;                            // 43520
     constexpr int OFF_A3H = P_BYTES;                                // PW3: layer-3 A tile, [2 halves of 32 k][32 rows][64 B]
     constexpr int OFF_A3L = OFF_A3H + 2 * 32 * 64;
-    constexpr int LDS_BYTES = PW3 ? OFF_A3L + 2 * 32 * 64 : OFF_AL + BM * 64;   // 51712 / 50944; P aliases from 0
+    constexpr int LDS_BYTES = OFF_A3L + 2 * 32 * 64;               // 51712; P aliases from 0
     static_assert(OFF_AL + BM * 64 <= LDS_BYTES, "pipeline buffers must fit");
     static_assert(LMR * 68 * 4 <= 2 * BM * 64, "log-mel band must fit in the A tile it aliases");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -2877,7 +2446,6 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < 9; ++t) c1wt[t] = *reinterpret_cast<const v4f*>(c1_w + t * 32 + c4 * 4);
     const v4f c1bias = *reinterpret_cast<const v4f*>(c1_b + c4 * 4);
-    ST_TS(1)
     // ---- A: log-mel rows 2 (r0 - 1) .. +14, zero halo columns of the conv1 band ----
     for (int i = tid; i < LMR * 17; i += 256) {
         const int j = i / 17, q = i % 17;
@@ -2891,7 +2459,6 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         *reinterpret_cast<float4*>(&s_c1[r][side ? 33 : 0][c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    ST_TS(2)
 
     // ---- B: conv1 rows r0 - 1 .. r0 + 5 ----
     // (consecutive conv1 rows share a log-mel row: a rolling window reads 45 values instead of 63; the four
@@ -2942,7 +2509,6 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
 #undef BD_STEM3_CONV1
     }
     __syncthreads();
-    ST_TS(3)
 
     // ---- C: depthwise 2 for rows r0 .. r0 + 4 -> split-f16 A tile [160][32] ----
     // (rolling window over the conv1 band: 21 LDS reads instead of 45)
@@ -2981,7 +2547,6 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    ST_TS(4)
 
     v4f d3wt[9];                                // depthwise-3 taps (channels 4 (tid & 15) ..): in flight during D and E
 #pragma unroll
@@ -3016,7 +2581,6 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
     __syncthreads();   // every wave is done with the A tile, the conv band and the log-mel band: P may overwrite them
-    ST_TS(5)
 
     // ---- E: bias + ReLU -> P; layer-2 rows past row 47 are the depthwise's zero padding ----
     {
@@ -3054,19 +2618,15 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    ST_TS(6)
 
-    f16x8 w3h[4], w3l[4];                       // PW3: this lane's layer-3 weight fragments, k16 steps 0..3 (in flight during F)
-    if constexpr (PW3) {
+    f16x8 w3h[4], w3l[4];                       // this lane's layer-3 weight fragments, k16 steps 0..3 (in flight during F)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t f = ((size_t)(wave * 4 + q) * 64 + lane) * 8;
-            w3h[q] = *reinterpret_cast<const f16x8*>(W3fhi + f);
-            w3l[q] = *reinterpret_cast<const f16x8*>(W3flo + f);
-        }
+    for (int q = 0; q < 4; ++q) {
+        const size_t f = ((size_t)(wave * 4 + q) * 64 + lane) * 8;
+        w3h[q] = *reinterpret_cast<const f16x8*>(W3fhi + f);
+        w3l[q] = *reinterpret_cast<const f16x8*>(W3flo + f);
     }
     // ---- F: depthwise 3, stride 2: out[o][ow][c] from P rows 2o + kh, columns 2ow + kw (column 32 = padding) ----
-    float* dst = out + (((size_t)win * 24 + 2 * ob) * 16) * 64;
     // 512 tasks: o (2) x ow (16) x c4 (16); a thread keeps its column and channels in both (o = it).  Every tap is an
     // immediate offset from one pointer; the tap right of column 31 (ow = 15, kw = 2) is read like the others and replaced by
     // the zero padding afterwards (what it reads - the next row, or for the last one the bytes after P - is never used)
@@ -3094,21 +2654,16 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
         acc.y = fmaxf(acc.y, 0.0f);
         acc.z = fmaxf(acc.z, 0.0f);
         acc.w = fmaxf(acc.w, 0.0f);
-        if constexpr (PW3) {
-            rmax = range_of(rmax, acc);
-            f16x4 hi, lo;
-            split_f16(acc.x, acc.y, acc.z, acc.w, hi, lo);
-            const int c = c16 & 7;
-            const int off = (c16 >> 3) * 32 * 64 + swz64(o * 16 + ow, c >> 1) + (c & 1) * 8;
-            *reinterpret_cast<f16x4*>(smem + OFF_A3H + off) = hi;
-            *reinterpret_cast<f16x4*>(smem + OFF_A3L + off) = lo;
-        } else {
-            *reinterpret_cast<v4f*>(dst + ((size_t)o * 16 + ow) * 64 + c16 * 4) = acc;
-        }
+        rmax = range_of(rmax, acc);
+        f16x4 hi, lo;
+        split_f16(acc.x, acc.y, acc.z, acc.w, hi, lo);
+        const int c = c16 & 7;
+        const int off = (c16 >> 3) * 32 * 64 + swz64(o * 16 + ow, c >> 1) + (c & 1) * 8;
+        *reinterpret_cast<f16x4*>(smem + OFF_A3H + off) = hi;
+        *reinterpret_cast<f16x4*>(smem + OFF_A3L + off) = lo;
     }
-    if constexpr (PW3) {
+    {
         __syncthreads();
-        ST_TS(7)
         // ---- G: [32][64] x [64][128], one 32 x 32 tile per wave ----
         f32x16 acc3;
 #pragma unroll
@@ -3124,7 +2679,6 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             }
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3h[q], acc3, 0, 0, 0);
         }
-        ST_TS(8)
         // ---- H: bias + ReLU, [32][128] block of the layer-3 output (rows are consecutive NHWC positions) ----
         float* dst3 = out + (((size_t)win * 24 + 2 * ob) * 16) * 128;
         const int n = 32 * wave + frow;
@@ -3137,10 +2691,8 @@ __global__ __launch_bounds__(256, 3) void stem3_kernel(const float* __restrict__
             dst3[(size_t)m * 128 + n] = fmaxf((r & 1) ? t2.y : t2.x, 0.0f);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ST_TS(9)
     }
     range_report(rmax, range_flag);
-#undef ST_TS
 }
 
 // --------------------------------------------------------------------------- pool + head
@@ -3372,7 +2924,7 @@ bool launch_pointwise_ws(const float* in, float* out, int64_t rows, const SepLay
         return true;
     }
     // (96 x 128 tiles with two workgroups per CU measured the same: 33.1 vs 32.6 us on layer 7)
-    launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1, 1>(in, L, out, rows, stream);
+    launch_sep_ws<0, 1>(in, L, out, rows, stream);
     return true;
 }
 
@@ -3389,12 +2941,11 @@ void launch_pointwise(const float* in, float* out, int64_t rows, const SepLayer&
 // Fused depthwise+pointwise of layer L followed by the stride-2 depthwise of the NEXT layer; `out` receives
 // that depthwise's output [windows][H/2][W/2][L.cout].  Only for whole-window tiles (12x8 and 6x4 maps).
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
-                                    bool band_tiles, hipStream_t stream, bool twelve_waves) {
+                                    hipStream_t stream) {
     const int P = L.h_out * L.w_out;
-    if (L.stride == 1 && next.stride == 2 && windows > 0 && P == 384 && L.w_out == 16 && L.cin >= 128 && L.cin % 64 == 0 &&
-        L.cout == 128 && next.cin == 128) {       // layer 4 + depthwise 5
-        if (L.cin == 128 && !band_tiles) launch_l4_window(in, L, next, out, windows, stream);   // a window per workgroup
-        else launch_sep_ws<128, 128, 0, 3, 96, 1, 1, 1, 1>(in, L, out, (long long)windows * P, stream, &next);   // overlapping 6-row band tiles
+    if (L.stride == 1 && next.stride == 2 && windows > 0 && P == 384 && L.w_out == 16 && L.cin == 128 && L.cout == 128 &&
+        next.cin == 128) {                        // layer 4 + depthwise 5: a window per workgroup
+        launch_l4_window(in, L, next, out, windows, stream);
         return true;
     }
     if (L.stride != 1 || next.stride != 2 || windows <= 0 || L.cin < 128 || L.cout % 256 != 0) return false;
@@ -3403,47 +2954,20 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
     const long long M = (long long)windows * P;
     if (M >= (1LL << 31)) return false;       // the kernel's tile arithmetic is 32-bit
     // 512 output channels (layer 12): all of them in one workgroup of the 12-wave kernel (the layer's depthwise runs once per
-    // row tile, not once per 256-column tile); bd_set_fusion separable = 4 keeps the 8-wave kernel (test hook)
+    // row tile, not once per 256-column tile)
     // (layer 12: 512 -> 512 on the 6 x 4 map - the instantiation carries the map.  Layer 6 is 256 -> 256: one column tile.)
-    if (twelve_waves && L.cout == 512 && L.cin == 512 && L.h_out == 6 && L.w_out == 4) {
+    if (L.cout == 512 && L.cin == 512 && L.h_out == 6 && L.w_out == 4) {
         launch_sep_w12_ndw<512>(in, out, L, next, M, stream);
         return true;
     }
-    launch_sep_ws<256, 96, 0, 1, 96, 1, 1, 1, 1>(in, L, out, M, stream, &next);
+    launch_sep_ws<1, 0>(in, L, out, M, stream, &next);
     return true;
-}
-
-// Fused depthwise+pointwise for a stride-1 layer; returns false if the layer shape is not covered (the caller then
-// runs the depthwise and the pointwise kernel one after the other).  variant: 0 / 1 = by shape (the default path);
-// 9 = always the 8-wave kernel (the 512 -> 512 layers otherwise run its 12-wave form, 12).
-bool launch_separable_fused(const float* in, float* out, int windows, const SepLayer& L, int variant,
-                            hipStream_t stream) {
-    if (L.stride != 1 || windows <= 0 || L.cin < 128 || L.cin % 64 != 0) return false;
-    const long long M = (long long)windows * L.h_out * L.w_out;
-    if (M >= (1LL << 31)) return false;       // the kernels' tile arithmetic is 32-bit
-    const int P = L.h_out * L.w_out;
-    // the wave-specialised kernel's index arithmetic assumes power-of-two widths and rows in threes
-    if ((L.w_out & (L.w_out - 1)) != 0 || !(P > 96 || L.h_out % 3 == 0)) return false;
-    if (variant != 9 && variant != 12 && variant > 1) return false;
-    // measured on MI355X: the 12x8, 6x4 and 3x2 maps run best with 96-row x 256-column tiles; the 24x16 map (K = 128,
-    // only 4 stages per tile) with 64-row x 128-column tiles, small enough for two workgroups per CU
-    if (P == 384 && L.w_out == 16 && L.cout % 128 == 0) {          // layer 4: bands of 4 rows (+ halo rows)
-        launch_sep_ws<128, 96, 0, 0, 64, 1, 1, 1, 1>(in, L, out, M, stream);
-        return true;
-    }
-    if ((P == 96 || P == 24 || P == 6) && L.cout % 256 == 0) {
-        // 512 -> 512 channels: the 12-wave kernel computes the depthwise once per row tile instead of once per 256 columns
-        if (variant != 9 && L.cout == 512 && L.cin <= 512) launch_sep_w12<96>(const_cast<float*>(in), out, &L, 1, M, stream);
-        else launch_sep_ws<256, 96, 0, 0, 96, 1, 1, 1, 1>(in, L, out, M, stream);
-        return true;
-    }
-    return false;
 }
 
 // A run of stride-1 512 -> 512 layers on the 6 x 4 map (layers 8-11) as one launch of the 12-wave kernel.  Returns how many
 // layers of L[0 .. max_layers) it ran (0: none - the caller goes layer by layer); the output of an odd count is in b, of an
 // even count in a.  A layer whose successor is a stride-2 one is left to launch_separable_fused_next_dw.
-int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream, bool on_chip) {
+int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream) {
     int n = 0;
     while (n < 4 && n + 1 < max_layers) {     // n + 1 < max_layers: L[n + 1] exists
         const SepLayer& l = L[n];
@@ -3453,8 +2977,7 @@ int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int
     }
     const long long M = (long long)windows * 24;
     if (n < 2 || windows <= 0 || M >= (1LL << 31)) return 0;
-    // sepchip.hip: only a and the result touch global memory
-    if (!on_chip || !launch_separable_chip(a, (n & 1) ? b : a, windows, L, n, stream)) launch_sep_w12<96>(a, b, L, n, M, stream);
+    launch_sep_w12<96>(a, b, L, n, M, stream);
     return n;
 }
 
@@ -3475,49 +2998,19 @@ int launch_separable_run_next_dw(const float* a, float* b, int windows, const Se
     return launch_separable_chip(a, b, windows, L, n, stream, &L[n]) ? n : 0;
 }
 
-void launch_stem3(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
-                  const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
-    if (windows <= 0) return;
-#define BD_STEM3(PLAIN)                                                                                              \
-    hipLaunchKernelGGL((stem3_kernel<false, PLAIN>), dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,  \
-                       c1_w, c1_b, dw_w_of(L2), dw_b_of(L2), static_cast<const _Float16*>(L2.pw_whi),                     \
-                       static_cast<const _Float16*>(L2.pw_wlo), L2.pw_u, L2.pw_b, dw_w_of(L3), dw_b_of(L3), out, nullptr,   \
-                       nullptr, nullptr, nullptr, nullptr, L2.range_flag)
-    if (L2.pw_mode == 2) BD_STEM3(true);
-    else BD_STEM3(false);
-#undef BD_STEM3
-}
-
 // Layers 1-3 complete: out = [windows][24][16][128], the layer-3 output.
 void launch_stem4(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,
                   const float* c1_b, const SepLayer& L2, const SepLayer& L3, float* out, hipStream_t stream) {
     if (windows <= 0) return;
-#ifdef BD_KERNEL_TRACE      // developer build only: BD_STEM_TRACE=1 prints a phase-level clock trace of one workgroup
-    static unsigned* dbg = nullptr;
-    static int shots = 0;
-    if (!dbg && getenv("BD_STEM_TRACE")) (void)hipMalloc(&dbg, 64);
-#else
-    unsigned* const dbg = nullptr;
-#endif
 #define BD_STEM4(PLAIN)                                                                                              \
-    hipLaunchKernelGGL((stem3_kernel<true, PLAIN>), dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,   \
+    hipLaunchKernelGGL((stem3_kernel<PLAIN>), dim3(12, windows), dim3(256), 0, stream, logmel, patch_step, map, w0,   \
                        c1_w, c1_b, dw_w_of(L2), dw_b_of(L2), static_cast<const _Float16*>(L2.pw_whi),                     \
                        static_cast<const _Float16*>(L2.pw_wlo), L2.pw_u, L2.pw_b, dw_w_of(L3), dw_b_of(L3), out,            \
                        static_cast<const _Float16*>(L3.pw_fhi), static_cast<const _Float16*>(L3.pw_flo), L3.pw_u, L3.pw_b,  \
-                       dbg, L2.range_flag)
+                       L2.range_flag)
     if (L2.pw_mode == 2) BD_STEM4(true);
     else BD_STEM4(false);
 #undef BD_STEM4
-#ifdef BD_KERNEL_TRACE
-    if (dbg) {
-        (void)hipStreamSynchronize(stream);
-        unsigned h[16];
-        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-        if (++shots == 4)
-            fprintf(stderr, "[trace] stem (layers 1-3), one workgroup, cycles: weights+setup %u | A log-mel band %u | B conv1 %u | C depthwise2 %u | D gemm2 %u | E tile %u | F depthwise3 %u | G gemm3 %u | H store %u | total %u\n",
-                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[9] - h[8], h[9] - h[0]);
-    }
-#endif
 }
 
 void launch_pool_head(const float* act, int windows, const float* head_wt, const float* head_b,
@@ -3537,15 +3030,12 @@ void launch_head(const float* pooled, int windows, const float* head_wt, const f
 
 // Last layer (3x2 map): fused depthwise+pointwise with the global average pool in the epilogue;
 // pooled = [windows][L.cout].
-bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream,
-                                 bool twelve_waves) {
+bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream) {
     const int P = L.h_out * L.w_out;
-    if (L.stride != 1 || windows <= 0 || P != 6 || L.w_out != 2 || L.cin < 128 || L.cin % 64 != 0 || L.cout % 256 != 0)
-        return false;
+    if (L.stride != 1 || windows <= 0 || P != 6 || L.w_out != 2 || L.cin != 1024 || L.cout != 1024) return false;
     const long long M = (long long)windows * P;
     if (M >= (1LL << 31)) return false;
-    if (twelve_waves && L.cin == 1024 && L.cout == 1024) launch_sep_w12_pool(in, pooled, L, M, stream);
-    else launch_sep_ws<256, 96, 0, 2, 96, 1, 1, 1, 1>(in, L, pooled, M, stream);
+    launch_sep_w12_pool(in, pooled, L, M, stream);       // two 512-column halves on the 12-wave kernel
     return true;
 }
 

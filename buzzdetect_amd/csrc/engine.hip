@@ -54,23 +54,14 @@ struct bd_engine {
     int group_windows = kDefaultGroup;
     int pointwise_mode = 1;           // 0 = exact f32 MFMA, 1 = split-f16 MFMA, 2 = plain f16 MFMA
     unsigned* d_range_flag = nullptr; // sticky: an activation exceeded the f16 range in mode 1 / 2 (bd_range_flag)
-    bool fuse_stem = true;            // layers 1-2 and the depthwise of layer 3 as one kernel (split-f16 mode only)
-    bool fuse_sep = true;             // stride-1 layers: depthwise inside the pointwise GEMM
-    bool fuse_stem3 = true;           // (always equal to fuse_stem: the layers 1-2 only kernel is gone)
-    bool fuse_stem4 = true;           // ... and layer 3's pointwise convolution (needs fuse_stem3)
-    bool stem_reg = true;             // layers 1-3 with the layer-2 tile handed over in registers (stemreg.hip; bd_set_fusion stem = 3, default)
-    bool fuse_next_dw = true;         // fused layers 6 and 12 also apply the next layer's stride-2 depthwise
-    bool fuse_run = true;             // layers 8-11 (one shape, stride 1) as one launch (bd_set_fusion separable = 3: one each)
-    bool chip_run = true;             // ... with the tiles between its layers kept on the CU (sepchip.hip; separable = 7: the
-                                      // round-3 form that hands them over through global memory)
-    bool chip_ndw = true;             // ... and layer 12 + depthwise 13 behind them in the same launch (separable = 8: layer 12 on
-                                      // its own kernel, as until round 5)
-    bool chip_mid = true;             // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one on-chip launch (sepmid.hip;
-                                      // separable = 10, 8, 7: the four kernels of round 4)
-    bool ndw_w12 = true;              // layer 12 (+ the next layer's depthwise) on the 12-wave kernel (separable = 4: 8-wave)
-    bool pool_w12 = true;             // layer 14 + pool on the 12-wave kernel, two 512-column halves (separable = 5: 8-wave, four quarters)
-    int sep_variant = 0;
-    bool l4_band_tiles = false;       // layer 4 + depthwise 5 as overlapping band tiles of the generic kernel (bd_set_fusion separable = 2)
+    // bd_set_fusion (round 6: per layer group the default, one kernel per op, and at most ONE previous form):
+    bool fuse_stem = true;            // layers 1-3 as one kernel (stem != 0)
+    bool stem_reg = true;             // ... with the layer-2 tile handed over in registers (stemreg.hip; stem = 3, default); 5: through LDS
+    bool fuse_sep = true;             // layers 4-14 on the fused kernels (separable != 0)
+    bool chip_run = true;             // layers 8-12 + depthwise 13 as one on-chip launch (sepchip.hip); separable = 7: the round-3 run
+                                      // of layers 8-11 that hands its tiles over through global memory, layer 12 + depthwise 13 behind it
+    bool chip_mid = true;             // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one on-chip launch (sepmid.hip);
+                                      // separable = 10 (and 7): the four kernels of round 4
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
     // operand scaling of the f16 modes (bd_internal.h, SepLayer): host copies of what the scaled tensors are made from
@@ -933,12 +924,11 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         int64_t last_floats = 0;
         bool stopped = false;
         int first_layer = 0;
-        // ... and the stride-2 depthwise of layer 3 rides along unless a tap wants layer 2's output
-        const bool fuse_stem3 = fuse_stem && e->fuse_stem3 && (stop_stage < 0 || stop_stage >= 4);
-        bool skip_dw3 = false;
+        // (a tap inside layers 1-3 runs them one kernel per op)
+        const bool fuse_stem3 = fuse_stem && (stop_stage < 0 || stop_stage >= 4);
         int skip_dw_layer = -1;      // loop index of a layer whose depthwise the previous kernel already applied
         bool f32_l4 = false;         // exact-f32 mode: layer 4 + the depthwise of layer 5 as one kernel behind the f32 stem
-        if (fuse_stem3 && e->fuse_stem4) {
+        if (fuse_stem3) {
             {
                 Scope sc(e, stream, 5);      // timed in the slot of pointwise 3 (slots 1-4 stay empty)
                 const bool alt = mode != 0 && (stop_stage < 0 || stop_stage == 4);
@@ -955,26 +945,15 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             last_floats = (int64_t)gw * 24 * 16 * 128;
             stopped = stop_stage == 4;
             first_layer = 2;
-        } else if (fuse_stem3) {
-            {
-                Scope sc(e, stream, 4);      // timed in the slot of depthwise 3 (slots 1-3 stay empty)
-                bd::launch_stem3(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_b, stream);
-            }
-            last = buf_b;
-            last_floats = (int64_t)gw * 24 * 16 * 64;
-            first_layer = 1;
-            skip_dw3 = true;
-        } else if (mode == 0 && e->fuse_stem && e->fuse_stem3 && e->fuse_stem4 && !calibrating && stop_stage < 0) {
+        } else if (mode == 0 && e->fuse_stem && !calibrating && stop_stage < 0) {
             // exact-f32 mode: layers 1-3 as one kernel on v_mfma_f32_32x32x2_f32 (sepf32.hip), bit-identical to the five
             // kernels it replaces (the calibration pass and the stage taps keep one kernel per op)
             {
                 Scope sc(e, stream, 5);
-                // (stem 3, the default: the layer-2 tile handed over in registers, stemregf32.hip; 4 / 5: stem3_f32_kernel)
+                // (the layer-2 tile handed over in registers, stemregf32.hip; the form of rounds 4-5 with its tiles through LDS
+                //  - stem3_f32_kernel / l4_f32_kernel, sepf32.hip - was removed in round 6: stem = 5 runs this one too)
                 auto stem_launch = [&]() {
-                    if (e->stem_reg)
-                        bd::launch_stem_reg_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
-                    else
-                        bd::launch_stem_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
+                    bd::launch_stem_reg_f32(lm, step, plan.map, (int)w0, gw, e->conv1_w, e->conv1_b, sep[0], sep[1], buf_a, stream);
                 };
                 stem_launch();
                 BD_REPEAT_EXTRA(5) stem_launch();
@@ -982,7 +961,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             last = buf_a;
             last_floats = (int64_t)gw * 24 * 16 * 128;
             first_layer = 2;
-            f32_l4 = e->fuse_sep && e->fuse_next_dw;
+            f32_l4 = e->fuse_sep;
         } else {
             {
                 Scope sc(e, stream, 1);
@@ -997,11 +976,10 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             const bd::SepLayer& L = sep[l];
             // last layer: the global average pool rides in the fused kernel's epilogue; only [windows][1024] is
             // written (into the caller's embedding buffer if there is one, else into buf_b)
-            if (l == 12 && e->fuse_sep && e->fuse_next_dw && mode != 0 && e->sep_variant <= 1 &&
-                stop_stage < 0 && skip_dw_layer != l) {
+            if (l == 12 && e->fuse_sep && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
                 float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
-                if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream, e->pool_w12)) {
-                    BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream, e->pool_w12);
+                if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream)) {
+                    BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream);
                     if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                     if (logits) {
                         Scope sc(e, stream, 28);
@@ -1016,8 +994,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as ONE launch, a window per tile, tiles on the CU (sepmid.hip):
             // reads the depthwise-5 output the layer-4 kernel left in buf_b, writes the layer-7 output into buf_a; timed in
             // layer 7's pointwise slot
-            if (l == 3 && skip_dw_layer == 3 && e->fuse_sep && e->fuse_next_dw && e->fuse_run && e->chip_run && e->chip_mid &&
-                mode != 0 && e->sep_variant <= 1 && stop_stage < 0 &&
+            if (l == 3 && skip_dw_layer == 3 && e->fuse_sep && e->chip_mid && mode != 0 && stop_stage < 0 &&
                 bd::launch_separable_mid(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream)) {
                 BD_REPEAT_EXTRA(13) (void)bd::launch_separable_mid(buf_b, buf_a, gw, sep[3], sep[4], sep[5], stream);
                 l = 5;
@@ -1028,8 +1005,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // layers 8-12 + the stride-2 depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchip.hip): reads
             // buf_a, writes only [windows][3][2][512] into buf_b; timed in layer 12's pointwise slot
-            if (e->fuse_sep && e->fuse_next_dw && e->fuse_run && e->chip_run && e->chip_ndw && mode != 0 && e->sep_variant <= 1 &&
-                stop_stage < 0 && skip_dw_layer != l) {
+            if (e->fuse_sep && e->chip_run && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
                 const int ran = bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
                 if (ran > 0) {
                     BD_REPEAT_EXTRA(3 + 2 * (l + ran - 1)) (void)bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
@@ -1044,11 +1020,9 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // stride-1 layers: depthwise inside the GEMM (split-f16 mode), unless a test taps the depthwise
             // ... and when the NEXT layer is a stride-2 one, its depthwise is applied in that kernel's epilogue
             // (whole-window tiles): the kernel then writes the next layer's depthwise output into buf_b
-            if (e->fuse_sep && e->fuse_next_dw && mode != 0 && e->sep_variant <= 1 && l + 1 < 13 &&
-                (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
-                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream, e->ndw_w12)) {
-                BD_REPEAT_EXTRA(3 + 2 * l)
-                    (void)bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], e->l4_band_tiles, stream, e->ndw_w12);
+            if (e->fuse_sep && mode != 0 && l + 1 < 13 && (stop_stage < 0 || stop_stage >= 2 * (l + 1) + 2) &&
+                bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], stream)) {
+                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused_next_dw(buf_a, buf_b, gw, L, sep[l + 1], stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
                 skip_dw_layer = l + 1;
                 last = buf_b;
@@ -1069,7 +1043,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // exact-f32 mode: layers 8-12 + the depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchipf32.hip).
             // Its input is the layer-7 output (buf_a) or, when the launch in front applied depthwise 8 in its epilogue, that
             // (buf_b); layer 13 then starts at its 1x1 convolution on the depthwise-13 output in buf_b
-            if (f32_l4 && l == 6 && e->chip_run && e->chip_ndw && stop_stage < 0) {
+            if (f32_l4 && l == 6 && e->chip_run && stop_stage < 0) {
                 const bool dw8_done = skip_dw_layer == 6;
                 float* const src = dw8_done ? buf_b : buf_a;
                 float* const dst = dw8_done ? buf_a : buf_b;
@@ -1090,10 +1064,8 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // exact-f32 mode, behind the f32 stem: layer 4 and layer 5's stride-2 depthwise as one kernel (bit-identical to the
             // three it replaces); layer 5 then starts at its 1x1 convolution
-            // (stem 3, the default: the layer-4 tile handed to depthwise 5 in registers, l4regf32.hip; 4 / 5: l4_f32_kernel)
-            auto l4_launch = [&]() {
-                return e->stem_reg ? bd::launch_l4_reg_f32(buf_a, buf_b, gw, L, sep[3], stream) : bd::launch_l4_f32(buf_a, buf_b, gw, L, sep[3], stream);
-            };
+            // (the layer-4 tile handed to depthwise 5 in registers, l4regf32.hip)
+            auto l4_launch = [&]() { return bd::launch_l4_reg_f32(buf_a, buf_b, gw, L, sep[3], stream); };
             if (f32_l4 && l == 2 && l4_launch()) {
                 BD_REPEAT_EXTRA(3 + 2 * l) (void)l4_launch();
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
@@ -1102,8 +1074,9 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 last_floats = (int64_t)gw * 12 * 8 * 128;
                 continue;
             }
-            if (e->fuse_sep && e->fuse_run && mode != 0 && e->sep_variant <= 1 && stop_stage < 0 && skip_dw_layer != l) {
-                const int ran = bd::launch_separable_run(buf_a, buf_b, gw, &sep[l], 13 - l, stream, e->chip_run);
+            // (separable = 7: layers 8-11 as the round-3 run, which hands its tiles over through global memory)
+            if (e->fuse_sep && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
+                const int ran = bd::launch_separable_run(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
                 if (ran > 0) {
                     l += ran - 1;
                     if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);      // the whole run in its last layer's slot
@@ -1117,20 +1090,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                     continue;
                 }
             }
-            if (e->fuse_sep && mode != 0 && stop_stage != 2 * l + 1 && skip_dw_layer != l &&
-                bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream)) {
-                BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused(buf_a, buf_b, gw, L, e->sep_variant, stream);
-                if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
-                // output landed in buf_b: swap roles so that buf_a is again "latest pointwise output"
-                float* t = buf_a;
-                buf_a = buf_b;
-                buf_b = t;
-                last = buf_a;
-                last_floats = (int64_t)gw * L.h_out * L.w_out * L.cout;
-                if (stop_stage == 2 * l + 2) stopped = true;
-                continue;
-            }
-            if (!(skip_dw3 && l == 1) && skip_dw_layer != l) {
+            if (skip_dw_layer != l) {
                 Scope sc(e, stream, 2 + 2 * l);
                 bd::launch_depthwise(buf_a, buf_b, gw, L, stream);
             }
@@ -1445,29 +1405,18 @@ int bd_set_pointwise_variant(bd_handle h, int32_t layer, int32_t variant) {
 
 int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
-    // (4 - the walk of stemroll.hip - was measured slower in round 5 and removed in round 6: refused like any unknown code)
-    if (stem != 0 && stem != 2 && stem != 3 && stem != 5) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 2, 3 or 5");
-    h->stem_reg = stem == 3;                 // 3 (default): the layer-2 tile handed over in registers (stemreg.hip); 5: through LDS, a
-    if (stem == 5) stem = 3;                 //    workgroup per row block (stem3_kernel<true>, the default until round 5; test hook)
-    // (6 - one exact-f32 kernel per separable layer, sepf32_kernel - was slower than the mode's default set; removed in round 6)
-    if (separable != 0 && separable != 1 && separable != 2 && separable != 3 && separable != 4 && separable != 5 &&
-        separable != 7 && separable != 8 && separable != 9 && separable != 10 && separable != 12)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 2, 3, 4, 5, 7, 8, 9, 10 or 12");
-    h->chip_mid = separable != 7 && separable != 8 && separable != 10;      // 10: as 1 with layers 5-7 on their four kernels
-    if (separable == 10) separable = 1;
-    h->chip_run = separable != 7;            // 7: layers 8-11 as one launch that hands its tiles over through global memory
-    h->chip_ndw = separable != 7 && separable != 8;      // 8: the on-chip run stops at layer 11; layer 12 + depthwise 13 on their own
-    if (separable == 7 || separable == 8) separable = 1;
+    // (removed in round 6 and refused like any unknown code: stem 2 = layers 1-2 + depthwise 3 only, 4 = the walk of stemroll.hip;
+    //  separable 2 = layer 4 as band tiles, 3 = one launch per layer for layers 8-11, 4 / 5 = layer 12 / 14 on the 8-wave kernel,
+    //  6 = one exact-f32 kernel per separable layer, 8 = the on-chip run ending at layer 11, 9 / 12 = plain fused layers)
+    if (stem != 0 && stem != 3 && stem != 5) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 3 or 5");
+    if (separable != 0 && separable != 1 && separable != 7 && separable != 10)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 7 or 10");
     h->fuse_stem = stem != 0;
-    h->fuse_stem3 = stem >= 2;
-    h->fuse_stem4 = stem >= 3;
+    h->stem_reg = stem == 3;                 // 3 (default): the layer-2 tile handed over in registers (stemreg.hip); 5: through LDS, a
+                                             //    workgroup per row block (stem3_kernel, the default until round 5)
     h->fuse_sep = separable != 0;
-    h->fuse_next_dw = separable >= 1 && separable <= 5;
-    h->fuse_run = separable == 1 || separable == 2 || separable == 4 || separable == 5;
-    h->ndw_w12 = separable != 4;
-    h->pool_w12 = separable != 5;
-    h->l4_band_tiles = separable == 2;
-    h->sep_variant = separable > 5 ? separable : 0;
+    h->chip_mid = separable == 1;            // 10 (and 7): layers 5-7 on the four kernels of round 4
+    h->chip_run = separable != 7;            // 7: the round-3 run of layers 8-11 + layer 12 / depthwise 13 on the 12-wave kernel
     return BD_OK;
 }
 

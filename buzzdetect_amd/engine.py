@@ -333,12 +333,11 @@ class HipEngine:
                                                     self._stream().cuda_stream))
 
     def set_fusion(self, stem=True, separable=True) -> None:
-        """Fused stem kernel (True/3 = layers 1-3 complete, 4 / 5 = the same on the walking / the block kernel, 2 = up to layer 3's
-        depthwise, False = off) and fused
-        depthwise+pointwise kernels (True = default path, 2 = the same with layer 4 as band tiles of the generic kernel,
-        3 = the same with one launch per layer for layers 8-11 instead of one for the four, 4 / 5 = the same with layer 12 /
-        layer 14 on the 8-wave kernel, 6 = as True and the exact-f32 mode on sepf32.hip's per-layer kernels, 9 / 12 = plain fused layers on
-        the 8-wave / 12-wave kernel (exact-f32 mode: the f32 stem, then two kernels per layer), False = one kernel per op)."""
+        """``bd_set_fusion``: stem True / 3 = layers 1-3 as one kernel (the default: the layer-2 tile handed over in registers),
+        5 = the same on the kernel of rounds 2-4 (its tile through LDS), False = one kernel per op; separable True / 1 = the
+        default launch set behind the stem (layer 4 + depthwise 5, pointwise 5 - layer 7 on chip, layers 8-12 + depthwise 13
+        on chip, pointwise 13, layer 14 + pool), 10 = layers 5-7 on the four kernels of round 4, 7 = ... and layers 8-11 as the
+        round-3 run through global memory, False = one kernel per op.  Every other code is refused (removed in round 6)."""
         stem_code = 3 if stem is True else int(stem)
         with self._lock:
             _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))

@@ -279,48 +279,32 @@ BD_API int bd_range_flag(bd_handle h, int32_t* flag_host, int32_t reset, void* s
    then, with reset != 0, its clearing.  For pipelines that read results through their own events. */
 BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* stream);
 
-/* Kernel fusion in mode 1 (both on by default; 0 = one kernel per op, the layout the stage taps use):
-   stem == 2       layers 1-2 (conv, depthwise, pointwise) and layer 3's stride-2 depthwise as one kernel that
-                   writes only the depthwise output (the 402 MB layer-2 tensor never reaches HBM); profile slot 4;
-   stem == 3       (default) ... and layer 3's pointwise convolution: layers 1-3 are one kernel that
-                   reads log-mel patches and writes the [24][16][128] layer-3 output; profile slot 5.  Since round 5 the
-                   kernel that hands the layer-2 tile to layer 3's depthwise in REGISTERS and carries the row two tiles share
-                   from tile to tile (stemreg.hip): bit-identical, 129-131 vs 139 us per launch under rocprofv3;
-                   (in the exact-f32 mode stem != 0 selects the same fusion on v_mfma_f32_32x32x2_f32, sepf32.hip);
-   stem == 5       as 3 on the kernel of rounds 2-4 (a workgroup per row block, the layer-2 tile through LDS:
-                   stem3_kernel<true>; test hook);
-   stem == 4       as 3 on the kernel that walks a window top to bottom and carries the rows its steps share in LDS instead of
-                   recomputing them per row block (stemroll.hip): bit-identical, a quarter fewer vector instructions and
-                   slower (155 vs 130 us per launch, round 5) - a measured alternative, not the default;
-   separable != 0  stride-1 layers 4, 6, 8-12, 14: depthwise computed inside the pointwise GEMM, timed
-                   in the layer's pointwise slot.  With 1 (default) layers 4, 6 and 12 also apply the NEXT
-                   layer's stride-2 depthwise in their epilogue, so depthwise 5, 7 and 13 have no launch of
-                   their own, and layer 14 average-pools in its epilogue (layer 4 + depthwise 5 run a window per
-                   workgroup, l4_window_kernel), and layers 8-11 (one shape, windows independent) are ONE launch
-                   in which every workgroup takes its four windows through the four layers with the tiles between the
-                   layers kept on the CU - accumulators -> depthwise in registers -> LDS ring, sepchip.hip - so that only
-                   the run's input and output touch global memory - and layer 12 with the stride-2 depthwise of layer 13 rides
-                   in the same launch (timed in layer 12's pointwise slot); pointwise 5, layer 6, depthwise 7 and pointwise 7
-                   are one on-chip launch too, a window per tile (sepmid.hip; timed in layer 7's pointwise slot).  10: as 1 with
-                   layers 5-7 on the four kernels of round 4 (test hook).  8: as 10 with the first launch ending at layer 11 and
-                   layer 12 + depthwise 13 on the 12-wave kernel (timed in layer 11's / 12's slots; test hook).  7: as 8 with the
-                   round-3 form of the run, which hands the tiles over through global memory (test hook).  2: the same with layer 4 as overlapping band tiles of the generic kernel (test
-                   hook).  3: as 1 with one launch per layer for layers 8-11 (test hook).  4: as 1 with layer 12 on the
-                   8-wave kernel (256-column tiles) instead of the 12-wave one (test hook).  5: as 1 with layer 14 + pool on the
-                   8-wave kernel (four 256-column tiles on all CUs: faster alone, slower in a full pipeline) instead of the
-                   12-wave one (two 512-column halves; test hook).  6: as 1, and in the exact-f32 mode every
-                   separable layer from 6 on is one kernel that keeps the depthwise output in LDS (sepf32.hip; slower on three
-                   streams than the default below - DESIGN.md 4.6).  9 / 12: plain fused layers on the 8-wave kernel only /
-                   with the 12-wave kernel for 512 -> 512 channels (test hook).
-                   The exact-f32 mode (bd_set_pointwise_mode 0) with stem == 3: layers 1-3 are one f32-MFMA kernel; with
-                   separable 1 .. 5 (default 1) layer 4 + depthwise 5 are another and every later 1x1 convolution applies the
-                   NEXT layer's depthwise in its epilogue (no stand-alone depthwise kernel is left; layer 14 average-pools in its) -
-                   except that, as in the default mode, pointwise 5 + layers 6-7 and layers 8-12 + depthwise 13 are one on-chip
-                   launch each (sepmidf32.hip, sepchipf32.hip: f32 stage tiles, products on v_mfma_f32_32x32x2_f32; 10 switches
-                   the first off, 7 / 8 both: test hooks); with 9 / 12 the layers
-                   behind the stem run depthwise_kernel + pointwise_kernel; with stem == 0 or during calibration / stage taps
-                   one kernel per op.
-   Other values are refused (BD_EINVAL).  Fused and unfused paths give bit-identical results. */
+/* Kernel fusion (both on by default; 0 = one kernel per op, the layout the stage taps use and the reference every fused
+   kernel is compared against bit for bit).  Round 6 cut the codes to: per layer group the default, one kernel per op, and at
+   most ONE previous form for same-box A/B; everything else is refused with BD_EINVAL.
+   stem == 3       (default) layers 1-3 as one kernel that reads log-mel patches and writes the [24][16][128] layer-3 output
+                   (the 402 MB layer-2 tensor never reaches HBM); profile slot 5.  The kernel hands the layer-2 tile to layer 3's
+                   depthwise in REGISTERS and carries the rows two tiles share (stemreg.hip; in the exact-f32 mode the same
+                   scheme on v_mfma_f32_32x32x2_f32, stemregf32.hip);
+   stem == 5       as 3 on the kernel of rounds 2-4 (a workgroup per row block, the layer-2 tile through LDS: stem3_kernel;
+                   split-f16 modes only - the exact-f32 mode has the one form);
+   separable == 1  (default) layer 4 + depthwise 5 a window per workgroup (l4_window_kernel); pointwise 5, layer 6, depthwise 7
+                   and pointwise 7 one on-chip launch, a window per tile (sepmid.hip; timed in layer 7's pointwise slot);
+                   layers 8-12 + the stride-2 depthwise of layer 13 ONE launch in which every workgroup takes its four windows
+                   through the five layers with the tiles between the layers kept on the CU - accumulators -> depthwise in
+                   registers -> LDS ring (sepchip.hip; timed in layer 12's pointwise slot); pointwise 13; layer 14 with the
+                   average pool in its epilogue.  The exact-f32 mode (bd_set_pointwise_mode 0): layers 1-3 one f32-MFMA
+                   kernel, layer 4 + depthwise 5 another, the two on-chip launches with f32 stage tiles (sepmidf32.hip,
+                   sepchipf32.hip), layers 13 / 14 as 1x1 kernels with the next depthwise / the pool in their epilogue;
+   separable == 10 as 1 with layers 5-7 on the four kernels of round 4 (pointwise 5, layer 6 + depthwise 7, pointwise 7);
+   separable == 7  as 10, and layers 8-11 as the round-3 run that hands its tiles over through global memory, layer 12 +
+                   depthwise 13 on the 12-wave kernel (exact-f32 mode: a 1x1 kernel per layer with the next depthwise in its
+                   epilogue).
+   Removed in round 6 (BD_EINVAL): stem 2 (layers 1-2 + depthwise 3 only), stem 4 (the walk of stemroll.hip); separable 2
+   (layer 4 as band tiles), 3 (a launch per layer for layers 8-11), 4 / 5 (layer 12 / 14 on the 8-wave kernel), 6 (one
+   exact-f32 kernel per separable layer, sepf32.hip), 8 (the on-chip run ending at layer 11), 9 / 12 (plain fused layers).
+   With stem == 0 or during calibration / stage taps inside a fused group: one kernel per op.  Fused and unfused paths give
+   bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);
 /* whi/wlo: [n][k] f16 halves of wt * scale[n] (wt[n][:] * scale[n] ~= whi[n][:] + wlo[n][:]); unscale[n] = 1 / (scale[n] *
    the scale the caller applied to a): c = relu(fma(acc, unscale[n], bias[n])) */

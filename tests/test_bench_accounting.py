@@ -12,8 +12,8 @@ from oracle import yamnet_oracle as O
 # profile slots that see a launch per batch (engine.hip run_chunks): slot 2 l + 1 is layer l + 2's pointwise / fused kernel
 DEFAULT = [0, 5, 7, 13, 23, 25, 27, 28]                               # layers 5-7 one launch (slot 13), layers 8-12 + depthwise 13 one (slot 23)
 NO_MID = [0, 5, 7, 9, 11, 13, 23, 25, 27, 28]                         # bd_set_fusion separable = 10: layers 5-7 on their four kernels
-RUN_TO_11 = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                  # bd_set_fusion separable = 8 / 7: the run ends at layer 11
-PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # bd_set_fusion separable = 3
+RUN_TO_11 = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                  # bd_set_fusion separable = 7: the run ends at layer 11
+PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # a launch per layer (the bookkeeping must still add up)
 
 
 def _plan(slots, chip=True):

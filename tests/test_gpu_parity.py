@@ -328,8 +328,8 @@ def test_pointwise_gemm_every_tile_variant(mode, m, k, n, gain):
 
 
 def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
-    """Layers 1-2 + depthwise 3 as one kernel (stem mode 2) and layers 1-3 complete (mode 3, default) must reproduce
-    conv1 -> depthwise -> pointwise -> depthwise -> pointwise launch by launch."""
+    """Layers 1-3 as one kernel (mode 3, the default; mode 5, the form of rounds 2-4) must reproduce conv1 -> depthwise ->
+    pointwise -> depthwise -> pointwise launch by launch."""
     x = O.synthetic_audio(HOP * 37 + 1234, seed=55)
     engine.set_pointwise_mode("f16x3")
     try:
@@ -338,9 +338,9 @@ def test_fused_stem_is_bit_identical_to_unfused(engine, weights_bundle):
         plain_pw3 = engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy()
         plain = engine.predict(x, 0.96).numpy()
         plain_half = engine.predict(x, 0.48).numpy()      # overlapping windows read shared log-mel rows
-        for mode in (2, 3, 5):             # 3 (default): the layer-2 tile handed over in registers (stemreg.hip), 5: a workgroup per row
-                                           # block, the tile through LDS (stem3_kernel<true>, the default until round 5); the
-                                           # layer-2 tap uses the block kernel
+        for mode in (3, 5):                # 3 (default): the layer-2 tile handed over in registers (stemreg.hip), 5: a workgroup per row
+                                           # block, the tile through LDS (stem3_kernel, the default until round 5); a tap inside
+                                           # layers 1-3 runs them one kernel per op
             engine.set_fusion(mode, False)
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 2, 38).cpu().numpy(), plain_pw2), mode
             assert np.array_equal(engine.stage_tap(x, HOP, STEP, 4, 38).cpu().numpy(), plain_pw3), mode
@@ -374,8 +374,8 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 2, 3, 4, 5, 9, 12):   # 2: layer 4 as band tiles instead of a window per workgroup; 3: layers 8-11 one launch each;
-                                                 # 4 / 5: layer 12 (+ the next depthwise) / layer 14 (+ pool) on the 8-wave kernel instead of the 12-wave one
+        for variant in (1, 7, 10):               # 1: the default launch set; 10: layers 5-7 on the four kernels of round 4; 7: ... and layers
+                                                 # 8-11 as the round-3 run, layer 12 + depthwise 13 on the 12-wave kernel
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
@@ -393,18 +393,17 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
     """Default path: every workgroup takes its four windows through layers 8-12 AND the stride-2 depthwise of layer 13 in ONE
     launch with the tiles between the layers kept on the CU (sepchip.hip: accumulators -> depthwise in registers -> LDS ring);
     hook 8: that launch ending at layer 11; hook 7: the round-3 form (each
-    layer's output written to the other buffer and read back by the same workgroup).  Against one launch per layer
-    (bd_set_fusion separable = 3): the same bits, in both f16 modes, whole and partial tiles, first and last workgroup."""
+    layer's output written to the other buffer and read back by the same workgroup).  Against one kernel per op
+    (bd_set_fusion 0, 0): the same bits, in both f16 modes, whole and partial tiles, first and last workgroup."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=800 + windows)
     try:
         for mode in ("f16x3", "f16"):
             engine.set_pointwise_mode(mode)
-            engine.set_fusion(True, 3)
+            engine.set_fusion(False, False)
             ref_logits = engine.predict(x, 0.96).numpy()
             ref_emb = engine.embed(x, 0.96).numpy()
-            for hook in (4, 5, 7, 8, 10):        # ... and layer 12 (+ depthwise 13) / layer 14 (+ pool): 8-wave vs 12-wave kernel;
-                                                 # 10: layers 5-7 on their four kernels instead of the on-chip launch (sepmid.hip);
-                                                 # 8 / 7: the on-chip run ending at layer 11 / the round-3 run through global memory
+            for hook in (7, 10):                 # 10: layers 5-7 on their four kernels instead of the on-chip launch (sepmid.hip);
+                                                 # 7: ... and the round-3 run of layers 8-11 through global memory
                 engine.set_fusion(True, hook)
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), (mode, hook)
                 assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), (mode, hook)
@@ -813,9 +812,8 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
     (conv1_kernel, depthwise_kernel, pointwise_kernel): the same chains of IEEE operations, so logits AND embeddings agree
     bit for bit; whole hop and half hop, partial tiles of every layer (windows x positions is not a multiple of the 96 ..
     512-row tiles; windows not a multiple of the 4 / 16 windows of a tile of the depthwise epilogue), two passes (1090).
-    Default: layers 1-3 as stem3_f32_kernel, layer 4 + depthwise 5 as l4_f32_kernel, every later 1x1 convolution with the
-    next layer's depthwise in its epilogue (pointwise_kernel<96, 128, 1, 4, NH, NW, NS>); 9: the stem, then two kernels per
-    layer."""
+    Default: layers 1-3 as stem_reg_f32_kernel, layer 4 + depthwise 5 as l4_reg_f32_kernel, the two on-chip runs, layers 13 / 14
+    as 1x1 kernels with the next depthwise / the pool in their epilogue (pointwise_kernel<96, 128, 1, 4, NH, NW, NS>)."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f32")
     try:
@@ -826,17 +824,14 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
         # the default (round 5): layers 1-3 as stem3_f32_kernel, layer 4 + depthwise 5 as l4_f32_kernel, pointwise 5 + layers 6-7
         # and layers 8-12 + depthwise 13 as the two on-chip runs (sepmidf32.hip, sepchipf32.hip), layers 13 / 14 as 1x1 kernels
         # with the next depthwise / the pool in their epilogue; 10 = without the middle run (the chip run then takes the
-        # depthwise-8 output), 8 / 7 = without either (a 1x1 kernel per layer); 9 = the stem alone, two kernels per layer
-        for code in (True, 10, 8, 7, 9):
+        # depthwise-8 output), 7 = without either (a 1x1 kernel per layer)
+        for code in (True, 10, 7):
             engine.set_fusion(True, code)
             assert np.array_equal(engine.predict(x, 0.96).numpy(), ref), code
             assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), code
             assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half), code
         assert ref.shape == (windows, 13)
-        engine.set_fusion(5, True)                 # the f32 stem of rounds 4-5 (a tile through LDS) under the default launch set
-        assert np.array_equal(engine.predict(x, 0.96).numpy(), ref)
-        assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half)
-        for gone in ((4, 1), (3, 6)):              # removed in round 6 (the walking stem, one f32 kernel per layer): refused
+        for gone in ((4, 1), (2, 1), (3, 6), (3, 2), (3, 3), (3, 4), (3, 5), (3, 8), (3, 9), (3, 12)):   # removed in round 6: refused
             with pytest.raises(Exception):
                 engine.set_fusion(*gone)
     finally:

@@ -47,7 +47,8 @@ def child(seconds):
     from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
     hw = hwmon_of(0)
     eng = HipEngine(device=0)
-    eng.set_fusion(True, 3)            # layers 8-11 one launch each: a repeated launch must not consume its own output
+    eng.set_fusion(False, False)       # one kernel per op: a repeated launch must not consume its own output (the on-chip runs
+                                       # and the round-3 run write into the buffer they read)
     hop, step = hop_samples(0.96), patch_step(0.96)
     x = torch.randn(1024 * hop + 240, device="cuda") * 0.1
     out = torch.empty((1024, 13), device="cuda")
