@@ -149,6 +149,15 @@ __global__ __launch_bounds__(512, 2) void sep_chip_f32_kernel(const ChipChainF32
 
     for (int li = 0; li < nl; ++li) {
         const float* const Wf = chain_f32_ptr<float>(1, li);
+        // B fragments: column tile (wc, wc + 8), super-step S -> ((tile * KS + S) * 64 + lane) * 16 bytes.  The first super-step's
+        // are requested in FRONT of the barrier that publishes the A operand (round 6, as in sepchip.hip)
+        const __amdgpu_buffer_rsrc_t br = F32_RSRC(Wf, K * K * 4);
+        const int btile = wc * (KS * 1024);
+        constexpr int jstep = 8 * KS * 1024;
+#define F32_LB(S, J) __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(br, lane16, btile + (J) * jstep + (S) * 1024, 0))
+        v4f bn[2];                                // the B fragments of the next super-step
+        bn[0] = F32_LB(0, 0);
+        bn[1] = F32_LB(0, 1);
         __syncthreads();                          // stages 0 .. NSLOT - 1 of layer li published
         float zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));      // (a zero the compiler cannot form early: sepchip.hip)
@@ -158,14 +167,6 @@ __global__ __launch_bounds__(512, 2) void sep_chip_f32_kernel(const ChipChainF32
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = zero;
-        // B fragments: column tile (wc, wc + 8), super-step S -> ((tile * KS + S) * 64 + lane) * 16 bytes
-        const __amdgpu_buffer_rsrc_t br = F32_RSRC(Wf, K * K * 4);
-        const int btile = wc * (KS * 1024);
-        constexpr int jstep = 8 * KS * 1024;
-#define F32_LB(S, J) __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(br, lane16, btile + (J) * jstep + (S) * 1024, 0))
-        v4f bn[2];                                // the B fragments of the next super-step
-        bn[0] = F32_LB(0, 0);
-        bn[1] = F32_LB(0, 1);
         // stages FROM .. TO - 1: four super-steps each
 #define F32_STAGES(FROM, TO)                                                                              \
     _Pragma("nounroll") for (int kk = (FROM); kk < (TO); ++kk) {                                          \
