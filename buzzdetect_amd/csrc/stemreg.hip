@@ -375,21 +375,28 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const v2f* const row = kh == 0 ? ev[0] : kh == 1 ? ev[1] : x2;
-                    const v2f shifted = v2f{row[k].y, k < 3 ? row[k < 3 ? k + 1 : 0].x : hal[kh]};
+                    v2f shifted;                         // (second column of pair k, first of pair k + 1 - or column 16): one v_pk_mov_b32
+                    if (k < 3) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(shifted) : "v"(row[k]), "v"(row[k < 3 ? k + 1 : 0]));
+                    else shifted = v2f{row[k].y, hal[kh]};
                     a = __builtin_elementwise_fma(row[k], v2f{d3w[kh * 3], d3w[kh * 3]}, a);
                     a = __builtin_elementwise_fma(row[4 + k], v2f{d3w[kh * 3 + 1], d3w[kh * 3 + 1]}, a);
                     a = __builtin_elementwise_fma(shifted, v2f{d3w[kh * 3 + 2], d3w[kh * 3 + 2]}, a);
                 }
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int j = 2 * k + e;
-                    const float av = fmaxf(e ? a.y : a.x, 0.0f);
-                    unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)av);
-                    asm volatile("v_fma_mixhi_f16 %0, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_max_f32 %1, %1, |%2|"
-                                 : "+v"(pk), "+v"(rmax) : "v"(av));
-                    const int off = wc * (32 * 64) + rg_swz64(fh * 16 + 8 * g + j, frow >> 3) + (frow & 7) * 2;
-                    *reinterpret_cast<unsigned short*>(smem + OFF_A3H + off) = (unsigned short)pk;
-                    *reinterpret_cast<unsigned short*>(smem + OFF_A3L + off) = (unsigned short)(pk >> 16);
+                {
+                    // both hi halves by one v_cvt_pk_f16_f32, lo = f16(v - hi) per value, the range guard's maximum by one v_max3_f32
+                    const float v0 = fmaxf(a.x, 0.0f), v1 = fmaxf(a.y, 0.0f);
+                    unsigned pkh, pkl;
+                    asm volatile("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+                                 "v_fma_mixlo_f16 %1, %0, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                                 "v_fma_mixhi_f16 %1, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                                 "v_max3_f32 %2, %2, %3, %4"
+                                 : "=&v"(pkh), "=&v"(pkl), "+v"(rmax) : "v"(v0), "v"(v1));
+                    const int off0 = wc * (32 * 64) + rg_swz64(fh * 16 + 8 * g + 2 * k, frow >> 3) + (frow & 7) * 2;
+                    const int off1 = wc * (32 * 64) + rg_swz64(fh * 16 + 8 * g + 2 * k + 1, frow >> 3) + (frow & 7) * 2;
+                    *reinterpret_cast<unsigned short*>(smem + OFF_A3H + off0) = (unsigned short)pkh;
+                    *reinterpret_cast<unsigned short*>(smem + OFF_A3H + off1) = (unsigned short)(pkh >> 16);
+                    *reinterpret_cast<unsigned short*>(smem + OFF_A3L + off0) = (unsigned short)pkl;
+                    *reinterpret_cast<unsigned short*>(smem + OFF_A3L + off1) = (unsigned short)(pkl >> 16);
                 }
             }
             // what the tile above takes over: this tile's first row
