@@ -2093,16 +2093,22 @@ void launch_pw_res(const float* X, const SepLayer& L, float* out, int M, hipStre
 //   waves 0-3 (matrix side)  the split-f16 weights of their 32 output channels live in registers for the whole launch
 //                            (64 VGPRs); per step they move two input rows global -> registers -> LDS ring (requested
 //                            four steps ahead), run the 24 MFMAs of the row tile the vector side finished in the previous
-//                            step and write bias + ReLU as f32 into a two-row buffer in LDS
+//                            step, and - round 6 - run depthwise 5 (stride 2) on the tile where it lies, in the
+//                            accumulators: lane (channel, half h) holds columns {0-3, 8-11} + 4 h of the tile's two map
+//                            rows, i.e. everything four of the eight output columns need but the one column behind each
+//                            group of four, which one v_permlane32_swap per group and row brings from the other half.
+//                            One output row per step; its third input row arrives a step later - the partial sums wait in
+//                            registers, the order of the nine FMAs is unchanged.  (Until round 5 the even-column vector
+//                            waves did this from an f32 copy of the tile in LDS: the vector side was the kernel's bound
+//                            - 2 550 of its cycles per step against 1 770 - and without that work the kernel takes 54
+//                            instead of 69 us, gpurun_out/r06/abl_l4_nodw5.log.)
 //   waves 4-11 (vector side) a thread owns four channels (its taps and shift stay in registers) and one map column: the
 //                            3x3 depthwise of the step's two outputs from a register window of 4 x 3 inputs that slides
-//                            down the map (6 LDS reads per step), split into the A tile of the next MFMA step; the waves
-//                            of the even columns also run depthwise 5 (stride 2) on the two-row buffer: one output row
-//                            per step, whose third input row arrives a step later - the partial sum waits in a register,
-//                            the order of the nine FMAs is unchanged.  Two vector waves and one matrix wave per SIMD.
+//                            down the map (6 LDS reads per step), split into the A tile of the next MFMA step.  Two vector
+//                            waves and one matrix wave per SIMD.
 // so nothing is computed twice, layer 4's own output never exists, and the input is read once.  The row tiles of a
-// workgroup's windows form ONE stream (tile T = 12 i + s): step K runs the depthwise of tile K, the MFMAs of tile K - 1
-// and depthwise 5 of tile K - 2, so the pipeline fills once per launch, not once per window; the top and bottom rows of
+// workgroup's windows form ONE stream (tile T = 12 i + s): step K runs the depthwise of tile K and the MFMAs + depthwise 5 of
+// tile K - 1, so the pipeline fills once per launch, not once per window; the top and bottom rows of
 // a window take zeros instead of their neighbours' rows.  One barrier per step.  Arithmetic order per element equals
 // depthwise_kernel / pointwise_f16x3_kernel: bit-identical to the unfused path.
 template <bool PLAIN>
@@ -2118,8 +2124,12 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
     constexpr int RING0 = COL_B;                       // a zero column in front of slot 0 (column -1 of slot 0)
     constexpr int A0 = RING0 + 8 * ROW_B;              // A tile [2 buffers][hi, lo][32 rows][128 f16], chunks XOR-swizzled
     constexpr int A_HALF = 32 * 2 * C, A_BUF = 2 * A_HALF;
-    constexpr int Y0 = A0 + 2 * A_BUF;                 // layer-4 rows [2 buffers][2 rows x 17 columns][132 f32]
-    constexpr int Y_POS = (C + 4) * 4, Y_BUF = 2 * (W + 1) * Y_POS;
+    constexpr int T5 = A0 + 2 * A_BUF;                 // depthwise 5's taps and shift per channel, [128][12] f32 (10 used): as registers
+                                                       // of the matrix waves they would not fit beside the weights (168 per lane)
+    constexpr int O5 = T5 + C * 12 * 4;                // finished depthwise-5 rows on their way out, [2 steps][2 rows][8][128] f32: the
+                                                       // matrix waves wait for their input rows with a counted vmcnt, which a store
+                                                       // of their own in between turns into vmcnt(0) - the vector waves store
+    constexpr int O5_ROW = (W / 2) * C * 4, O5_BUF = 2 * O5_ROW;
     constexpr size_t WIN_IN = (size_t)H * W * C, WIN_OUT = (size_t)STEPS * (W / 2) * C;
     static_assert(A0 % 512 == 0, "fragment addresses are formed by XOR");
     static_assert((2 * STEPS) % 8 == 0 && STEPS % 2 == 0, "ring slots and buffer parities carry over from window to window");
@@ -2131,15 +2141,14 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
     if (b >= windows) return;
     const int NT = STEPS * ((windows - b + G - 1) / G);          // row tiles of this workgroup
 
-    // the zero columns: in front of the ring, column 16 of every ring slot and of every row of the two-row buffers
-    for (int i = tid; i < 9 * 32 + 4 * 33; i += 768) {
-        if (i < 9 * 32) {
-            const int z = i >> 5;
-            *reinterpret_cast<v4f*>(smem + (z == 0 ? 0 : RING0 + (z - 1) * ROW_B + W * COL_B) + (i & 31) * 16) = v4f{0.f, 0.f, 0.f, 0.f};
-        } else {
-            const int j = i - 9 * 32, z = j / 33;      // z: buffer * 2 + row
-            *reinterpret_cast<v4f*>(smem + Y0 + (z >> 1) * Y_BUF + ((z & 1) * (W + 1) + W) * Y_POS + (j % 33) * 16) = v4f{0.f, 0.f, 0.f, 0.f};
-        }
+    // the zero columns: in front of the ring and column 16 of every ring slot
+    for (int i = tid; i < 9 * 32; i += 768) {
+        const int z = i >> 5;
+        *reinterpret_cast<v4f*>(smem + (z == 0 ? 0 : RING0 + (z - 1) * ROW_B + W * COL_B) + (i & 31) * 16) = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = tid; i < 10 * C; i += 768) {          // taps t = 0 .. 8 and the shift (t = 9) of channel c at [c][t]
+        const int t = i / C, c = i - t * C;
+        reinterpret_cast<float*>(smem + T5)[c * 12 + t] = t < 9 ? ndw_w[t * C + c] : ndw_b[c];
     }
     float rmax = 0.0f;
 
@@ -2172,6 +2181,12 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
         }
         const int ncol = 32 * wave + frow;
         const float bcol = pw_b[ncol], ucol = pw_u[ncol];
+        // depthwise 5 of this lane's channel: the four partial sums (output columns 2 fh, 2 fh + 1, 4 + 2 fh, 5 + 2 fh); its taps
+        // and shift are read from LDS when a step needs them
+        const float* const t5 = reinterpret_cast<const float*>(smem + T5) + ncol * 12;
+        float acc5[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float* const o5 = reinterpret_cast<float*>(smem + O5) + (2 * fh) * C + ncol;
+        int s5 = 0;                                    // row tile within its window, of the tile the MFMAs work on
         BD_L4_STORE(rs[0], 0)
         BD_L4_STORE(rs[1], 1)
         BD_L4_LOAD(rs[0], 2)
@@ -2184,7 +2199,6 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
         // fragment (row frow, k 16 q + 8 fh ..) sits in chunk (2 q + fh) ^ (frow & 15) of its row: fr0 ^ (q << 5)
         const unsigned fr0 = pw_lds_addr(smem) + (unsigned)(A0 + frow * 2 * C + ((fh ^ (frow & 15)) << 4));
         // accumulator element e is tile row (e & 3) + 8 (e >> 2) + 4 fh: map row m >> 4, column m & 15
-        float* const yt = reinterpret_cast<float*>(smem + Y0) + 4 * fh * (C + 4) + ncol;
         __syncthreads();
         auto step = [&](auto pc, int k) {
             constexpr int p = decltype(pc)::value;     // k & 1
@@ -2222,16 +2236,62 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
             if (k + 2 < NT) { BD_L4_STORE(rs[p], k + 2) }
             if (k + 4 < NT) BD_L4_LOAD(rs[p], k + 4)
             if (k >= 1 && k <= NT) {
-                float* const yb = yt + (p ^ 1) * (Y_BUF / 4);
+                // ---- bias + ReLU, then depthwise 5 on the tile's two map rows 2 s5, 2 s5 + 1: y[r][0 .. 7] = this lane's columns
+                // {0-3, 8-11} + 4 fh of row r; nb[r][g] = the column behind group g (column 4 / 12 for half 0: the other half's
+                // first of that group; column 8 / 16 for half 1: half 0's first of its second group / the zero padding)
+                float y[2][8], nb[2][2];
+                const v4f t5a = *reinterpret_cast<const v4f*>(t5), t5b = *reinterpret_cast<const v4f*>(t5 + 4), t5c = *reinterpret_cast<const v4f*>(t5 + 8);
+                const float w5[9] = {t5a.x, t5a.y, t5a.z, t5a.w, t5b.x, t5b.y, t5b.z, t5b.w, t5c.x};
+                const float b5 = t5c.y;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = (e & 3) + 8 * (e >> 2);                // + 4 fh, in yt: rows 16 .. 31 are map row 1
-                    yb[((m >> 4) * (W + 1) + (m & 15)) * (C + 4)] = fmaxf(fmaf(acc[e], ucol, bcol), 0.0f);
+                for (int e = 0; e < 16; ++e) y[e >> 3][e & 7] = fmaxf(fmaf(acc[e], ucol, bcol), 0.0f);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    // v_permlane32_swap vdst, src trades lanes 32-63 of vdst against lanes 0-31 of src: with vdst = own column 0
+                    // of the group pair and src = own first column of the second group, half 1 finds half 0's column 8 in vdst
+                    // and half 0 finds half 1's column 4 in src; a second swap brings half 1's column 12 to half 0
+                    float va = y[r][0], wa = y[r][4], vb = y[r][4], wb = 0.0f;
+                    asm("" : "+v"(va), "+v"(wa), "+v"(vb), "+v"(wb));
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, wa), false, false);
+                    const auto s2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, vb), __builtin_bit_cast(unsigned, wb), false, false);
+                    nb[r][0] = __builtin_bit_cast(float, fh ? (unsigned)s1[0] : (unsigned)s1[1]);
+                    nb[r][1] = fh ? 0.0f : __builtin_bit_cast(float, (unsigned)s2[1]);
                 }
+                // output t of this lane (t = 0, 1: group 0, t = 2, 3: group 1) reads, per input row, in[t][0 .. 2]
+#define BD_L4_IN(R, T, KW) ((T) == 0 ? y[R][KW] : (T) == 1 ? ((KW) < 2 ? y[R][2 + (KW)] : nb[R][0]) : (T) == 2 ? y[R][4 + (KW)] : ((KW) < 2 ? y[R][6 + (KW)] : nb[R][1]))
+                float* const orow = o5 + (p ^ 1) * (O5_BUF / 4);        // (tile k - 1: buffer of its parity; row slot 0, the last tile's second row slot 1)
+                if (s5 > 0) {                          // finishes output row s5 - 1: its kh = 2 row is map row 2 s5
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc5[t] = fmaf(BD_L4_IN(0, t, kw), w5[6 + kw], acc5[t]);
+                        orow[((t >> 1) * 4 + (t & 1)) * C] = fmaxf(acc5[t], 0.0f);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {          // starts output row s5: kh = 0, 1
+                    acc5[t] = b5;
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc5[t] = fmaf(BD_L4_IN(kh, t, kw), w5[3 * kh + kw], acc5[t]);
+                }
+                if (s5 == STEPS - 1) {                 // map row 24 is the zero padding (multiplied, as depthwise_kernel does)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc5[t] = fmaf(0.0f, w5[6 + kw], acc5[t]);
+                        orow[((W / 2) + (t >> 1) * 4 + (t & 1)) * C] = fmaxf(acc5[t], 0.0f);
+                    }
+                    s5 = 0;
+                } else {
+                    ++s5;
+                }
+#undef BD_L4_IN
             }
             __syncthreads();
         };
-        for (int k = 0; k < NT + 2; k += 2) {
+        for (int k = 0; k < NT + 2; k += 2) {          // (steps 0 .. NT + 1: NT is even; the last one is idle on both sides)
             step(std::integral_constant<int, 0>{}, k);
             step(std::integral_constant<int, 1>{}, k + 1);
         }
@@ -2239,20 +2299,13 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
 #undef BD_L4_STORE
     } else {
         // ================================================================= vector side
-        // wave v = 0..7, half-wave hi: channels 4 c4 .. of ONE map column - the even columns in waves 0-3 (which also run
-        // depthwise 5: output column = column / 2), the odd ones in waves 4-7, so every SIMD carries one wave of each kind
+        // wave v = 0..7, half-wave hi: channels 4 c4 .. of ONE map column - the even columns in waves 0-3, the odd ones in waves 4-7
         const int v = wave - 4, c4 = lane & 31;
         const int col = v < 4 ? 2 * (2 * v + (lane >> 5)) : 2 * (2 * (v - 4) + (lane >> 5)) + 1;
         v4f w4[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) w4[t] = *reinterpret_cast<const v4f*>(dw_w + t * C + c4 * 4);
         const v4f b4 = *reinterpret_cast<const v4f*>(dw_b + c4 * 4);
-        v4f w5[9], b5 = {0.f, 0.f, 0.f, 0.f};
-        if (v < 4) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) w5[t] = *reinterpret_cast<const v4f*>(ndw_w + t * C + c4 * 4);
-            b5 = *reinterpret_cast<const v4f*>(ndw_b + c4 * 4);
-        }
         // input row r, columns col - 1 .. col + 1 (column -1 is the zero column in front, column 16 the one behind)
         const char* const xin = smem + RING0 + (col - 1) * COL_B + c4 * 16;
         // A tile: row m = 16 rr + col, channels 4 c4 ..: 8 bytes of chunk c4 >> 1
@@ -2262,20 +2315,27 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
             const int m = 16 * rr + col;
             a_st[rr] = A0 + m * 2 * C + (((c4 >> 1) ^ (m & 15)) << 4) + (c4 & 1) * 8;
         }
-        const char* const yin = smem + Y0 + col * Y_POS + c4 * 16;
-        float* const ot = out + (size_t)b * WIN_OUT + (size_t)(col >> 1) * C + c4 * 4;
         v4f xr[4][3];                                  // input rows 2 s - 1 .. 2 s + 2 at [(2 p + i) & 3], three columns
-        v4f acc5 = b5;
-        int s4 = 0;                                    // row tile within its window: of the depthwise-4 stream ..
-        int s5 = 0, i5 = 0;                            // .. and of the depthwise-5 stream (two steps behind), with its window
+        int s4 = 0;                                    // row tile within its window
+        // waves v < 4 also carry the finished depthwise-5 rows from LDS to global memory, 16 bytes per lane: step k stores what the
+        // matrix side finished in step k - 1 with tile k - 2 (row s5 - 1 of window i5; behind a window's last tile also row 11)
+        const int o_lane = (v & 3) * 64 + lane;        // float4 index within a row of [8][128] f32
+        float* const ot = out + (size_t)b * WIN_OUT + (size_t)o_lane * 4;
+        int s5 = 0, i5 = 0;
         __syncthreads();
         auto step = [&](auto pc, int k) {
             constexpr int p = decltype(pc)::value;     // k & 1
-            const char* const yb = yin + p * Y_BUF;
-            v4f y[3];                                  // depthwise 5: the first of its two rows is requested before depthwise 4
             if (v < 4 && k >= 2) {
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) y[kw] = *reinterpret_cast<const v4f*>(yb + kw * Y_POS);
+                const char* const ob = smem + O5 + p * O5_BUF + o_lane * 16;          // (tile k - 2: buffer of its parity)
+                float* const orow = ot + (size_t)i5 * G * WIN_OUT;
+                if (s5 > 0) *reinterpret_cast<v4f*>(orow + (size_t)(s5 - 1) * (W / 2) * C) = *reinterpret_cast<const v4f*>(ob);
+                if (s5 == STEPS - 1) {
+                    *reinterpret_cast<v4f*>(orow + (size_t)s5 * (W / 2) * C) = *reinterpret_cast<const v4f*>(ob + O5_ROW);
+                    s5 = 0;
+                    ++i5;
+                } else {
+                    ++s5;
+                }
             }
             if (k < NT) {
                 // ---- depthwise 4 of map rows 2 s4, 2 s4 + 1 -> A tile buffer p (ring slots continue across windows)
@@ -2316,35 +2376,6 @@ __global__ __launch_bounds__(768) void l4_window_kernel(
                 }
                 s4 = s4 + 1 == STEPS ? 0 : s4 + 1;
             }
-            if (v < 4 && k >= 2) {
-                // ---- depthwise 5 on layer-4 rows 2 s5, 2 s5 + 1 (tile k - 2, buffer p): finishes output row s5 - 1 (its
-                // kh = 2 row is 2 s5), starts output row s5 (kh = 0, 1); row 11's third row is the zero padding
-                float* const orow = ot + (size_t)i5 * G * WIN_OUT;
-                if (s5 > 0) {
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[kw], w5[6 + kw], acc5);
-                    acc5.x = fmaxf(acc5.x, 0.0f); acc5.y = fmaxf(acc5.y, 0.0f); acc5.z = fmaxf(acc5.z, 0.0f); acc5.w = fmaxf(acc5.w, 0.0f);
-                    *reinterpret_cast<v4f*>(orow + (size_t)(s5 - 1) * (W / 2) * C) = acc5;
-                }
-                acc5 = b5;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[kw], w5[kw], acc5);
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) y[kw] = *reinterpret_cast<const v4f*>(yb + ((W + 1) + kw) * Y_POS);
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(y[kw], w5[3 + kw], acc5);
-                if (s5 == STEPS - 1) {
-                    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) acc5 = __builtin_elementwise_fma(zero, w5[6 + kw], acc5);
-                    acc5.x = fmaxf(acc5.x, 0.0f); acc5.y = fmaxf(acc5.y, 0.0f); acc5.z = fmaxf(acc5.z, 0.0f); acc5.w = fmaxf(acc5.w, 0.0f);
-                    *reinterpret_cast<v4f*>(orow + (size_t)s5 * (W / 2) * C) = acc5;
-                    s5 = 0;
-                    ++i5;
-                } else {
-                    ++s5;
-                }
-            }
             __syncthreads();
         };
         for (int k = 0; k < NT + 2; k += 2) {
@@ -2360,7 +2391,7 @@ void launch_l4_window(const float* X, const SepLayer& L, const SepLayer& next, f
     if constexpr (!PLAIN) {
         if (L.pw_mode == 2) return launch_l4_window<true>(X, L, next, out, windows, stream);
     }
-    constexpr int lds = 512 + 8 * 17 * 512 + 2 * 2 * 32 * 256 + 2 * 2 * 17 * 132 * 4;
+    constexpr int lds = 512 + 8 * 17 * 512 + 2 * 2 * 32 * 256 + 128 * 12 * 4 + 2 * 2 * 8 * 128 * 4;
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&l4_window_kernel<PLAIN>, lds, lds_once);
     const int grid = windows < 256 ? windows : 256;           // one persistent workgroup per CU
