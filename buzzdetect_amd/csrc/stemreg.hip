@@ -63,16 +63,21 @@ __device__ __forceinline__ void rg_split(v4f a, f16x4& hi, f16x4& lo) {
     lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
 }
 
-// ---- LDS map (bytes): 53 504, three workgroups per CU ----
+// ---- LDS map (bytes): 53 248, three workgroups per CU ----
 constexpr int OFF_C1 = 0;                        // conv1 band [6][34][32] f32
 constexpr int OFF_AH = 6 * 34 * 32 * 4;          // 26112: split-f16 A tile of layer 2 [128 rows][64 B]; the log-mel band [13][68] f32 before it
 constexpr int OFF_AL = OFF_AH + 128 * 64;        // 34304
 constexpr int OFF_A3H = OFF_AL + 128 * 64;       // 42496: split-f16 A tile of layer 3, [2 halves of 32 k][32 rows][64 B]
 constexpr int OFF_A3L = OFF_A3H + 2 * 32 * 64;   // 46592
-constexpr int OFF_HALO = OFF_A3L + 2 * 32 * 64;  // 50688: column 16 of the three input rows of a half, [column tile][half][3][32 channels] f32
-constexpr int OFF_D2W = OFF_HALO + 2 * 2 * 3 * 32 * 4;   // 52224: taps and shift of depthwise 2, [10][32] f32, for the whole run (as registers
-                                                         // requested a phase ahead they were the peak of the register pressure)
-constexpr int kRegLds = OFF_D2W + 10 * 32 * 4;           // 53504
+constexpr int OFF_HALO = OFF_C1 + (2 * 34 + 1) * 32 * 4;   // column 16 of the three input rows of a half, [column tile][half][3][32 channels] f32: in
+                                                 // conv band row 2 (from its column 0 on, which phase B rewrites - not the zero column -1), dead from
+                                                 // the third barrier of a tile to the next tile's phase B
+constexpr int OFF_D2W = OFF_A3L + 2 * 32 * 64;   // 50688: taps and shift of depthwise 2, [10][32] f32, for the whole run (as registers
+                                                 // requested a phase ahead they were the peak of the register pressure)
+constexpr int OFF_C1W = OFF_D2W + 10 * 32 * 4;   // 51968: taps and shift of conv1, [10][32] f32, for the whole run: as global loads at the top
+                                                 // of a tile they stood right behind the previous tile's output stores, and a wave can
+                                                 // only wait for a load behind stores with vmcnt(0) - the stores' whole round trip
+constexpr int kRegLds = OFF_C1W + 10 * 32 * 4;   // 53248
 
 template <bool PLAIN>
 __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restrict__ logmel, int patch_step, const WindowMap map, int w0,
@@ -91,6 +96,7 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
     char* const s_al = smem + OFF_AL;
     float* const s_halo = reinterpret_cast<float*>(smem + OFF_HALO);
     const float* const s_d2 = reinterpret_cast<const float*>(smem + OFF_D2W);
+    const float* const s_c1w = reinterpret_cast<const float*>(smem + OFF_C1W);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, col = tid >> 3;               // vector phases: channel quad, map column
@@ -152,8 +158,8 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
         constexpr int C1R = ROWS + 2;
         v4f c1wt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) c1wt[t] = *(gptr4)(pc1w + t * 32 + c4 * 4);
-        const v4f c1bias = *(gptr4)(pc1b + c4 * 4);
+        for (int t = 0; t < 9; ++t) c1wt[t] = *reinterpret_cast<const v4f*>(s_c1w + t * 32 + c4 * 4);
+        const v4f c1bias = *reinterpret_cast<const v4f*>(s_c1w + 9 * 32 + c4 * 4);
         // (phase A - the tile's log-mel band into LDS - has happened a tile earlier: band_to_lds below)
         // ---- B: conv1 rows r_first - 1 .. r_first + 4 (conv1_kernel's chain: taps in (kh, kw) order, a tap row past the patch
         //         skipped; a conv1 row outside the map is the depthwise's zero padding) ----
@@ -286,9 +292,10 @@ __global__ __launch_bounds__(256, 3) void stem_reg_kernel(const float* __restric
 
     v2f carry[8];                                          // half 0: row 0 of the tile below (= row 4 of this one), in ev's pairs
     if (t_begin < t_end) {
-        if (tid >= 128 && tid < 128 + 80) {                // depthwise 2's taps [9][32] and shift [32] into LDS for the whole run
-            const int row = (tid - 128) >> 3, cc = tid & 7;
-            *reinterpret_cast<v4f*>(smem + OFF_D2W + (row * 32 + cc * 4) * 4) = row < 9 ? *(gptr4)(pd2w + row * 32 + cc * 4) : *(gptr4)(pd2b + cc * 4);
+        if (tid >= 96 && tid < 96 + 160) {                 // conv1's and depthwise 2's taps [9][32] and shift [32] into LDS for the whole run
+            const int which = (tid - 96) / 80, row = ((tid - 96) % 80) >> 3, cc = tid & 7;
+            gptr w = which ? pd2w : pc1w, bs = which ? pd2b : pc1b;
+            *reinterpret_cast<v4f*>(smem + (which ? OFF_D2W : OFF_C1W) + (row * 32 + cc * 4) * 4) = row < 9 ? *(gptr4)(w + row * 32 + cc * 4) : *(gptr4)(bs + cc * 4);
         }
         if (tid < 6 * 2 * 8) {                             // columns -1 and 32 of the conv1 band: zero for the whole run
             const int r = tid / 16, side = (tid >> 3) & 1, cc = tid & 7;
