@@ -3,31 +3,22 @@
 // All activations are NHWC float32, exactly the reference's layout.
 // TF "SAME" for an even extent with stride 2 pads 0 before / 1 after; stride 1 pads 1 / 1.
 //
-// Default path (7 launches per pass since round 5): stem_reg_kernel (stemreg.hip: layers 1-3),
-// l4_window_kernel (here), sep_mid_kernel (sepmid.hip: pointwise 5 + layers 6-7), sep_chip_kernel (sepchip.hip: layers 8-12 +
-// depthwise 13), sep_ws_kernel (here: the plain 1x1 of layer 13), sep_w12_kernel<NDW = 2> (here: layer 14 + pool),
-// pool_head_kernel<1>.  The kernels of this file:
-//   stem3_kernel<true>   layers 1-3: conv 3x3 s2 -> dw 3x3 -> pw 32->64 -> dw 3x3 s2 -> pw 64->128, one kernel, a workgroup per
-//                        row block (the default of rounds 2-4; bd_set_fusion stem = 5)
-//   l4_window_kernel     layer 4 (depthwise + pointwise 128 -> 128 on the 24 x 16 map) + depthwise 5: persistent
-//                        workgroups that walk whole windows two map rows at a time, weights in registers
-//   pw_res_kernel        the 1x1 convolutions of layers 5 and 7 (K = 128 / 256): persistent, weights in registers (round 4's
-//                        path; bd_set_fusion separable = 10)
-//   sep_ws_kernel        fused depthwise + pointwise of a stride-1 layer, wave-specialised (4 producer + 4 MFMA
-//                        waves, slab ring by LDS-DMA, split-f16 MFMA); with PWO the plain 1x1 convolution of layer 13;
-//                        NDW = 1: next layer's stride-2 depthwise in the epilogue (layer 6 of round 4's path; NDW = 3: layer 4 as
-//                        overlapping band tiles, the test hook bd_set_fusion(.., 2)); NDW = 2: global average pool in
-//                        the epilogue (layer 14 on the test-hook path)
-//   sep_w12_kernel       the same with 8 MFMA waves and 512 columns per workgroup (the depthwise once per row tile): NDW = 2:
-//                        layer 14 + average pool, two 512-column halves per row tile (default); layers 8-11 as ONE launch
-//                        through global memory and NDW = 1: layer 12 + depthwise 13 (rounds 3-4; bd_set_fusion separable = 7 / 8)
+// Default path (7 launches per pass): stem_reg_kernel (stemreg.hip: layers 1-3), l4_window_kernel (here),
+// sep_mid_kernel (sepmid.hip: pointwise 5 + layers 6-7), sep_chip_kernel (sepchip.hip: layers 8-12 + depthwise 13),
+// sep_ws_kernel<0, 1> (here: the plain 1x1 of layer 13), sep_w12_kernel<NDW = 2> (here: layer 14 + pool), pool_head_kernel<1>.
+// The kernels of this file:
+//   stem3_kernel         layers 1-3 as one kernel, a workgroup per row block (the default of rounds 2-4; bd_set_fusion stem = 5)
+//   l4_window_kernel     layer 4 + depthwise 5: persistent workgroups walk whole windows two map rows at a time
+//   pw_res_kernel        the 1x1 convolutions of layers 5 and 7: persistent, weights in registers (separable = 10; one kernel per op)
+//   sep_ws_kernel        wave-specialised 96 x 256 tiles (4 producer + 4 MFMA waves, slab ring by LDS-DMA): PWO = the plain 1x1
+//                        convolution of the wide layers; NDW = 1 = layer 6 + depthwise 7 (separable = 7 / 10)
+//   sep_w12_kernel       the same with 8 MFMA waves and 512 columns per workgroup: NDW = 2 = layer 14 + average pool (default);
+//                        layers 8-11 as ONE launch through global memory, NDW = 1 = layer 12 + depthwise 13 (separable = 7)
 //   pool_head_kernel<1>  Dense(1024 -> n_classes) on the pooled embeddings
-// Reference kernels, one per op (the fused ones are tested bit for bit against them; they are also the exact-f32 mode):
-//   conv1_kernel, depthwise_kernel, pointwise_f16x3_kernel (split-f16), pointwise_kernel (exact-f32 MFMA),
-//   stem3_kernel<false> (layers 1-2 + depthwise 3, for the stage taps), pool_head_kernel<6>
-// Workgroup -> tile mapping is XCD-aware (tile_of).  Clock traces of single workgroups exist only in a developer build
-// (-DBD_KERNEL_TRACE, then selected by BD_WS_TRACE / BD_STEM_TRACE / BD_L4_TRACE); the shipped launch path reads no environment and
-// keeps no mutable state besides the once-per-device dynamic-LDS attribute flags.
+// Reference kernels, one per op (the fused ones are tested bit for bit against them; they are also the exact-f32 mode's tail):
+//   conv1_kernel, depthwise_kernel, pointwise_f16x3_kernel (split-f16), pointwise_kernel (exact-f32 MFMA), pool_head_kernel<6>
+// Workgroup -> tile mapping is XCD-aware (tile_of).  The launch path reads no environment and keeps no mutable state besides
+// the once-per-device dynamic-LDS attribute flags.
 #include "bd_internal.h"
 #include <mutex>
 #include <type_traits>
@@ -1792,46 +1783,6 @@ void launch_sep_w12_ndw(const float* in, float* out, const SepLayer& L, const Se
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&sep_w12_kernel<96, false, PLAIN, KT, 1>, (int)lds, lds_once);
     const long long tiles = (M + 95) / 96;
-#ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=5: wall clock (10 ns ticks) of the phases of every workgroup
-    const char* tr = getenv("BD_WS_TRACE");
-    if (tr && tr[0] == '5') {
-        constexpr size_t kDbgBytes = 512 + 1024 * 8 * 4;
-        static unsigned* dbg = nullptr;
-        static int shots = 0;
-        if (!dbg) {
-            (void)hipMalloc(&dbg, kDbgBytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<96, true, PLAIN, KT, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        }
-        (void)hipMemsetAsync(dbg, 0, kDbgBytes, stream);
-        hipLaunchKernelGGL((sep_w12_kernel<96, true, PLAIN, KT, 1>), dim3((unsigned)tiles), dim3(768), lds, stream,
-                           const_cast<float*>(in), out, ch, 1, M, L.cin, L.h_out, L.w_out, dbg, L.range_flag, dw_w_of(next),
-                           dw_b_of(next));
-        (void)hipStreamSynchronize(stream);
-        static unsigned h[kDbgBytes / 4];
-        (void)hipMemcpy(h, dbg, kDbgBytes, hipMemcpyDeviceToHost);
-        if (++shots == 6) {
-            const int nb = tiles < 1024 ? (int)tiles : 1024;
-            unsigned t0 = ~0u;
-            for (int bl = 0; bl < nb; ++bl) t0 = h[128 + bl * 8] < t0 ? h[128 + bl * 8] : t0;
-            static const char* names[8] = {"start", "stage loop done", "half 0 parked", "barrier", "depthwise 0 done", "half 1 parked + barrier",
-                                           "depthwise 1 done", "stores complete"};
-            fprintf(stderr, "[trace] 12-wave kernel with next-layer depthwise, K = %d, %d workgroups; x 10 ns since the first start (min / avg / max):\n", KT, nb);
-            for (int i = 0; i < 8; ++i) {
-                unsigned lo = ~0u, hi = 0;
-                double sum = 0;
-                for (int bl = 0; bl < nb; ++bl) {
-                    const unsigned t = h[128 + bl * 8 + i] - t0;
-                    lo = t < lo ? t : lo;
-                    hi = t > hi ? t : hi;
-                    sum += t;
-                }
-                fprintf(stderr, "[trace]   %-26s %6u %8.0f %6u\n", names[i], lo, sum / nb, hi);
-            }
-        }
-        return;
-    }
-#endif
     hipLaunchKernelGGL((sep_w12_kernel<96, false, PLAIN, KT, 1>), dim3((unsigned)tiles), dim3(768), lds, stream,
                        const_cast<float*>(in), out, ch, 1, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag, dw_w_of(next),
                        dw_b_of(next));
