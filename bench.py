@@ -47,8 +47,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f
 PEAK_F16_MFMA_TFLOPS = 2500.0                    # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (the 2:1-sparse figure is never used)
 PEAK_SPLIT_F16_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # ... / 3 MFMAs per f32-accurate product
 PEAK_HBM_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E spec
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
-PMC_TRAFFIC_STRICT_FILE = os.path.join("profiles", "r05_pmc_traffic_strict_f32.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
+PMC_TRAFFIC_STRICT_FILE = os.path.join("profiles", "r06_pmc_traffic_strict_f32.json")
 # What the board's 1400 W limit leaves of the paper peak: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, constant operands,
 # held for 3 s, settles at 1987 TFLOP/s (2.0 GHz, 1345 W) - tools/ubench_power.hip, profiles/r03_ubench_power.txt.  The headline
 # loop itself runs AT the limit (the `power` object of the line), so this is the ceiling its matrix work is priced against in
