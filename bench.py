@@ -61,7 +61,7 @@ _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 
         (1, 512), (1, 512), (2, 1024), (1, 1024))
 
 
-def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel"):
+def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel", tail=True):
     """Map the 29 profile slots to (slot name, kernel family, per-window algorithmic bytes, per-window flops)
     for the launches that actually happened (fused kernels are timed in the pointwise slot of their layer)."""
     plan = {0: ("frontend", "logmel_kernel", FRONTEND_BYTES_PER_WINDOW, 0)}
@@ -79,6 +79,17 @@ def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel
         dw_slot, pw_slot = 2 * layer - 2, 2 * layer - 1
         dw = ((h * w * c + ho * wo * c) * 4, 2 * 9 * ho * wo * c)
         pw = ((ho * wo * c + ho * wo * cout) * 4, 2 * ho * wo * c * cout)
+        if tail and chip and layer in (13, 14) and launches[dw_slot] == 0 and launches[pw_slot] > 0:
+            # septail.hip: pointwise 13 with depthwise 14 in its epilogue (f16 planes in, f16 planes out: 4 bytes per element), pointwise
+            # 14 with the average pool; depthwise 13 has run in the on-chip launch in front
+            if layer == 13:
+                nm, fam, nb, fl = plan[pw_slot - 2]
+                plan[pw_slot - 2] = (nm + "+dw13", fam, nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
+                plan[pw_slot] = ("pw13+dw14", "tail_gemm_kernel", (ho * wo * c + ho * wo * cout) * 4, pw[1] + 2 * 9 * ho * wo * cout)
+            else:
+                plan[pw_slot] = ("pw14+pool", "tail_gemm_kernel", (ho * wo * c + cout) * 4, pw[1] + ho * wo * cout)
+            h, w, c = ho, wo, cout
+            continue
         if mid_mode and layer in (5, 6, 7):
             if layer == 5:        # its stride-2 depthwise ran in the layer-4 kernel's epilogue (as below), its 1x1 opens the launch
                 nm, fam, nb, fl = plan[7]
@@ -146,7 +157,7 @@ def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel
                 else:
                     plan[pw_slot] = (f"sep{layer}", fam, (h * w * c + ho * wo * cout) * 4, dw[1] + pw[1])
         h, w, c = ho, wo, cout
-    if pool_fused and 27 in plan and plan[27][0] == "sep14+pool":
+    if pool_fused and 27 in plan and plan[27][0] in ("sep14+pool", "pw14+pool"):
         plan[28] = ("head", "pool_head_kernel", (1024 + 13) * 4, 2 * 1024 * 13)
     else:
         plan[28] = ("pool_head", "pool_head_kernel", (6 * 1024 + 13) * 4, 2 * 1024 * 13)
@@ -549,7 +560,7 @@ def main() -> int:
                          "the on-chip kernels of layers 5-12 hold a whole CU each, so a third stream only adds queueing (same box, "
                          "alternating: 1.852 / 1.855 / 1.849 M windows/s with two, 1.835 / 1.826 / 1.832 M with three, 1.75 M with "
                          "four, 1.57 M with one; DESIGN.md 7)")
-    ap.add_argument("--sep-variant", type=int, default=None, help="tuning: bd_set_fusion separable code (1 = default, 10 = layers 5-7 on four kernels, 7 = the round-3 launch set)")
+    ap.add_argument("--sep-variant", type=int, default=None, help="tuning: bd_set_fusion separable code (1 = default, 11 = layers 13 / 14 on the round-5 kernels, 10 = ... and layers 5-7 on four kernels, 7 = the round-3 launch set)")
     ap.add_argument("--pointwise-mode", choices=["f16x3", "f32", "f16"], default=None,
                     help="profiling only: run the WHOLE bench in this arithmetic mode (the line then carries mode_override; "
                          "the driver's headline never uses it)")
@@ -846,7 +857,7 @@ def main() -> int:
         stem_kernel = {None: "stem_reg_kernel", 3: "stem_reg_kernel"}.get(args.stem, "stem3_kernel")
         if events_on and launches.sum() > 0 and args.per_slot:
             plan = (slot_plan_f32(launches, "stem_reg_f32_kernel" if args.stem in (None, 3) else "stem3_f32_kernel") if args.pointwise_mode == "f32"
-                    else slot_plan(launches, pool_fused=True, chip=args.sep_variant is None, stem_kernel=stem_kernel))
+                    else slot_plan(launches, pool_fused=True, chip=args.sep_variant in (None, 11), stem_kernel=stem_kernel, tail=args.sep_variant is None))
             for slot, (nm, fam, nb, fl) in sorted(plan.items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
                 wl = windows_per_file * ev_steps / max(int(launches[slot]), 1)     # windows per launch on average
@@ -856,7 +867,7 @@ def main() -> int:
             out["ms_per_recording_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
             out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * files_per_step), 4)
             fams = {}
-            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=True, chip=args.sep_variant is None, stem_kernel=stem_kernel).items():
+            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=True, chip=args.sep_variant in (None, 11), stem_kernel=stem_kernel, tail=args.sep_variant is None).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                 f["ms"] += ms[slot]
                 f["launches"] += int(launches[slot])
@@ -866,7 +877,7 @@ def main() -> int:
             total_ms = float(ms.sum())
             # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise (layer 12) or the
             #  average pool (layer 14) in the epilogue)
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "stem3_kernel", "stem_reg_kernel",
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "tail_gemm_kernel", "stem3_kernel", "stem_reg_kernel",
                          "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]

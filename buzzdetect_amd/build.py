@@ -18,7 +18,7 @@ import tempfile
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libbuzzdetect_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ("engine.hip", "frontend.hip", "resample.hip", "sepchip.hip", "sepchipf32.hip", "sepmid.hip", "sepmidf32.hip", "stemreg.hip", "stemregf32.hip", "l4regf32.hip", "cnn.hip", "rowfmt.hip")
+SOURCES = ("engine.hip", "frontend.hip", "resample.hip", "sepchip.hip", "sepchipf32.hip", "sepmid.hip", "sepmidf32.hip", "septail.hip", "stemreg.hip", "stemregf32.hip", "l4regf32.hip", "cnn.hip", "rowfmt.hip")
 # extra compiler flags of single files (part of the source hash below, like the sources themselves)
 FILE_FLAGS = {
     # sep_chip_kernel lives at the 256-register limit of two waves per SIMD: the default machine scheduler spills 4-28 of its

@@ -151,14 +151,18 @@ bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, cons
 bool launch_l4_reg_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
 int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
-                           const SepLayer* next = nullptr);
+                           const SepLayer* next = nullptr, bool planes = false);
+bool tail_supported(const SepLayer& L13, const SepLayer& L14);      // septail.hip: would the two launches below run?
+bool launch_tail_pw13_dw14(const void* in, void* out, int windows, const SepLayer& L13, const SepLayer& L14, hipStream_t stream);   // septail.hip
+bool launch_tail_pw14_pool(const void* in, float* pooled, int windows, const SepLayer& L14, hipStream_t stream);
 bool launch_separable_chip_f32(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
                                const SepLayer* next, bool dw0_done);
 bool launch_separable_mid_f32(const float* in, float* out, int windows, const SepLayer& L5, const SepLayer& L6, const SepLayer& L7,
                               hipStream_t stream);   // sepchip.hip
 bool launch_separable_mid(const float* in, float* out, int windows, const SepLayer& L5, const SepLayer& L6, const SepLayer& L7,
                           hipStream_t stream);       // sepmid.hip
-int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
+int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,
+                                 bool planes = false);
 bool launch_separable_fused_next_dw(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& next,
                                     hipStream_t stream);
 void launch_stem_reg(const float* logmel, int patch_step, const WindowMap& map, int w0, int windows, const float* c1_w,

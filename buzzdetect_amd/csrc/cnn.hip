@@ -1808,6 +1808,43 @@ void launch_sep_w12_pool(const float* in, float* pooled, const SepLayer& L, long
     static std::once_flag lds_once[kMaxDevices];
     allow_dynamic_lds(&sep_w12_kernel<96, false, PLAIN, 1024, 2>, (int)lds, lds_once);
     const long long tiles = (M + 95) / 96;
+#ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=4 traces workgroup 0 of layer 14 + pool
+    const char* tr = getenv("BD_WS_TRACE");
+    if (tr && tr[0] == '4') {
+        static unsigned* dbg = nullptr;
+        static int shots = 0;
+        constexpr int DBG = (128 + 1024 * 8) * 4;
+        if (!dbg) {
+            (void)hipMalloc(&dbg, DBG);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<96, true, PLAIN, 1024, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        (void)hipMemsetAsync(dbg, 0, DBG, stream);
+        hipLaunchKernelGGL((sep_w12_kernel<96, true, PLAIN, 1024, 2>), dim3((unsigned)tiles, 2), dim3(768), lds, stream,
+                           const_cast<float*>(in), pooled, ch, 1, M, L.cin, L.h_out, L.w_out, dbg, L.range_flag, nullptr, nullptr);
+        (void)hipStreamSynchronize(stream);
+        static unsigned h[128 + 1024 * 8];
+        (void)hipMemcpy(h, dbg, DBG, hipMemcpyDeviceToHost);
+        if (++shots == 8) {
+            for (int role = 0; role < 2; ++role) {
+                fprintf(stderr, "[trace] layer 14 %s: work / wait cycles per barrier:", role ? "producer" : "consumer");
+                for (int i = 0; i < 32; ++i) {
+                    const unsigned arr = h[(role * 32 + i) * 2], lv = h[(role * 32 + i) * 2 + 1];
+                    const unsigned prev = i ? h[(role * 32 + i - 1) * 2 + 1] : arr;
+                    if (!arr && !lv) break;
+                    fprintf(stderr, " %u/%u", arr - prev, lv - arr);
+                }
+                fprintf(stderr, "\n");
+            }
+            for (int wg = 0; wg < 3; ++wg) {
+                fprintf(stderr, "[trace] layer 14 workgroup %d wall clock (100 MHz ticks) start, park0, parked, sync, pool0, park1, pool1, end:", wg);
+                for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", h[128 + wg * 8 + i] - h[128 + wg * 8]);
+                fprintf(stderr, "\n");
+            }
+        }
+        return;
+    }
+#endif
     hipLaunchKernelGGL((sep_w12_kernel<96, false, PLAIN, 1024, 2>), dim3((unsigned)tiles, 2), dim3(768), lds, stream,
                        const_cast<float*>(in), pooled, ch, 1, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag, nullptr, nullptr);
 }
@@ -2967,7 +3004,8 @@ int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int
 // 12) - with that successor's depthwise in the epilogue: layers 8-12 + depthwise 13 as ONE launch of the on-chip kernel
 // (sepchip.hip), a -> b = [windows][3][2][512].  Returns the number of layers of L it ran (5) or 0 (the caller goes on as
 // before: launch_separable_run + launch_separable_fused_next_dw).
-int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream) {
+int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,
+                                 bool planes) {
     int n = 0;
     while (n < 5 && n + 1 < max_layers) {
         const SepLayer& l = L[n];
@@ -2977,7 +3015,7 @@ int launch_separable_run_next_dw(const float* a, float* b, int windows, const Se
     }
     if (n < 2 || n > 5 || n >= max_layers || L[n].stride != 2 || L[n].cin != 512 || windows <= 0 || (long long)windows * 24 >= (1LL << 31))
         return 0;
-    return launch_separable_chip(a, b, windows, L, n, stream, &L[n]) ? n : 0;
+    return launch_separable_chip(a, b, windows, L, n, stream, &L[n], planes) ? n : 0;
 }
 
 // Layers 1-3 complete: out = [windows][24][16][128], the layer-3 output.

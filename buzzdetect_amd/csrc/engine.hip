@@ -62,6 +62,9 @@ struct bd_engine {
                                       // of layers 8-11 that hands its tiles over through global memory, layer 12 + depthwise 13 behind it
     bool chip_mid = true;             // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one on-chip launch (sepmid.hip);
                                       // separable = 10 (and 7): the four kernels of round 4
+    bool tail = true;                 // pointwise 13 + depthwise 14 and pointwise 14 + pool on the one-wave-per-SIMD matrix kernel
+                                      // (septail.hip; needs chip_run: its input are the f16 planes that run writes); separable = 11
+                                      // (and 10, 7): the round-5 kernels (sep_ws_kernel, sep_w12_kernel<NDW = 2>)
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
     // operand scaling of the f16 modes (bd_internal.h, SepLayer): host copies of what the scaled tensors are made from
@@ -1006,11 +1009,32 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // layers 8-12 + the stride-2 depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchip.hip): reads
             // buf_a, writes only [windows][3][2][512] into buf_b; timed in layer 12's pointwise slot
             if (e->fuse_sep && e->chip_run && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
-                const int ran = bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
+                // ... and with the tail behind it on septail.hip's kernel, that output leaves as f16 hi / lo planes
+                const bool planes = e->tail && l == 6 && bd::tail_supported(sep[11], sep[12]);
+                const int ran = bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream, planes);
                 if (ran > 0) {
-                    BD_REPEAT_EXTRA(3 + 2 * (l + ran - 1)) (void)bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
+                    BD_REPEAT_EXTRA(3 + 2 * (l + ran - 1)) (void)bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream, planes);
                     l += ran - 1;
                     if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
+                    if (planes) {
+                        // pointwise 13 + depthwise 14 (planes buf_b -> planes buf_a), pointwise 14 + average pool (-> [windows][1024]),
+                        // timed in the two layers' pointwise slots
+                        float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
+                        (void)bd::launch_tail_pw13_dw14(buf_b, buf_a, gw, sep[11], sep[12], stream);
+                        BD_REPEAT_EXTRA(25) (void)bd::launch_tail_pw13_dw14(buf_b, buf_a, gw, sep[11], sep[12], stream);
+                        if (e->profiling) Scope::mark(e, stream, 25);
+                        (void)bd::launch_tail_pw14_pool(buf_a, pooled, gw, sep[12], stream);
+                        BD_REPEAT_EXTRA(27) (void)bd::launch_tail_pw14_pool(buf_a, pooled, gw, sep[12], stream);
+                        if (e->profiling) Scope::mark(e, stream, 27);
+                        if (logits) {
+                            Scope sc(e, stream, 28);
+                            bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
+                            BD_REPEAT_EXTRA(28)
+                                bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
+                        }
+                        pooled_done = true;
+                        break;
+                    }
                     skip_dw_layer = l + 1;
                     last = buf_b;
                     last_floats = (int64_t)gw * sep[l + 1].h_out * sep[l + 1].w_out * sep[l].cout;
@@ -1409,13 +1433,14 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     //  separable 2 = layer 4 as band tiles, 3 = one launch per layer for layers 8-11, 4 / 5 = layer 12 / 14 on the 8-wave kernel,
     //  6 = one exact-f32 kernel per separable layer, 8 = the on-chip run ending at layer 11, 9 / 12 = plain fused layers)
     if (stem != 0 && stem != 3 && stem != 5) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 3 or 5");
-    if (separable != 0 && separable != 1 && separable != 7 && separable != 10)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 7 or 10");
+    if (separable != 0 && separable != 1 && separable != 7 && separable != 10 && separable != 11)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 7, 10 or 11");
     h->fuse_stem = stem != 0;
     h->stem_reg = stem == 3;                 // 3 (default): the layer-2 tile handed over in registers (stemreg.hip); 5: through LDS, a
                                              //    workgroup per row block (stem3_kernel, the default until round 5)
     h->fuse_sep = separable != 0;
-    h->chip_mid = separable == 1;            // 10 (and 7): layers 5-7 on the four kernels of round 4
+    h->chip_mid = separable == 1 || separable == 11;   // 10 (and 7): layers 5-7 on the four kernels of round 4
+    h->tail = separable == 1;                // 11 (and 10, 7): layers 13 / 14 on the round-5 kernels
     h->chip_run = separable != 7;            // 7: the round-3 run of layers 8-11 + layer 12 / depthwise 13 on the 12-wave kernel
     return BD_OK;
 }

@@ -74,7 +74,9 @@ static_assert(sizeof(ChipChain) == (6 * kChipMaxLayers + 1) * 8, "six tables of 
 // (3 x 3, stride 2, SAME = pad 0 before / 1 after on the 6 x 4 map: outputs 3 x 2) is applied to it in registers - after the
 // same half-wave swap as between the layers a lane holds whole windows of its channel - and only [windows][3][2][512] goes
 // to Y: the arithmetic of sep_w12_kernel's NDW = 1 epilogue (shift, then the taps in row-major order with fmaf, ReLU).
-template <bool PLAIN, int NSLOT, bool TRACE = false, bool NDW = false>
+// PLANES (with NDW): the depthwise-13 output leaves as the two f16 halves the tail's matrix kernel reads (septail.hip): hi plane
+// [windows * 6][512] at Y, lo plane behind it - the split and the range guard of the kernel that would otherwise read it as f32.
+template <bool PLAIN, int NSLOT, bool TRACE = false, bool NDW = false, bool PLANES = false>
 __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, const float* X, float* Y, int nl,
                                                            long long M, unsigned* __restrict__ range_flag,
                                                            unsigned long long* __restrict__ dbg = nullptr, int tune = 0) {
@@ -369,6 +371,9 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
             // the tile's windows are rows m0 / 24 .. + 3 of the [windows][6][512] output: 6 output rows per window, a quarter
             // of the tile's bytes
             const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)(m0 / 4) * K, 0, tile_bytes / 4, 0x00020000);
+            _Float16* const yh = reinterpret_cast<_Float16*>(Y);
+            const __amdgpu_buffer_rsrc_t yhr = __builtin_amdgcn_make_buffer_rsrc(yh + (size_t)(m0 / 4) * K, 0, tile_bytes / 8, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ylr = __builtin_amdgcn_make_buffer_rsrc(yh + (size_t)(M / 4 + m0 / 4) * K, 0, tile_bytes / 8, 0x00020000);
             const __amdgpu_buffer_rsrc_t ntaps = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ch.ndw_w), 0, 10 * K * 4, 0x00020000);
             const unsigned yo = (12u * fh * K) * 4 + c4;            // this lane's windows 2 fh, 2 fh + 1: output rows 12 fh ..
 #pragma unroll
@@ -407,9 +412,21 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
                                 a = __builtin_elementwise_fma(v2f{ev[iy][ix], ev[6 + iy][ix]}, v2f{wt[kh * 3 + kw], wt[kh * 3 + kw]}, a);
                             }
 #pragma unroll
-                        for (int w = 0; w < 2; ++w)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(w ? a.y : a.x, 0.0f)), yrs, yo,
-                                                                  ((6 * w + 2 * oy + ox) * K + 32 * st) * 4, 0);
+                        for (int w = 0; w < 2; ++w) {
+                            const float o = fmaxf(w ? a.y : a.x, 0.0f);
+                            if constexpr (PLANES) {
+                                unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)o);
+                                asm volatile("v_fma_mixhi_f16 %0, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_max_f32 %1, %1, |%2|"
+                                             : "+v"(pk), "+v"(rmax) : "v"(o));
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pk, yhr, yo >> 1, ((6 * w + 2 * oy + ox) * K + 32 * st) * 2, 0);
+                                if constexpr (!PLAIN)
+                                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk >> 16), ylr, yo >> 1,
+                                                                          ((6 * w + 2 * oy + ox) * K + 32 * st) * 2, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), yrs, yo,
+                                                                      ((6 * w + 2 * oy + ox) * K + 32 * st) * 4, 0);
+                            }
+                        }
                     }
             }
         }
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void sep_chip_kernel(const ChipChain ch, co
 
 constexpr int kMaxDevicesChip = 64;
 
-template <bool PLAIN, bool NDW>
+template <bool PLAIN, bool NDW, bool PLANES = false>
 void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long long M, const float* ndw_w, hipStream_t stream) {
     ChipChain ch{};
     for (int i = 0; i < nl; ++i) {
@@ -441,7 +458,7 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (kMaxDevicesChip - 1)], [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_chip_kernel<PLAIN, NSLOT, false, NDW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_chip_kernel<PLAIN, NSLOT, false, NDW, PLANES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const long long tiles = (M + 95) / 96;
@@ -449,7 +466,7 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
 #ifdef BD_KERNEL_TRACE      // developer build only: BD_CHIP_TUNE = policy under test; BD_WS_TRACE=7 stamps workgroup 0
     if (const char* tn = getenv("BD_CHIP_TUNE")) tune = atoi(tn);
     const char* tr = getenv("BD_WS_TRACE");
-    if (tr && tr[0] == '7') {
+    if (tr && tr[0] == '7' && !PLANES) {
         static unsigned long long* dbg = nullptr;
         static int shots = 0;
         if (!dbg) (void)hipMalloc(&dbg, 128 * 8);
@@ -471,7 +488,7 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
         return;
     }
 #endif
-    hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT, false, NDW>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl, M,
+    hipLaunchKernelGGL((sep_chip_kernel<PLAIN, NSLOT, false, NDW, PLANES>), dim3((unsigned)tiles), dim3(512), lds, stream, ch, in, out, nl, M,
                        L[0].range_flag, (unsigned long long*)nullptr, tune);
 }
 
@@ -483,14 +500,21 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
 // next's depthwise is applied in the epilogue and out = [windows][3][2][512] (then `out` must not be `in`: the tiles' rows
 // differ).  False (nothing launched) when a layer's shift table does not follow its taps (the kernel reads both through
 // one [10][512] resource; engine.hip lays dw_b16 behind dw_w16).
+// planes (with next): the output leaves as f16 hi / lo planes [windows * 6][512] (hi at out, lo behind it), what septail.hip reads.
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
-                           const SepLayer* next) {
+                           const SepLayer* next, bool planes) {
+    if (planes && !next) return false;
     if (nl < 1 || nl > kChipMaxLayers) return false;
     for (int i = 0; i < nl; ++i)
         if (dw_b_of(L[i]) != dw_w_of(L[i]) + 9 * 512) return false;
     if (next && (dw_b_of(*next) != dw_w_of(*next) + 9 * 512 || next->cin != 512 || next->stride != 2 || in == out)) return false;
     const long long M = (long long)windows * 24;
     const float* nw = next ? dw_w_of(*next) : nullptr;
+    if (planes) {
+        if (L[0].pw_mode == 2) launch_chip<true, true, true>(in, out, L, nl, M, nw, stream);
+        else launch_chip<false, true, true>(in, out, L, nl, M, nw, stream);
+        return true;
+    }
     if (L[0].pw_mode == 2) {
         if (next) launch_chip<true, true>(in, out, L, nl, M, nw, stream);
         else launch_chip<true, false>(in, out, L, nl, M, nw, stream);

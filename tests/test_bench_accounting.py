@@ -16,10 +16,10 @@ RUN_TO_11 = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                  # bd_set_f
 PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # a launch per layer (the bookkeeping must still add up)
 
 
-def _plan(slots, chip=True):
+def _plan(slots, chip=True, tail=False):
     launches = np.zeros(29, dtype=np.int64)
     launches[slots] = 40
-    return bench.slot_plan(launches, chip=chip)
+    return bench.slot_plan(launches, chip=chip, tail=tail)
 
 
 def _network_flops():
@@ -56,6 +56,13 @@ def test_slot_plan_adds_up_to_the_network_in_both_layouts():
     m = _plan(DEFAULT)
     assert m[13][:2] == ("pw5-pw7", "sep_mid_kernel") and m[13][2] == (96 * 128 + 24 * 512) * 4
     assert m[13][3] == d[9][3] + d[11][3] + d[13][3] and m[7] == d[7]
+    # ... and layers 13 / 14 on septail.hip's kernel (the default): depthwise 14 moves from layer 14's slot into pointwise 13's;
+    # [6][512] in and [6][1024] out per window (as f16 planes: 4 bytes per element), then [6][1024] in and [1024] out
+    t = _plan(DEFAULT, tail=True)
+    assert sorted(t) == sorted(DEFAULT) and sum(v[3] for v in t.values()) == _network_flops()
+    assert t[25][:2] == ("pw13+dw14", "tail_gemm_kernel") and t[25][2] == (6 * 512 + 6 * 1024) * 4
+    assert t[27][:2] == ("pw14+pool", "tail_gemm_kernel") and t[27][2] == (6 * 1024 + 1024) * 4 and t[28][0] == "head"
+    assert t[25][3] + t[27][3] == m[25][3] + m[27][3] and t[23] == m[23]
 
 
 def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():

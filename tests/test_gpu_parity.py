@@ -374,8 +374,9 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 7, 10):               # 1: the default launch set; 10: layers 5-7 on the four kernels of round 4; 7: ... and layers
-                                                 # 8-11 as the round-3 run, layer 12 + depthwise 13 on the 12-wave kernel
+        for variant in (1, 11, 7, 10):           # 1: the default launch set; 11: layers 13 / 14 on the round-5 kernels; 10: ... and layers 5-7
+                                                 # on the four kernels of round 4; 7: ... and layers 8-11 as the round-3 run, layer 12 +
+                                                 # depthwise 13 on the 12-wave kernel
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
@@ -402,8 +403,9 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
             engine.set_fusion(False, False)
             ref_logits = engine.predict(x, 0.96).numpy()
             ref_emb = engine.embed(x, 0.96).numpy()
-            for hook in (7, 10):                 # 10: layers 5-7 on their four kernels instead of the on-chip launch (sepmid.hip);
-                                                 # 7: ... and the round-3 run of layers 8-11 through global memory
+            for hook in (7, 10, 11):             # 11: layers 13 / 14 on the round-5 kernels instead of septail.hip's; 10: ... and layers 5-7
+                                                 # on their four kernels instead of the on-chip launch (sepmid.hip); 7: ... and the
+                                                 # round-3 run of layers 8-11 through global memory
                 engine.set_fusion(True, hook)
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), (mode, hook)
                 assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), (mode, hook)
@@ -411,6 +413,30 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
             for _ in range(2):                   # twice: the second pass reads buffers the first one left behind
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), mode
             assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), mode
+    finally:
+        engine.set_pointwise_mode("f16x3")
+        engine.set_fusion(True, True)
+
+
+@pytest.mark.parametrize("windows", [1, 7, 16, 17, 63, 64, 65, 678, 1024, 1031])
+def test_tail_on_the_one_wave_per_simd_kernel_bit_identical_to_a_kernel_per_op(engine, windows):
+    """Layers 13 / 14 + pool (septail.hip): pointwise 13 reads the depthwise-13 output as f16 hi / lo planes written by the on-chip
+    run, applies depthwise 14 to its accumulators and writes planes again; pointwise 14 pools its accumulators.  Against one
+    kernel per op: the same logits and embeddings bit for bit, both f16 modes; row tiles of 16 windows whole and partial, grids
+    rounded up to four row tiles (workgroups that leave at once), a second pass of a 1024-window group, twice (the second
+    call reads buffers the first left behind)."""
+    x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=1300 + windows)
+    try:
+        for mode in ("f16x3", "f16"):
+            engine.set_pointwise_mode(mode)
+            engine.set_fusion(False, False)
+            ref_logits = engine.predict(x, 0.96).numpy()
+            ref_emb = engine.embed(x, 0.96).numpy()
+            engine.set_fusion(True, True)
+            for _ in range(2):
+                assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), mode
+                assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), mode
+            assert ref_emb.shape == (windows, 1024)
     finally:
         engine.set_pointwise_mode("f16x3")
         engine.set_fusion(True, True)

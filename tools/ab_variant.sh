@@ -1,12 +1,11 @@
 #!/bin/bash
-# Same-box A/B of two fusion variants of ONE build: the default path against `--sep-variant $1` (e.g. 7 = layers 8-11 handed
-# over through global memory), alternating, per-slot HIP-event times of the slots matching $2 and the three-stream rate.
-#   gpurun -- 'bash tools/ab_variant.sh 7 "sep8|sep11"'
-v=${1:-7}
-pat=${2:-"sep"}
+# Same-box A/B of two launch sets of ONE library: bench.py --sep-variant $1 ("old") against the default ("new"), alternating
+# three times; prints the rate and the per-slot HIP-event lines matching $2.
+#   gpurun -- 'bash tools/ab_variant.sh 11 "slot 2[57]"'
+old=$1; pat=${2:-"windows/s"}; flags=$3
 for round in 1 2 3; do
-  for arm in default "$v"; do
-    extra=""; [ "$arm" != default ] && extra="--sep-variant $arm"
-    timeout -k 10 300 python bench.py --steps 10 --warmup 3 --per-slot --no-cpu-baseline --no-extras $extra 2>&1 >/dev/null | grep -E "$pat|windows/s" | sed "s/^/[$arm r$round] /"
+  for arm in new old; do
+    if [ $arm = old ]; then v="--sep-variant $old"; else v=""; fi
+    timeout -k 10 300 python bench.py --steps 6 --warmup 2 --per-slot --no-cpu-baseline --no-extras $v $flags 2>&1 >/dev/null | grep -E "$pat|windows/s \(" | sed "s/^/[$arm r$round] /"
   done
 done

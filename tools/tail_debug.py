@@ -1,0 +1,37 @@
+"""Developer aid: embeddings of the default launch set against bd_set_fusion(·, 11) (layers 13 / 14 on the round-5 kernels)."""
+import os
+import sys
+
+os.environ.setdefault("BUZZDETECT_SYNTHETIC_WEIGHTS", "1")
+
+import numpy as np
+
+from buzzdetect_amd.engine import HipEngine
+from oracle import yamnet_oracle as O
+
+HOP = 15360
+
+
+def main():
+    windows = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    mode = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
+    eng = HipEngine(embeddername="yamnet_k2", modelname="model_general_v3")
+    x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
+    eng.set_pointwise_mode(mode)
+    eng.set_fusion(True, 11)
+    ref = eng.embed(x, 0.96).numpy()
+    eng.set_fusion(True, True)
+    got = eng.embed(x, 0.96).numpy()
+    d = np.abs(got - ref)
+    print("windows", windows, "mode", mode, "max |d|", d.max(), "of", np.abs(ref).max(), "wrong", int((got != ref).sum()), "of", got.size)
+    bad_w = np.nonzero((got != ref).any(axis=1))[0]
+    bad_c = np.nonzero((got != ref).any(axis=0))[0]
+    print("windows wrong:", bad_w[:40], "...", len(bad_w))
+    print("channels wrong:", bad_c[:64], "...", len(bad_c))
+    for w in bad_w[:3]:
+        c = np.nonzero(got[w] != ref[w])[0][:8]
+        print(" w", w, "c", c, "got", got[w, c], "ref", ref[w, c])
+
+
+if __name__ == "__main__":
+    main()
