@@ -560,7 +560,7 @@ def main() -> int:
                          "the on-chip kernels of layers 5-12 hold a whole CU each, so a third stream only adds queueing (same box, "
                          "alternating: 1.852 / 1.855 / 1.849 M windows/s with two, 1.835 / 1.826 / 1.832 M with three, 1.75 M with "
                          "four, 1.57 M with one; DESIGN.md 7)")
-    ap.add_argument("--sep-variant", type=int, default=None, help="tuning: bd_set_fusion separable code (1 = default, 11 = layers 13 / 14 on the round-5 kernels, 10 = ... and layers 5-7 on four kernels, 7 = the round-3 launch set)")
+    ap.add_argument("--sep-variant", type=int, default=None, help="tuning: bd_set_fusion separable code (1 = default, 10 = layers 5-7 on four kernels)")
     ap.add_argument("--pointwise-mode", choices=["f16x3", "f32", "f16"], default=None,
                     help="profiling only: run the WHOLE bench in this arithmetic mode (the line then carries mode_override; "
                          "the driver's headline never uses it)")
@@ -857,7 +857,7 @@ def main() -> int:
         stem_kernel = {None: "stem_reg_kernel", 3: "stem_reg_kernel"}.get(args.stem, "stem3_kernel")
         if events_on and launches.sum() > 0 and args.per_slot:
             plan = (slot_plan_f32(launches, "stem_reg_f32_kernel" if args.stem in (None, 3) else "stem3_f32_kernel") if args.pointwise_mode == "f32"
-                    else slot_plan(launches, pool_fused=True, chip=args.sep_variant in (None, 11), stem_kernel=stem_kernel, tail=args.sep_variant is None))
+                    else slot_plan(launches, pool_fused=True, chip=True, stem_kernel=stem_kernel, tail=True))
             for slot, (nm, fam, nb, fl) in sorted(plan.items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
                 wl = windows_per_file * ev_steps / max(int(launches[slot]), 1)     # windows per launch on average
@@ -867,7 +867,7 @@ def main() -> int:
             out["ms_per_recording_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
             out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * files_per_step), 4)
             fams = {}
-            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=True, chip=args.sep_variant in (None, 11), stem_kernel=stem_kernel, tail=args.sep_variant is None).items():
+            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=True, chip=True, stem_kernel=stem_kernel, tail=True).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                 f["ms"] += ms[slot]
                 f["launches"] += int(launches[slot])

@@ -149,7 +149,6 @@ bool launch_pointwise_next_dw_f32(const float* in, float* out, int windows, cons
                                   hipStream_t stream);
 bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
 bool launch_l4_reg_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
-int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream);
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
                            const SepLayer* next = nullptr, bool planes = false);
 bool tail_supported(const SepLayer& L13, const SepLayer& L14);      // septail.hip: would the two launches below run?
@@ -176,6 +175,5 @@ void launch_pool_head(const float* act, int windows, const float* head_wt, const
                       int n_classes, float* emb, float* logits, hipStream_t stream);
 void launch_head(const float* pooled, int windows, const float* head_wt, const float* head_b, int n_classes,
                  float* logits, hipStream_t stream);
-bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
 
 }  // namespace bd

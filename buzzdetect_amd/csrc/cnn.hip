@@ -5,15 +5,13 @@
 //
 // Default path (7 launches per pass): stem_reg_kernel (stemreg.hip: layers 1-3), l4_window_kernel (here),
 // sep_mid_kernel (sepmid.hip: pointwise 5 + layers 6-7), sep_chip_kernel (sepchip.hip: layers 8-12 + depthwise 13),
-// sep_ws_kernel<0, 1> (here: the plain 1x1 of layer 13), sep_w12_kernel<NDW = 2> (here: layer 14 + pool), pool_head_kernel<1>.
+// tail_gemm_kernel twice (septail.hip: pointwise 13 + depthwise 14, pointwise 14 + pool), pool_head_kernel<1>.
 // The kernels of this file:
 //   stem3_kernel         layers 1-3 as one kernel, a workgroup per row block (the default of rounds 2-4; bd_set_fusion stem = 5)
 //   l4_window_kernel     layer 4 + depthwise 5: persistent workgroups walk whole windows two map rows at a time
 //   pw_res_kernel        the 1x1 convolutions of layers 5 and 7: persistent, weights in registers (separable = 10; one kernel per op)
-//   sep_ws_kernel        wave-specialised 96 x 256 tiles (4 producer + 4 MFMA waves, slab ring by LDS-DMA): PWO = the plain 1x1
-//                        convolution of the wide layers; NDW = 1 = layer 6 + depthwise 7 (separable = 7 / 10)
-//   sep_w12_kernel       the same with 8 MFMA waves and 512 columns per workgroup: NDW = 2 = layer 14 + average pool (default);
-//                        layers 8-11 as ONE launch through global memory, NDW = 1 = layer 12 + depthwise 13 (separable = 7)
+//   sep_ws_kernel        wave-specialised 96 x 256 tiles (4 producer + 4 MFMA waves, slab ring by LDS-DMA): NDW = 1 = layer 6 +
+//                        depthwise 7 (separable = 10); PWO = a plain 1x1 convolution of a wide layer (one kernel per op)
 //   pool_head_kernel<1>  Dense(1024 -> n_classes) on the pooled embeddings
 // Reference kernels, one per op (the fused ones are tested bit for bit against them; they are also the exact-f32 mode's tail):
 //   conv1_kernel, depthwise_kernel, pointwise_f16x3_kernel (split-f16), pointwise_kernel (exact-f32 MFMA), pool_head_kernel<6>
@@ -1233,622 +1231,6 @@ void launch_sep_ws(const float* X, const SepLayer& L, float* out, long long M, h
                        next ? dw_b_of(*next) : nullptr, out, L.range_flag);
 }
 
-// --------------------------------------------------------------------------- 12-wave form for N = 512
-// sep_ws_kernel computes the depthwise of a row tile once per 256-column tile, i.e. twice on the K = N = 512 layers,
-// and is bound by that producer work.  Here a workgroup is 12 waves: waves 8-11 are the producers (unchanged:
-// slab ring by LDS-DMA, vertical tap sharing, counted waits), waves 0-7 the consumers, each owning 96 x 64 of a
-// 96 x 512 tile - the depthwise runs once per row tile and every SIMD carries two MFMA waves and one VALU wave.
-// Twelve waves per CU leave 168 registers per wave, 96 of them accumulators: A fragments are read per 32-row tile
-// and weight fragments per 16-deep k step, double-buffered.  The output goes out in three 32-row chunks.
-// Plain instantiation only (no epilogue fusion); same products in the same order: bit-identical.
-//
-// A run of such layers (8-11: the same 6 x 4 map, 512 -> 512) can go out as ONE launch: a tile is four whole windows, a
-// window's rows depend on no other window's, so a workgroup takes its own tile through all the layers of the run, writing each
-// layer's output to the other of two buffers and reading it back (same CU, same L2) as the next layer's slabs.  Between
-// layers: the tile's stores complete (vmcnt 0), a workgroup barrier, and the CU's L1 is invalidated (workgroup scope).
-// Per layer the instructions are those of a single-layer launch: bit-identical.
-struct W12Chain {
-    const float* dw_w[4];
-    const float* dw_b[4];
-    const _Float16* whi[4];
-    const _Float16* wlo[4];
-    const float* pw_u[4];
-    const float* pw_b[4];
-};
-// (selects, not an indexed load: indexing a by-value kernel argument with a run-time index makes a scratch copy of it)
-template <typename T>
-__device__ __forceinline__ T w12_pick(const T (&a)[4], int i) {
-    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
-}
-
-//
-// NDW = 1 (layer 12, whose successor is a stride-2 layer; single-layer launches, 6 x 4 map only): the tile is not written; the NEXT
-// layer's stride-2 depthwise (taps ndw_w, shift ndw_b, SAME = pad 0 before / 1 after) is applied to it in LDS - 256 channels
-// at a time, consumer waves 0-3 then 4-7 parking their columns in an f32 tile that overlays the (dead) stage buffers - and
-// only that result goes to B1.  The 8-wave kernel does the same per 256-column tile, i.e. runs the layer's own depthwise twice.
-// NDW = 2 (layer 14: 1024 -> 1024 on the 3 x 2 map, 16 windows per tile): blockIdx.y picks one of the layer's 512-column halves
-// (the depthwise runs twice per row tile where the 8-wave kernel's four 256-column tiles run it four times); the tile is not
-// written: its windows are average-pooled, 256 channels at a time, and only [windows][1024] goes to B1.
-template <int XPMAX, bool TRACE, bool PLAIN, int KT = 0, int NDW = 0>   // KT: the number of input channels when known at compile time
-__global__ __launch_bounds__(768, 3) void sep_w12_kernel(   // (512 for layers 8-11: tap and slab strides become immediates)
-    float* B0, float* B1, const W12Chain ch, int nl,        // layer i reads B[i & 1] and writes B[(i & 1) ^ 1]
-    long long M, int K_, int H, int W, unsigned* __restrict__ dbg,
-    unsigned* __restrict__ range_flag, const float* __restrict__ ndw_w = nullptr, const float* __restrict__ ndw_b = nullptr) {
-    const int K = KT > 0 ? KT : K_;
-    float rmax = 0.0f;
-    constexpr int BM = 96, BN = 512, N = 512;
-    constexpr int TM = 3, TN = 2, LA = 3;
-    constexpr int XS_FLOATS = (XPMAX + 1) * 32;
-    constexpr int A_BYTES = BM * 64;
-    constexpr int NG = XPMAX / 8, GPW = NG / 4, ND = GPW;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* const Xs = reinterpret_cast<float*>(smem_raw);              // [3][XS_FLOATS]
-    char* const Ah = reinterpret_cast<char*>(Xs + 3 * XS_FLOATS);      // [2][A_BYTES]
-    char* const Al = Ah + 2 * A_BYTES;
-    float* const Wall = reinterpret_cast<float*>(Al + 2 * A_BYTES);    // [10][K]
-    float* const Cc = Wall + 10 * K;                                   // [32][BN + 4]
-    constexpr int NDW_TAPS_AT = BM * (256 + 4) * 4;                    // NDW = 1: the next layer's taps + shift [10][N], behind the f32 tile
-    const int n0 = NDW == 2 ? (int)blockIdx.y * BN : 0;                // NDW = 2: this workgroup's half of the layer's 1024 columns
-    constexpr int NT = NDW == 2 ? 2 * BN : BN;                         // columns of the layer (row length of its output)
-
-    const int nk = K / 32;                    // even, >= 4
-    const int P = H * W;                      // whole windows: P divides BM
-    const unsigned m0u = blockIdx.x * (unsigned)BM;
-    const long long m0 = m0u;
-    const int x_cnt = (int)((M - m0) < BM ? (M - m0) : BM);
-    // developer aid (BD_WS_TRACE=3): cycles before / inside every barrier for wave 0 (consumer) and wave 8 (producer)
-    int tsn = 0;
-#define W12_TS(WH)                                                                                        \
-    if constexpr (TRACE) {                                                                                \
-        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 8) && tsn < 32 && li == 0)              \
-            dbg[((wave >> 3) * 32 + tsn) * 2 + (WH)] = (unsigned)__builtin_readcyclecounter();            \
-        if (WH) ++tsn;                                                                                    \
-    }
-
-    // next layer's stride-2 depthwise on channels 256 HALF .. of the tile parked in Ct (whole windows: every tap is in LDS);
-    // the arithmetic of sep_ws_kernel's NDW = 1 epilogue.  A wave's 64 lanes are the 64 channel quads of ONE output position
-    // (12 waves x 2 positions = the tile's 24), so position, padding tests and row arithmetic are scalar, and the map's size is
-    // a constant of the instantiation (layer 12: 6 x 4): no division survives.
-#define W12_NDW(HALF)                                                                                     \
-    {                                                                                                     \
-        const float* Ct_ = reinterpret_cast<const float*>(smem_raw);                                      \
-        constexpr int CTW = 256 + 4;                                                                      \
-        constexpr int HH = 6, WW = 4, PP = HH * WW;                                                       \
-        constexpr int OW2 = WW / 2, P2 = (HH / 2) * OW2, NPOS = (BM / PP) * P2;                           \
-        static_assert(NPOS == 24, "two output positions per wave");                                       \
-        int tn_ = tid;                                                                                    \
-        asm volatile("" : "+v"(tn_));       /* taps requested HERE: hoisted to the kernel's start they were spilled */ \
-        const int c4 = tn_ & 63, nc = 256 * (HALF) + c4 * 4;                                              \
-        const int slot = __builtin_amdgcn_readfirstlane(tn_ >> 6);                                        \
-        v4f wt[9];                                                                                        \
-        const float* Nw_ = reinterpret_cast<const float*>(smem_raw + NDW_TAPS_AT);   /* [10][N], there since the prologue */ \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(Nw_ + t * N + nc); \
-        const v4f shift = *reinterpret_cast<const v4f*>(Nw_ + 9 * N + nc);                                \
-        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};                                                           \
-        _Pragma("unroll") for (int pp = 0; pp < NPOS; pp += 12) {                                         \
-            const int ps = pp + slot;                                                                     \
-            const int wl = ps / P2, pos2 = ps % P2;                                                       \
-            if (m0 + (long long)wl * PP >= M) continue;                                                   \
-            const int oh = pos2 / OW2, ow = pos2 % OW2;                                                   \
-            const float* base_ = Ct_ + (wl * PP + 2 * oh * WW + 2 * ow) * CTW + c4 * 4;                   \
-            v4f acc2 = shift;                                                                             \
-            _Pragma("unroll") for (int kh = 0; kh < 3; ++kh)                                              \
-                _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                        \
-                    v4f v = zero4;           /* SAME padding: 0 before, 1 after - a wave-uniform test */  \
-                    if (2 * oh + kh < HH && 2 * ow + kw < WW) v = *reinterpret_cast<const v4f*>(base_ + (kh * WW + kw) * CTW); \
-                    acc2 = __builtin_elementwise_fma(v, wt[kh * 3 + kw], acc2);                           \
-                }                                                                                         \
-            acc2.x = fmaxf(acc2.x, 0.0f);                                                                 \
-            acc2.y = fmaxf(acc2.y, 0.0f);                                                                 \
-            acc2.z = fmaxf(acc2.z, 0.0f);                                                                 \
-            acc2.w = fmaxf(acc2.w, 0.0f);                                                                 \
-            const long long row2 = (long long)(m0u / (unsigned)PP + wl) * P2 + pos2;                      \
-            *reinterpret_cast<v4f*>(B1 + (size_t)row2 * N + nc) = acc2;                                   \
-        }                                                                                                 \
-    }
-    // NDW = 2: average pool (yamnet.py:104) of the 16 windows parked in Ct, channels n0 + 256 HALF ..: a wave takes windows
-    // slot and slot + 12, its lanes the 64 channel quads; summed in position order and divided by P exactly as
-    // pool_head_kernel and the 8-wave kernel do
-#define W12_POOL(HALF)                                                                                    \
-    {                                                                                                     \
-        const float* Ct_ = reinterpret_cast<const float*>(smem_raw);                                      \
-        constexpr int CTW = 256 + 4, PP = 6;                                                              \
-        int tn_ = tid;                                                                                    \
-        asm volatile("" : "+v"(tn_));                                                                     \
-        const int c4 = tn_ & 63;                                                                          \
-        const int slot = __builtin_amdgcn_readfirstlane(tn_ >> 6);                                        \
-        for (int wl = slot; wl < BM / PP; wl += 12) {                                                     \
-            if (m0 + (long long)wl * PP >= M) continue;                                                   \
-            v4f s4 = *reinterpret_cast<const v4f*>(Ct_ + (wl * PP) * CTW + c4 * 4);                       \
-            _Pragma("unroll") for (int q = 1; q < PP; ++q) s4 += *reinterpret_cast<const v4f*>(Ct_ + (wl * PP + q) * CTW + c4 * 4); \
-            const float fp = (float)PP;                                                                   \
-            s4.x /= fp; s4.y /= fp; s4.z /= fp; s4.w /= fp;                                               \
-            *reinterpret_cast<v4f*>(B1 + (size_t)(m0u / (unsigned)PP + wl) * NT + n0 + 256 * (HALF) + c4 * 4) = s4; \
-        }                                                                                                 \
-    }
-#define W12_EPI(HALF) { if constexpr (NDW == 1) W12_NDW(HALF) else W12_POOL(HALF) }
-#define W12_WALL(I)                                                                                       \
-    if constexpr (TRACE) {                                                                                \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) dbg[128 + blockIdx.x * 8 + (I)] = (unsigned)wall_clock64(); \
-    }
-    W12_WALL(0)
-    for (int li = 0; li < nl; ++li) {
-    // the thread's index tables are rebuilt per layer (a hundred instructions): kept across the layer loop they would
-    // not fit the 168 registers and the compiler spills them INTO the stage loops
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* const X = (li & 1) ? B1 : B0;
-    float* const Cout = (li & 1) ? B0 : B1;
-    const float* const dw_w = w12_pick(ch.dw_w, li);
-    const float* const dw_b = w12_pick(ch.dw_b, li);
-    const _Float16* const Wfhi = w12_pick(ch.whi, li);
-    const _Float16* const Wflo = w12_pick(ch.wlo, li);
-    const float* const pw_u = w12_pick(ch.pw_u, li);
-    const float* const pw_b = w12_pick(ch.pw_b, li);
-    if (wave >= 8) {
-        // ================================================================= producers (as sep_ws_kernel, XD + VS)
-        const int pt = tid - 512;
-        const int lrow = pt >> 3, lc4 = pt & 7;
-        const int pw = wave - 8;
-        const int lw = 31 - __builtin_clz(W);
-        int wl = 0, g = lrow;
-        if (P < BM) {
-            const int lg = 31 - __builtin_clz(P / LA);
-            wl = lrow >> lg;
-            g = lrow & ((1 << lg) - 1);
-        }
-        const int og = g >> lw, ow = g & (W - 1);
-        const int ml0 = wl * P + LA * og * W + ow;
-        int xt[(LA + 2) * 3], a_st[LA];
-#pragma unroll
-        for (int r = 0; r < LA + 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int ih = LA * og - 1 + r, iw = ow - 1 + c;
-                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
-                xt[r * 3 + c] = (ok ? ml0 + (r - 1) * W + (c - 1) : XPMAX) * 32 + lc4 * 4;
-            }
-#pragma unroll
-        for (int i = 0; i < LA; ++i) a_st[i] = swz64(ml0 + i * W, lc4 >> 1) + (lc4 & 1) * 8;
-        const float* xsrc[GPW];
-#pragma unroll
-        for (int q = 0; q < GPW; ++q) {
-            int row = 8 * (GPW * pw + q) + (lane >> 3);
-            row = row < x_cnt ? row : x_cnt - 1;
-            xsrc[q] = X + (size_t)(m0 + row) * K + (lane & 7) * 4 - 256 * q;
-        }
-#define W12_DMA1(Q, KOFF, XB)                                                                             \
-    if constexpr ((Q) < GPW)                                                                              \
-        __builtin_amdgcn_global_load_lds(                                                                 \
-            (const __attribute__((address_space(1))) void*)(xsrc[(Q) < GPW ? (Q) : 0] + (KOFF)),          \
-            (__attribute__((address_space(3))) void*)(Xs + (XB) * XS_FLOATS + GPW * pw * 256), 16, 1024 * (Q), 0);
-#define W12_DMA(KOFF, XB) { W12_DMA1(0, KOFF, XB) W12_DMA1(1, KOFF, XB) W12_DMA1(2, KOFF, XB) W12_DMA1(3, KOFF, XB) }
-#define W12_PSYNC(KEEP)                                                                                   \
-    {                                                                                                     \
-        W12_TS(0)                                                                                         \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-        __builtin_amdgcn_s_barrier();                                                                     \
-        asm volatile("" ::: "memory");                                                                    \
-        W12_TS(1)                                                                                         \
-    }
-#define W12_DW(XB, AB, KCH)                                                                               \
-    {                                                                                                     \
-        const float* xs_ = Xs + (XB) * XS_FLOATS;                                                         \
-        const float* ws_ = Wall + (KCH) + lc4 * 4;                                                        \
-        v4f wt[9];                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const v4f*>(ws_ + t * K); \
-        const v4f bias4 = *reinterpret_cast<const v4f*>(ws_ + 9 * K);                                     \
-        v4f xv[(LA + 2) * 3];                                                                             \
-        _Pragma("unroll") for (int t = 0; t < (LA + 2) * 3; ++t) xv[t] = *reinterpret_cast<const v4f*>(xs_ + xt[t]); \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
-            v4f a4 = bias4;                                                                               \
-            /* plain v_fma_f32, not v_pk_fma_f32: this wave shares its SIMD with TWO matrix waves, and beside back-to-back */ \
-            /* MFMAs a packed-f32 instruction costs more than the two plain ones it replaces (MI355X_MICROARCH.md; same  */ \
-            /* box 44.3 -> 43.4 us per launch; the 8-wave kernel, one matrix wave per SIMD, prefers the packed form:     */ \
-            /* 59.3 vs 61.2 us).  The same IEEE fmas in the same order: bit-identical.                                   */ \
-            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                               \
-                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a4.x) : "v"(xv[i * 3 + t].x), "v"(wt[t].x));        \
-                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a4.y) : "v"(xv[i * 3 + t].y), "v"(wt[t].y));        \
-                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a4.z) : "v"(xv[i * 3 + t].z), "v"(wt[t].z));        \
-                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a4.w) : "v"(xv[i * 3 + t].w), "v"(wt[t].w));        \
-            }                                                                                             \
-            a4.x = fmaxf(a4.x, 0.0f); a4.y = fmaxf(a4.y, 0.0f); a4.z = fmaxf(a4.z, 0.0f); a4.w = fmaxf(a4.w, 0.0f); \
-            rmax = range_of(rmax, a4);                                                                    \
-            f16x4 hi, lo;                                                                                 \
-            split_f16(a4.x, a4.y, a4.z, a4.w, hi, lo);                                                  \
-            *reinterpret_cast<f16x4*>(Ah + (AB) * A_BYTES + a_st[i]) = hi;                                \
-            *reinterpret_cast<f16x4*>(Al + (AB) * A_BYTES + a_st[i]) = lo;                                \
-        }                                                                                                 \
-    }
-        if (pt < 24) {
-            float z = 0.f;
-            asm volatile("" : "+v"(z));        // (a zero the compiler would otherwise keep - and spill - across the layers)
-            *reinterpret_cast<v4f*>(Xs + (pt >> 3) * XS_FLOATS + XPMAX * 32 + (pt & 7) * 4) = v4f{z, z, z, z};
-        }
-        {
-            // taps + shift of this layer into Wall by LDS-DMA, 1 KB per instruction, issued BEFORE the slabs: the counted wait
-            // below (all but the two youngest slabs) then covers them.  (Ten v4f per lane through registers, as the 8-wave
-            // kernel does it, no longer fit beside the layer loop's state: the compiler spilled them one load at a time.)
-            // Lanes past the table re-read its last entry into the first bytes of Cc, which the epilogue overwrites.
-            const int n_w = 9 * (K / 4), n_all = 10 * (K / 4);
-            for (int c = pw; c * 64 < n_all; c += 4) {
-                int i = c * 64 + lane;
-                i = i < n_all ? i : n_all - 1;
-                const float* src = i < n_w ? dw_w + 4 * (size_t)i : dw_b + 4 * (size_t)(i - n_w);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(Wall + c * 256), 16, 0, 0);
-            }
-        }
-        if constexpr (NDW == 1) {             // ... and the NEXT layer's taps + shift for the epilogue, 20 KB behind the f32 tile
-            float* const Nw = reinterpret_cast<float*>(smem_raw + NDW_TAPS_AT);
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const int i = (pw + 4 * c) * 64 + lane;            // float4 index into [10][N / 4]: 9 rows of taps, then the shift
-                const float* src = i < 9 * (N / 4) ? ndw_w + 4 * (size_t)i : ndw_b + 4 * (size_t)(i - 9 * (N / 4));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(Nw + (pw + 4 * c) * 256), 16, 0, 0);
-            }
-        }
-        W12_DMA(0, 0)
-        W12_DMA(32, 1)
-        W12_DMA(64, 2)
-        W12_PSYNC(2 * ND)
-        W12_DW(0, 0, 0)
-        W12_PSYNC(ND)
-        int rs = 1;
-        int k = 0;
-        for (; k + 3 < nk; ++k) {
-            const int r3 = rs == 0 ? 2 : rs - 1;
-            W12_DMA((k + 3) * 32, r3)
-            W12_DW(rs, (k + 1) & 1, (k + 1) * 32)
-            W12_PSYNC(ND)
-            rs = rs == 2 ? 0 : rs + 1;
-        }
-        for (; k + 1 < nk; ++k) {
-            W12_DW(rs, (k + 1) & 1, (k + 1) * 32)
-            W12_PSYNC(0)
-            rs = rs == 2 ? 0 : rs + 1;
-        }
-        W12_PSYNC(0)                          // consumers' last MFMA stage
-#undef W12_DMA1
-#undef W12_DMA
-#undef W12_PSYNC
-#undef W12_DW
-    } else {
-        // ================================================================= consumers: wave wc owns columns 64 wc ..
-        const int wc = wave;
-        const int frow = lane & 31, fh = lane >> 5;
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        // fragment base: column tile 2 wc + j, k16 step q -> + (j * (K/16) + q) * 512 halves
-        const _Float16* const wbh = Wfhi + ((size_t)(n0 / 32 + 2 * wc) * (K / 16) * 64 + lane) * 8;
-        const _Float16* const wbl = Wflo + ((size_t)(n0 / 32 + 2 * wc) * (K / 16) * 64 + lane) * 8;
-        const int jstep = (K / 16) * 512;     // halves between the two column tiles
-        f16x8 bh0[TN], bl0[TN], bh1[TN], bl1[TN];     // fragments of an even / an odd k16 step
-#define W12_BLOAD(BH, BL, Q)                                                                              \
-    {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                  \
-            BH[j] = *reinterpret_cast<const f16x8*>(wbh + j * jstep + (Q) * 512);                         \
-            BL[j] = *reinterpret_cast<const f16x8*>(wbl + j * jstep + (Q) * 512);                         \
-        }                                                                                                 \
-    }
-        // One stage = 6 steps (k16 step s = 0, 1 x row tile i = 0..2) of 6 MFMAs each.  The A fragments of step t+1
-        // are requested before the MFMAs of step t are issued: with the LDS queue this busy (8 consumer waves read the
-        // whole A tile, 4 producer waves their taps) a fragment read just before its use waits several hundred cycles.
-#define W12_ALOAD(AH, AL, ABUF, S, I)                                                                     \
-    {                                                                                                     \
-        const int off = (ABUF) * A_BYTES + swz64((I) * 32 + frow, 2 * (S) + fh);                          \
-        AH = *reinterpret_cast<const f16x8*>(Ah + off);                                                   \
-        AL = *reinterpret_cast<const f16x8*>(Al + off);                                                   \
-    }
-#define W12_STEP(I, AH, AL, BH, BL)                                                                       \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                      \
-        if constexpr (!PLAIN) {                                                                           \
-            acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH[j], acc[I][j], 0, 0, 0);            \
-            acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL[j], acc[I][j], 0, 0, 0);            \
-        }                                                                                                 \
-        acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH[j], acc[I][j], 0, 0, 0);                \
-    }
-        W12_BLOAD(bh0, bl0, 0)
-        W12_BLOAD(bh1, bl1, 1)
-        W12_TS(0) __syncthreads(); W12_TS(1)
-        W12_TS(0) __syncthreads(); W12_TS(1)
-        const int nq = K / 16;                // k16 steps, two per stage
-        for (int kk = 0; kk < nk; ++kk) {
-            const int ab = kk & 1;
-            f16x8 ah0, al0, ah1, al1;
-            W12_ALOAD(ah0, al0, ab, 0, 0)
-            W12_ALOAD(ah1, al1, ab, 0, 1)
-            W12_STEP(0, ah0, al0, bh0, bl0)
-            W12_ALOAD(ah0, al0, ab, 0, 2)
-            W12_STEP(1, ah1, al1, bh0, bl0)
-            W12_ALOAD(ah1, al1, ab, 1, 0)
-            W12_STEP(2, ah0, al0, bh0, bl0)
-            if (2 * kk + 2 < nq) W12_BLOAD(bh0, bl0, 2 * kk + 2)
-            W12_ALOAD(ah0, al0, ab, 1, 1)
-            W12_STEP(0, ah1, al1, bh1, bl1)
-            W12_ALOAD(ah1, al1, ab, 1, 2)
-            W12_STEP(1, ah0, al0, bh1, bl1)
-            W12_STEP(2, ah1, al1, bh1, bl1)
-            if (2 * kk + 3 < nq) W12_BLOAD(bh1, bl1, 2 * kk + 3)
-            W12_TS(0) __syncthreads(); W12_TS(1)
-        }
-#undef W12_ALOAD
-#undef W12_STEP
-#undef W12_BLOAD
-        // ---- epilogue, consumer part: bias + ReLU, 32 rows at a time through the chunk ----
-        float bias_[TN], unsc_[TN];
-        if constexpr (NDW == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bias_[j] = pw_b[64 * wc + j * 32 + frow];
-                unsc_[j] = pw_u[64 * wc + j * 32 + frow];
-            }
-        }
-        if constexpr (NDW != 0) {
-            float* const Ct = reinterpret_cast<float*>(smem_raw);      // [BM][256 + 4]: every stage buffer is dead by now
-            // (written out per half: in a loop over the halves the compiler computes all 96 outputs ahead of it and spills them)
-#define W12_PARK()                                                                                        \
-    {                                                                                                     \
-        int fr_ = frow;                     /* addresses and outputs formed HERE: left to itself the compiler forms */ \
-        float us_[TN], bs_[TN];             /* both during the last stage's MFMAs and spills them */      \
-        asm volatile("" : "+v"(fr_));                                                                     \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                  \
-            us_[j] = pw_u[n0 + 64 * wc + j * 32 + fr_];                                                   \
-            bs_[j] = pw_b[n0 + 64 * wc + j * 32 + fr_];                                                   \
-        }                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
-            float* const cb_ = Ct + (32 * i + 4 * fh) * (256 + 4) + 64 * (wc & 3) + fr_;                  \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                            \
-                    cb_[((r & 3) + 8 * (r >> 2)) * (256 + 4) + j * 32] = fmaxf(fmaf(acc[i][j][r], us_[j], bs_[j]), 0.0f); \
-        }                                                                                                 \
-    }
-            W12_WALL(1)
-            if (wc < 4) { W12_PARK() }
-            W12_WALL(2)
-            __syncthreads();
-            W12_WALL(3)
-            W12_EPI(0)
-            W12_WALL(4)
-            __syncthreads();
-            if (wc >= 4) { W12_PARK() }
-            __syncthreads();
-            W12_WALL(5)
-            W12_EPI(1)
-            __syncthreads();
-            W12_WALL(6)
-#undef W12_PARK
-        } else
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = 64 * wc + j * 32 + frow;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = 4 * fh + (r & 3) + 8 * (r >> 2);
-                    Cc[ml * (BN + 4) + nl] = fmaxf(fmaf(acc[i][j][r], unsc_[j], bias_[j]), 0.0f);
-                }
-            }
-            __syncthreads();
-            for (int id = tid; id < 32 * (BN / 4); id += 768) {
-                const int ml = id / (BN / 4), c4_ = id % (BN / 4);
-                const long long m = m0 + 32 * i + ml;
-                if (m < M) *reinterpret_cast<v4f*>(Cout + (size_t)m * N + c4_ * 4) = *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);
-            }
-            __syncthreads();
-        }
-    }
-    if (wave >= 8) {
-        // ---- epilogue, producer part: help store the three chunks ----
-        int tid_e = tid;
-        asm volatile("" : "+v"(tid_e));       // addresses computed here, not ahead of the stage loop
-        if constexpr (NDW != 0) {
-            __syncthreads();
-            W12_EPI(0)
-            __syncthreads();
-            __syncthreads();
-            W12_EPI(1)
-            __syncthreads();
-        } else
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            __syncthreads();
-            for (int id = tid_e; id < 32 * (BN / 4); id += 768) {
-                const int ml = id / (BN / 4), c4_ = id % (BN / 4);
-                const long long m = m0 + 32 * i + ml;
-                if (m < M) *reinterpret_cast<v4f*>(Cout + (size_t)m * N + c4_ * 4) = *reinterpret_cast<const v4f*>(Cc + ml * (BN + 4) + c4_ * 4);
-            }
-            __syncthreads();
-        }
-    }
-    if (li + 1 < nl) {                        // this tile's rows of the next layer's input: written and visible to this CU
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // What this hand-off relies on (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
-        //  * producer and consumer of every byte are THIS workgroup, i.e. one CU: no other CU ever reads or writes the tile's
-        //    rows, so none of the inter-workgroup rules (agent-scope release / acquire, `sc1`) is needed - those exist because
-        //    a CU's vector L1 is never refreshed by ANOTHER CU's stores and the XCDs' L2s are not coherent with each other;
-        //  * the vector L1 is write-through: once a wave's `s_waitcnt vmcnt(0)` has returned, its stores have left the CU for
-        //    this XCD's L2, which is where this CU's L1 misses (and the producers' LDS-DMA loads) are served from; the
-        //    workgroup barrier makes that true for all twelve waves before any of them requests the next layer's slabs;
-        //  * what CAN be stale is this CU's own L1: it may still hold lines of the buffer read next from when the workgroup
-        //    read it two layers ago.  `buffer_inv sc0` (workgroup scope) invalidates exactly that L1 and nothing else.  The
-        //    guide's table is explicit that `sc0` is NOT an acquire for data written by other CUs - there is none here.
-        // NOT `buffer_inv sc1`: the agent-scope form also drops this XCD's L2 contents - issued by 12 waves of 32 drifting
-        // workgroups it cost the run a third of its speed (layers 2-4 of a run 58-68 us each instead of 41-44; 1.389 vs 1.496 M
-        // windows/s on one stream).  The under-load check (tests/test_gpu_parity.py, tools/stress_identity.py: every batch of a
-        // three-stream run against its idle-GPU bits, one counter per stream, with a negative control) covers it.
-        asm volatile("buffer_inv sc0" ::: "memory");
-    }
-    }   // layers of the run
-    if (threadIdx.x >= 512) range_report(rmax, range_flag);
-    if constexpr (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    W12_WALL(7)
-#undef W12_WALL
-#undef W12_TS
-#undef W12_NDW
-#undef W12_POOL
-#undef W12_EPI
-}
-
-// Layers L[0 .. nl) (1 <= nl <= 4, all of one shape) in one launch: layer i reads (i odd ? b : a) and writes the other
-// buffer, so the run's output is in b for odd nl and in a for even nl.  nl == 1 is the plain single-layer launch.
-template <int XPMAX, bool PLAIN = false>
-void launch_sep_w12(float* a, float* b, const SepLayer* L, int nl, long long M, hipStream_t stream) {
-    if constexpr (!PLAIN) {                   // mode 2: the same kernel with one MFMA per product
-        if (L[0].pw_mode == 2) return launch_sep_w12<XPMAX, true>(a, b, L, nl, M, stream);
-    }
-    W12Chain ch{};
-    for (int i = 0; i < nl; ++i) {
-        ch.dw_w[i] = dw_w_of(L[i]);
-        ch.dw_b[i] = dw_b_of(L[i]);
-        ch.whi[i] = static_cast<const _Float16*>(L[i].pw_fhi);
-        ch.wlo[i] = static_cast<const _Float16*>(L[i].pw_flo);
-        ch.pw_u[i] = L[i].pw_u;
-        ch.pw_b[i] = L[i].pw_b;
-    }
-    const int cin = L[0].cin, H = L[0].h_out, W = L[0].w_out;
-    const size_t lds = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + (size_t)40 * cin + 32u * (512 + 4) * 4;
-    constexpr size_t lds_max = 3u * (XPMAX + 1) * 128 + 4u * 96 * 64 + 40u * 512u + 32u * (512 + 4) * 4;
-    static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&sep_w12_kernel<XPMAX, false, PLAIN>, (int)lds_max, lds_once);
-    const long long tiles = (M + 95) / 96;
-#ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=3 traces one workgroup of this kernel
-    const char* tr = getenv("BD_WS_TRACE");
-    if (tr && tr[0] == '3') {
-        static unsigned* dbg = nullptr;
-        static int shots = 0;
-        if (!dbg) {
-            (void)hipMalloc(&dbg, 512);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<XPMAX, true, PLAIN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        }
-        (void)hipMemsetAsync(dbg, 0, 512, stream);
-        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, true, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, a, b, ch, nl, M,
-                           cin, H, W, dbg, L[0].range_flag);
-        (void)hipStreamSynchronize(stream);
-        unsigned h[128];
-        (void)hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
-        if (++shots == 8)
-            for (int role = 0; role < 2; ++role) {
-                fprintf(stderr, "[trace] 12-wave kernel %s: work / wait cycles per barrier:", role ? "producer" : "consumer");
-                for (int i = 0; i < 20; ++i) {
-                    const unsigned arr = h[(role * 32 + i) * 2], lv = h[(role * 32 + i) * 2 + 1];
-                    const unsigned prev = i ? h[(role * 32 + i - 1) * 2 + 1] : arr;
-                    if (!arr && !lv) break;
-                    fprintf(stderr, " %u/%u", arr - prev, lv - arr);
-                }
-                fprintf(stderr, "\n");
-            }
-        return;
-    }
-#endif
-    if (cin == 512) {
-        static std::once_flag lds_once512[kMaxDevices];
-        allow_dynamic_lds(&sep_w12_kernel<XPMAX, false, PLAIN, 512>, (int)lds_max, lds_once512);
-        hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN, 512>), dim3((unsigned)tiles), dim3(768), lds, stream, a, b, ch, nl,
-                           M, cin, H, W, nullptr, L[0].range_flag);
-        return;
-    }
-    hipLaunchKernelGGL((sep_w12_kernel<XPMAX, false, PLAIN>), dim3((unsigned)tiles), dim3(768), lds, stream, a, b, ch, nl, M, cin,
-                       H, W, nullptr, L[0].range_flag);
-}
-
-// Layer L (stride 1, 512 output channels, whole-window tiles) on the 12-wave kernel followed by the stride-2 depthwise of
-// `next` in its epilogue: out = [windows][H/2][W/2][512].
-template <int KT, bool PLAIN = false>
-void launch_sep_w12_ndw(const float* in, float* out, const SepLayer& L, const SepLayer& next, long long M, hipStream_t stream) {
-    if constexpr (!PLAIN) {
-        if (L.pw_mode == 2) return launch_sep_w12_ndw<KT, true>(in, out, L, next, M, stream);
-    }
-    W12Chain ch{};
-    ch.dw_w[0] = dw_w_of(L);
-    ch.dw_b[0] = dw_b_of(L);
-    ch.whi[0] = static_cast<const _Float16*>(L.pw_fhi);
-    ch.wlo[0] = static_cast<const _Float16*>(L.pw_flo);
-    ch.pw_u[0] = L.pw_u;
-    ch.pw_b[0] = L.pw_b;
-    constexpr size_t lds = 96u * (256 + 4) * 4 + 40u * 512;     // f32 tile (it overlays the stage buffers) + the next layer's taps
-    static_assert(3u * (96 + 1) * 128 + 4u * 96 * 64 + 40u * KT <= 96u * (256 + 4) * 4, "stage buffers under the tile");
-    static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&sep_w12_kernel<96, false, PLAIN, KT, 1>, (int)lds, lds_once);
-    const long long tiles = (M + 95) / 96;
-    hipLaunchKernelGGL((sep_w12_kernel<96, false, PLAIN, KT, 1>), dim3((unsigned)tiles), dim3(768), lds, stream,
-                       const_cast<float*>(in), out, ch, 1, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag, dw_w_of(next),
-                       dw_b_of(next));
-}
-
-// Layer 14 (1024 -> 1024 on the 3 x 2 map) on the 12-wave kernel, two 512-column halves per row tile, average pool in the
-// epilogue: pooled = [windows][1024].
-template <bool PLAIN = false>
-void launch_sep_w12_pool(const float* in, float* pooled, const SepLayer& L, long long M, hipStream_t stream) {
-    if constexpr (!PLAIN) {
-        if (L.pw_mode == 2) return launch_sep_w12_pool<true>(in, pooled, L, M, stream);
-    }
-    W12Chain ch{};
-    ch.dw_w[0] = dw_w_of(L);
-    ch.dw_b[0] = dw_b_of(L);
-    ch.whi[0] = static_cast<const _Float16*>(L.pw_fhi);
-    ch.wlo[0] = static_cast<const _Float16*>(L.pw_flo);
-    ch.pw_u[0] = L.pw_u;
-    ch.pw_b[0] = L.pw_b;
-    constexpr size_t lds_pipe = 3u * (96 + 1) * 128 + 4u * 96 * 64 + 40u * 1024;
-    constexpr size_t lds_tile = 96u * (256 + 4) * 4;
-    constexpr size_t lds = lds_pipe > lds_tile ? lds_pipe : lds_tile;
-    static std::once_flag lds_once[kMaxDevices];
-    allow_dynamic_lds(&sep_w12_kernel<96, false, PLAIN, 1024, 2>, (int)lds, lds_once);
-    const long long tiles = (M + 95) / 96;
-#ifdef BD_KERNEL_TRACE      // developer build only: BD_WS_TRACE=4 traces workgroup 0 of layer 14 + pool
-    const char* tr = getenv("BD_WS_TRACE");
-    if (tr && tr[0] == '4') {
-        static unsigned* dbg = nullptr;
-        static int shots = 0;
-        constexpr int DBG = (128 + 1024 * 8) * 4;
-        if (!dbg) {
-            (void)hipMalloc(&dbg, DBG);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_w12_kernel<96, true, PLAIN, 1024, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        }
-        (void)hipMemsetAsync(dbg, 0, DBG, stream);
-        hipLaunchKernelGGL((sep_w12_kernel<96, true, PLAIN, 1024, 2>), dim3((unsigned)tiles, 2), dim3(768), lds, stream,
-                           const_cast<float*>(in), pooled, ch, 1, M, L.cin, L.h_out, L.w_out, dbg, L.range_flag, nullptr, nullptr);
-        (void)hipStreamSynchronize(stream);
-        static unsigned h[128 + 1024 * 8];
-        (void)hipMemcpy(h, dbg, DBG, hipMemcpyDeviceToHost);
-        if (++shots == 8) {
-            for (int role = 0; role < 2; ++role) {
-                fprintf(stderr, "[trace] layer 14 %s: work / wait cycles per barrier:", role ? "producer" : "consumer");
-                for (int i = 0; i < 32; ++i) {
-                    const unsigned arr = h[(role * 32 + i) * 2], lv = h[(role * 32 + i) * 2 + 1];
-                    const unsigned prev = i ? h[(role * 32 + i - 1) * 2 + 1] : arr;
-                    if (!arr && !lv) break;
-                    fprintf(stderr, " %u/%u", arr - prev, lv - arr);
-                }
-                fprintf(stderr, "\n");
-            }
-            for (int wg = 0; wg < 3; ++wg) {
-                fprintf(stderr, "[trace] layer 14 workgroup %d wall clock (100 MHz ticks) start, park0, parked, sync, pool0, park1, pool1, end:", wg);
-                for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", h[128 + wg * 8 + i] - h[128 + wg * 8]);
-                fprintf(stderr, "\n");
-            }
-        }
-        return;
-    }
-#endif
-    hipLaunchKernelGGL((sep_w12_kernel<96, false, PLAIN, 1024, 2>), dim3((unsigned)tiles, 2), dim3(768), lds, stream,
-                       const_cast<float*>(in), pooled, ch, 1, M, L.cin, L.h_out, L.w_out, nullptr, L.range_flag, nullptr, nullptr);
-}
-
 // --------------------------------------------------------------------------- pointwise with the weights in registers
 // LDS operations the compiler must not reorder or wait for on its own: the kernel below counts them (lgkmcnt).
 __device__ __forceinline__ unsigned pw_lds_addr(const void* p) {
@@ -2972,38 +2354,14 @@ bool launch_separable_fused_next_dw(const float* in, float* out, int windows, co
     if (!((L.h_out == 12 && L.w_out == 8) || (L.h_out == 6 && L.w_out == 4)) || next.cin != L.cout) return false;
     const long long M = (long long)windows * P;
     if (M >= (1LL << 31)) return false;       // the kernel's tile arithmetic is 32-bit
-    // 512 output channels (layer 12): all of them in one workgroup of the 12-wave kernel (the layer's depthwise runs once per
-    // row tile, not once per 256-column tile)
-    // (layer 12: 512 -> 512 on the 6 x 4 map - the instantiation carries the map.  Layer 6 is 256 -> 256: one column tile.)
-    if (L.cout == 512 && L.cin == 512 && L.h_out == 6 && L.w_out == 4) {
-        launch_sep_w12_ndw<512>(in, out, L, next, M, stream);
-        return true;
-    }
     launch_sep_ws<1, 0>(in, L, out, M, stream, &next);
     return true;
 }
 
-// A run of stride-1 512 -> 512 layers on the 6 x 4 map (layers 8-11) as one launch of the 12-wave kernel.  Returns how many
-// layers of L[0 .. max_layers) it ran (0: none - the caller goes layer by layer); the output of an odd count is in b, of an
-// even count in a.  A layer whose successor is a stride-2 one is left to launch_separable_fused_next_dw.
-int launch_separable_run(float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream) {
-    int n = 0;
-    while (n < 4 && n + 1 < max_layers) {     // n + 1 < max_layers: L[n + 1] exists
-        const SepLayer& l = L[n];
-        if (l.stride != 1 || l.cin != 512 || l.cout != 512 || l.h_out != 6 || l.w_out != 4 || L[n + 1].stride != 1) break;
-        if (l.pw_mode != L[0].pw_mode) break;
-        ++n;
-    }
-    const long long M = (long long)windows * 24;
-    if (n < 2 || windows <= 0 || M >= (1LL << 31)) return 0;
-    launch_sep_w12<96>(a, b, L, n, M, stream);
-    return n;
-}
-
-// The same run extended by the layer that closes it - the stride-1 512 -> 512 layer whose successor is a stride-2 one (layer
-// 12) - with that successor's depthwise in the epilogue: layers 8-12 + depthwise 13 as ONE launch of the on-chip kernel
-// (sepchip.hip), a -> b = [windows][3][2][512].  Returns the number of layers of L it ran (5) or 0 (the caller goes on as
-// before: launch_separable_run + launch_separable_fused_next_dw).
+// The run of stride-1 512 -> 512 layers on the 6 x 4 map (layers 8-11) extended by the layer that closes it - the stride-1
+// 512 -> 512 layer whose successor is a stride-2 one (layer 12) - with that successor's depthwise in the epilogue: layers 8-12 +
+// depthwise 13 as ONE launch of the on-chip kernel (sepchip.hip), a -> b = [windows][3][2][512] (planes: as f16 hi / lo planes,
+// what septail.hip reads).  Returns the number of layers of L it ran (5) or 0 (the caller goes on layer by layer).
 int launch_separable_run_next_dw(const float* a, float* b, int windows, const SepLayer* L, int max_layers, hipStream_t stream,
                                  bool planes) {
     int n = 0;
@@ -3046,17 +2404,6 @@ void launch_head(const float* pooled, int windows, const float* head_wt, const f
     if (windows <= 0 || !logits) return;
     hipLaunchKernelGGL(pool_head_kernel<1>, dim3(windows), dim3(256), 0, stream, pooled, head_wt, head_b,
                        n_classes, static_cast<float*>(nullptr), logits);
-}
-
-// Last layer (3x2 map): fused depthwise+pointwise with the global average pool in the epilogue;
-// pooled = [windows][L.cout].
-bool launch_separable_fused_pool(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream) {
-    const int P = L.h_out * L.w_out;
-    if (L.stride != 1 || windows <= 0 || P != 6 || L.w_out != 2 || L.cin != 1024 || L.cout != 1024) return false;
-    const long long M = (long long)windows * P;
-    if (M >= (1LL << 31)) return false;
-    launch_sep_w12_pool(in, pooled, L, M, stream);       // two 512-column halves on the 12-wave kernel
-    return true;
 }
 
 }  // namespace bd

@@ -58,13 +58,9 @@ struct bd_engine {
     bool fuse_stem = true;            // layers 1-3 as one kernel (stem != 0)
     bool stem_reg = true;             // ... with the layer-2 tile handed over in registers (stemreg.hip; stem = 3, default); 5: through LDS
     bool fuse_sep = true;             // layers 4-14 on the fused kernels (separable != 0)
-    bool chip_run = true;             // layers 8-12 + depthwise 13 as one on-chip launch (sepchip.hip); separable = 7: the round-3 run
-                                      // of layers 8-11 that hands its tiles over through global memory, layer 12 + depthwise 13 behind it
     bool chip_mid = true;             // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one on-chip launch (sepmid.hip);
-                                      // separable = 10 (and 7): the four kernels of round 4
-    bool tail = true;                 // pointwise 13 + depthwise 14 and pointwise 14 + pool on the one-wave-per-SIMD matrix kernel
-                                      // (septail.hip; needs chip_run: its input are the f16 planes that run writes); separable = 11
-                                      // (and 10, 7): the round-5 kernels (sep_ws_kernel, sep_w12_kernel<NDW = 2>)
+                                      // separable = 10: the four kernels of round 4.  (Layers 8-12 + depthwise 13 as one on-chip launch
+                                      // - sepchip.hip - and layers 13 / 14 on septail.hip's kernel have no other fused form left.)
     float* d_pool = nullptr;          // one allocation for every folded tensor
     bd::FeTables* d_tables = nullptr;
     // operand scaling of the f16 modes (bd_internal.h, SepLayer): host copies of what the scaled tensors are made from
@@ -977,23 +973,6 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
         bool pooled_done = false;    // the last layer's kernel already produced the pooled embeddings
         for (int l = first_layer; l < 13 && !stopped; ++l) {
             const bd::SepLayer& L = sep[l];
-            // last layer: the global average pool rides in the fused kernel's epilogue; only [windows][1024] is
-            // written (into the caller's embedding buffer if there is one, else into buf_b)
-            if (l == 12 && e->fuse_sep && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
-                float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
-                if (bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream)) {
-                    BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_separable_fused_pool(buf_a, pooled, gw, L, stream);
-                    if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
-                    if (logits) {
-                        Scope sc(e, stream, 28);
-                        bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
-                        BD_REPEAT_EXTRA(28)
-                            bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
-                    }
-                    pooled_done = true;
-                    break;
-                }
-            }
             // pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as ONE launch, a window per tile, tiles on the CU (sepmid.hip):
             // reads the depthwise-5 output the layer-4 kernel left in buf_b, writes the layer-7 output into buf_a; timed in
             // layer 7's pointwise slot
@@ -1008,9 +987,9 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // layers 8-12 + the stride-2 depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchip.hip): reads
             // buf_a, writes only [windows][3][2][512] into buf_b; timed in layer 12's pointwise slot
-            if (e->fuse_sep && e->chip_run && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
+            if (e->fuse_sep && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
                 // ... and with the tail behind it on septail.hip's kernel, that output leaves as f16 hi / lo planes
-                const bool planes = e->tail && l == 6 && bd::tail_supported(sep[11], sep[12]);
+                const bool planes = l == 6 && bd::tail_supported(sep[11], sep[12]);
                 const int ran = bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream, planes);
                 if (ran > 0) {
                     BD_REPEAT_EXTRA(3 + 2 * (l + ran - 1)) (void)bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream, planes);
@@ -1067,7 +1046,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // exact-f32 mode: layers 8-12 + the depthwise of layer 13 as ONE launch whose tiles stay on the CU (sepchipf32.hip).
             // Its input is the layer-7 output (buf_a) or, when the launch in front applied depthwise 8 in its epilogue, that
             // (buf_b); layer 13 then starts at its 1x1 convolution on the depthwise-13 output in buf_b
-            if (f32_l4 && l == 6 && e->chip_run && stop_stage < 0) {
+            if (f32_l4 && l == 6 && stop_stage < 0) {
                 const bool dw8_done = skip_dw_layer == 6;
                 float* const src = dw8_done ? buf_b : buf_a;
                 float* const dst = dw8_done ? buf_a : buf_b;
@@ -1097,22 +1076,6 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                 last = buf_b;
                 last_floats = (int64_t)gw * 12 * 8 * 128;
                 continue;
-            }
-            // (separable = 7: layers 8-11 as the round-3 run, which hands its tiles over through global memory)
-            if (e->fuse_sep && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
-                const int ran = bd::launch_separable_run(buf_a, buf_b, gw, &sep[l], 13 - l, stream);
-                if (ran > 0) {
-                    l += ran - 1;
-                    if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);      // the whole run in its last layer's slot
-                    if (ran & 1) {
-                        float* t = buf_a;
-                        buf_a = buf_b;
-                        buf_b = t;
-                    }
-                    last = buf_a;
-                    last_floats = (int64_t)gw * sep[l].h_out * sep[l].w_out * sep[l].cout;
-                    continue;
-                }
             }
             if (skip_dw_layer != l) {
                 Scope sc(e, stream, 2 + 2 * l);
@@ -1431,17 +1394,16 @@ int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable) {
     if (!h) return fail(BD_EINVAL, "null handle");
     // (removed in round 6 and refused like any unknown code: stem 2 = layers 1-2 + depthwise 3 only, 4 = the walk of stemroll.hip;
     //  separable 2 = layer 4 as band tiles, 3 = one launch per layer for layers 8-11, 4 / 5 = layer 12 / 14 on the 8-wave kernel,
-    //  6 = one exact-f32 kernel per separable layer, 8 = the on-chip run ending at layer 11, 9 / 12 = plain fused layers)
+    //  6 = one exact-f32 kernel per separable layer, 7 = the round-3 run of layers 8-11 through global memory + layer 12 / 14 on the
+    //  12-wave kernel, 8 = the on-chip run ending at layer 11, 9 / 12 = plain fused layers)
     if (stem != 0 && stem != 3 && stem != 5) return fail(BD_EINVAL, "bd_set_fusion: stem must be 0, 3 or 5");
-    if (separable != 0 && separable != 1 && separable != 7 && separable != 10 && separable != 11)
-        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1, 7, 10 or 11");
+    if (separable != 0 && separable != 1 && separable != 10)
+        return fail(BD_EINVAL, "bd_set_fusion: separable must be 0, 1 or 10");
     h->fuse_stem = stem != 0;
     h->stem_reg = stem == 3;                 // 3 (default): the layer-2 tile handed over in registers (stemreg.hip); 5: through LDS, a
                                              //    workgroup per row block (stem3_kernel, the default until round 5)
     h->fuse_sep = separable != 0;
-    h->chip_mid = separable == 1 || separable == 11;   // 10 (and 7): layers 5-7 on the four kernels of round 4
-    h->tail = separable == 1;                // 11 (and 10, 7): layers 13 / 14 on the round-5 kernels
-    h->chip_run = separable != 7;            // 7: the round-3 run of layers 8-11 + layer 12 / depthwise 13 on the 12-wave kernel
+    h->chip_mid = separable == 1;            // 10: layers 5-7 on the four kernels of round 4
     return BD_OK;
 }
 

@@ -18,10 +18,10 @@
 //     0-2 have been consumed, and then take their slots.  Four workgroup barriers per layer (tile published / slots 0-2
 //     free / pending published / tile consumed) instead of one per stage: between them the eight waves drift freely and two
 //     matrix waves per SIMD cover each other's LDS and L2 latency.
-//   * Weights as in sep_w12_kernel: B fragments straight from the fragment-ordered copy (L2) into registers, two k16 steps
+//   * Weights as in the 12-wave kernel of rounds 2-5: B fragments straight from the fragment-ordered copy (L2) into registers, two k16 steps
 //     ahead.
 //
-// Arithmetic is that of sep_w12_kernel / depthwise_kernel + pointwise_f16x3_kernel bit for bit: the depthwise sums shift +
+// Arithmetic is that of depthwise_kernel + pointwise_f16x3_kernel bit for bit: the depthwise sums shift +
 // taps in row-major tap order with fmaf, ReLU, the split, and per accumulator the products lo*hi, hi*lo, hi*hi of k16 step
 // q = 0..31 in ascending order; which wave owns which column block changes nothing.  Taps that fall outside the map are skipped
 // instead of multiplied by zero: fma(0, w, a) == a for every a but -0.0, and a sum that starts at a float shift is never -0.0
@@ -43,7 +43,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kF16MaxChip = 65504.0f;
 
 // LDS image of one stage's A tile: two halves (hi, lo) of [96 rows][32 k] f16 = 64-byte rows, the 16-byte slot of a row
-// XORed with (row >> 2) & 3 (sep_w12_kernel's swizzle: the 8 rows a ds_read_b128 lane group touches land in different
+// XORed with (row >> 2) & 3 (the swizzle of the round 2-5 kernels: the 8 rows a ds_read_b128 lane group touches land in different
 // banks), and rows 48.. pushed back by one row: the two half-waves of a publishing wave write rows r and r + 48 at once,
 // which would otherwise meet in the same 16 banks.
 constexpr int kChipHalfBytes = 97 * 64;
@@ -73,7 +73,7 @@ static_assert(sizeof(ChipChain) == (6 * kChipMaxLayers + 1) * 8, "six tables of 
 // NDW (layer 12 closes the run and layer 13 is a stride-2 layer): the run's output is not written; layer 13's depthwise
 // (3 x 3, stride 2, SAME = pad 0 before / 1 after on the 6 x 4 map: outputs 3 x 2) is applied to it in registers - after the
 // same half-wave swap as between the layers a lane holds whole windows of its channel - and only [windows][3][2][512] goes
-// to Y: the arithmetic of sep_w12_kernel's NDW = 1 epilogue (shift, then the taps in row-major order with fmaf, ReLU).
+// to Y: the arithmetic of depthwise_kernel (shift, then the taps in row-major order with fmaf, ReLU).
 // PLANES (with NDW): the depthwise-13 output leaves as the two f16 halves the tail's matrix kernel reads (septail.hip): hi plane
 // [windows * 6][512] at Y, lo plane behind it - the split and the range guard of the kernel that would otherwise read it as f32.
 template <bool PLAIN, int NSLOT, bool TRACE = false, bool NDW = false, bool PLANES = false>
@@ -496,7 +496,7 @@ void launch_chip(const float* in, float* out, const SepLayer* L, int nl, long lo
 
 // A run of stride-1 512 -> 512 layers on the 6 x 4 map with the tiles between its layers kept on the CU: reads `in`, writes
 // `out`.  They may be the same buffer: a workgroup has read all rows of its tile before it writes any.  The caller has
-// checked the shapes (launch_separable_run).  With `next` (the stride-2 layer behind the run) the run's output is not written:
+// checked the shapes (launch_separable_run_next_dw).  With `next` (the stride-2 layer behind the run) the run's output is not written:
 // next's depthwise is applied in the epilogue and out = [windows][3][2][512] (then `out` must not be `in`: the tiles' rows
 // differ).  False (nothing launched) when a layer's shift table does not follow its taps (the kernel reads both through
 // one [10][512] resource; engine.hip lays dw_b16 behind dw_w16).

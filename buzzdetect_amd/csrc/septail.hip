@@ -1,8 +1,8 @@
 // The tail of YAMNet as two launches of ONE matrix kernel (round 6): pointwise 13 (512 -> 1024 on the 3 x 2 map) with layer
 // 14's depthwise in its epilogue, and pointwise 14 (1024 -> 1024) with the average pool in its epilogue (yamnet.py:91-92,104).
 //
-// Until now: sep_ws_kernel<0, 1> (24.9 us per 1024 windows) and sep_w12_kernel<NDW = 2> (61.1 us).  The second ran 128
-// workgroups on 256 CUs - its 96 x 512 tiles are all the 6144 x 1024 output has - with two matrix waves and a depthwise
+// Until round 6: sep_ws_kernel<0, 1> (24.9 us per 1024 windows) and the 12-wave kernel of rounds 2-5 (61.1 us).  The second ran
+// 128 workgroups on 256 CUs - its 96 x 512 tiles are all the 6144 x 1024 output has - with two matrix waves and a depthwise
 // producer per SIMD in step behind one barrier per 32 input channels: 3 300 cycles per stage for 2 304 of matrix work.
 //
 // Here every SIMD of the chip owns ONE 96 x 64 wave tile of the output (6144 x 1024 = 1024 wave tiles = 256 CUs x 4 SIMDs) and
@@ -47,10 +47,7 @@ constexpr float kF16MaxTail = 65504.0f;
 constexpr int kTailN = 1024;                   // output channels of both layers
 constexpr int kTailPlane = 96 * 128;           // one f16 half of a stage: 96 rows x 64 input channels
 constexpr int kTailStage = 2 * kTailPlane;     // 24 576
-#ifndef BD_TAIL_RING
-#define BD_TAIL_RING 4
-#endif
-constexpr int kTailRing = BD_TAIL_RING;       // stages in LDS: the DMA runs kTailRing - 1 stages ahead
+constexpr int kTailRing = 4;                   // stages in LDS: the DMA runs kTailRing - 1 stages ahead (3: measures the same)
 constexpr int kTailLds = kTailRing * kTailStage;   // 98 304
 
 struct TailArgs {
@@ -136,27 +133,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int sb0 = (n0 / 32 + 2 * wc) * KQ * 1024;
     unsigned bvo[2];
 #pragma unroll
-#ifndef BD_TAIL_EVENODD
-#define BD_TAIL_EVENODD 1
-#endif
-#ifndef BD_TAIL_SPREAD
-#define BD_TAIL_SPREAD 1
-#endif
-    for (int j = 0; j < 2; ++j)
-        bvo[j] = BD_TAIL_EVENODD ? (frow >> 4) * (KQ * 1024) + ((((2 * frow + j) & 31) + 32 * fh) << 4) : j * (KQ * 1024) + lane * 16;
+    for (int j = 0; j < 2; ++j) bvo[j] = (frow >> 4) * (KQ * 1024) + ((((2 * frow + j) & 31) + 32 * fh) << 4);
     f16x8 bh[4][2], bl[4][2];
     // epilogue constants of this lane's two channels, requested now
-    constexpr int CS = BD_TAIL_EVENODD ? 1 : 32;   // distance of the lane's two channels
-    const int ch0 = n0 + 64 * wc + (BD_TAIL_EVENODD ? 2 : 1) * frow;       // ... and ch0 + CS
-    v2f u2, b2;
-    u2.x = a.pu[ch0]; u2.y = a.pu[ch0 + CS];
-    b2.x = a.pb[ch0]; b2.y = a.pb[ch0 + CS];
+    const int ch0 = n0 + 64 * wc + 2 * frow;       // ... and ch0 + 1
+    const v2f u2 = *reinterpret_cast<const v2f*>(a.pu + ch0), b2 = *reinterpret_cast<const v2f*>(a.pb + ch0);
     v2f wt2[9], shift2;
     if constexpr (EPI == 0) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { wt2[t].x = a.taps[t * N + ch0]; wt2[t].y = a.taps[t * N + ch0 + CS]; }
-        shift2.x = a.taps[9 * N + ch0];
-        shift2.y = a.taps[9 * N + ch0 + CS];
+        for (int t = 0; t < 9; ++t) wt2[t] = *reinterpret_cast<const v2f*>(a.taps + t * N + ch0);
+        shift2 = *reinterpret_cast<const v2f*>(a.taps + 9 * N + ch0);
     }
 
     dma(0);
@@ -234,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             } else if (k < NAL + 2) {
                 if (lb && BD_TAIL_ABLATE != 3) TAIL_BLOAD(br, k - NAL, g + 3)
-            } else if (BD_TAIL_SPREAD && (g & 3) == 2 && (g >> 2) + kTailRing - 1 < NST && BD_TAIL_ABLATE != 2) {
+            } else if ((g & 3) == 2 && (g >> 2) + kTailRing - 1 < NST && BD_TAIL_ABLATE != 2) {
                 // the DMA of stage t + 3 (its slot is free since the barrier behind step 1), a piece behind each of the next matrix
                 // instructions: issued in one go behind the barrier by all four waves, they held the matrix pipe up
                 if constexpr (PLAIN) {
@@ -251,7 +237,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_s_barrier();                                   // ... everybody's; and the stage before is read
                 asm volatile("" ::: "memory");
             }
-            if (!BD_TAIL_SPREAD && (g >> 2) + kTailRing - 1 < NST) dma((g >> 2) + kTailRing - 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (TRACE) {
@@ -285,12 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             sx /= six;
             sy /= six;
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            if (BD_TAIL_EVENODD) {
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, sx), __builtin_bit_cast(unsigned, sy)}, pr, po, w * N * 4, 0);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sx), pr, po, w * N * 4, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sy), pr, po + 128, w * N * 4, 0);
-            }
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, sx), __builtin_bit_cast(unsigned, sy)}, pr, po, w * N * 4, 0);
         }
     } else {
         float rmax = 0.0f;
@@ -322,17 +302,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                  : "=&v"(hi2), "=&v"(lo2), "+v"(rmax)
                                  : "v"(ox_), "v"(oy_));
                     const int so = (6 * w + 2 * oy + ox) * N * 2;
-                    if (BD_TAIL_EVENODD) {
-                        __builtin_amdgcn_raw_buffer_store_b32(hi2, ohr, oo, so, 0);
-                        if constexpr (!PLAIN) __builtin_amdgcn_raw_buffer_store_b32(lo2, olr, oo, so, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hi2, ohr, oo, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(hi2 >> 16), ohr, oo + 64, so, 0);
-                        if constexpr (!PLAIN) {
-                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)lo2, olr, oo, so, 0);
-                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(lo2 >> 16), olr, oo + 64, so, 0);
-                        }
-                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(hi2, ohr, oo, so, 0);
+                    if constexpr (!PLAIN) __builtin_amdgcn_raw_buffer_store_b32(lo2, olr, oo, so, 0);
                 }
         if (range_flag && !(rmax <= kF16MaxTail)) *range_flag = 1u;
     }

@@ -336,8 +336,8 @@ class HipEngine:
         """``bd_set_fusion``: stem True / 3 = layers 1-3 as one kernel (the default: the layer-2 tile handed over in registers),
         5 = the same on the kernel of rounds 2-4 (its tile through LDS), False = one kernel per op; separable True / 1 = the
         default launch set behind the stem (layer 4 + depthwise 5, pointwise 5 - layer 7 on chip, layers 8-12 + depthwise 13
-        on chip, pointwise 13, layer 14 + pool), 10 = layers 5-7 on the four kernels of round 4, 7 = ... and layers 8-11 as the
-        round-3 run through global memory, False = one kernel per op.  Every other code is refused (removed in round 6)."""
+        on chip, pointwise 13 + depthwise 14, pointwise 14 + pool), 10 = layers 5-7 on the four kernels of round 4, False = one
+        kernel per op.  Every other code is refused (removed in round 6)."""
         stem_code = 3 if stem is True else int(stem)
         with self._lock:
             _lib.check(self._lib.bd_set_fusion(self._handle, stem_code, int(separable)))

@@ -292,17 +292,18 @@ BD_API int bd_range_flag_copy(bd_handle h, int32_t* dst, int32_t reset, void* st
                    and pointwise 7 one on-chip launch, a window per tile (sepmid.hip; timed in layer 7's pointwise slot);
                    layers 8-12 + the stride-2 depthwise of layer 13 ONE launch in which every workgroup takes its four windows
                    through the five layers with the tiles between the layers kept on the CU - accumulators -> depthwise in
-                   registers -> LDS ring (sepchip.hip; timed in layer 12's pointwise slot); pointwise 13; layer 14 with the
-                   average pool in its epilogue.  The exact-f32 mode (bd_set_pointwise_mode 0): layers 1-3 one f32-MFMA
+                   registers -> LDS ring (sepchip.hip; timed in layer 12's pointwise slot), its output written as the f16 hi / lo
+                   planes the next launch reads; pointwise 13 with depthwise 14 on its accumulators and pointwise 14 with the
+                   average pool, two launches of one matrix kernel that gives every SIMD of the chip one 96 x 64 tile
+                   (septail.hip).  The exact-f32 mode (bd_set_pointwise_mode 0): layers 1-3 one f32-MFMA
                    kernel, layer 4 + depthwise 5 another, the two on-chip launches with f32 stage tiles (sepmidf32.hip,
                    sepchipf32.hip), layers 13 / 14 as 1x1 kernels with the next depthwise / the pool in their epilogue;
-   separable == 10 as 1 with layers 5-7 on the four kernels of round 4 (pointwise 5, layer 6 + depthwise 7, pointwise 7);
-   separable == 7  as 10, and layers 8-11 as the round-3 run that hands its tiles over through global memory, layer 12 +
-                   depthwise 13 on the 12-wave kernel (exact-f32 mode: a 1x1 kernel per layer with the next depthwise in its
-                   epilogue).
+   separable == 10 as 1 with layers 5-7 on the four kernels of round 4 (pointwise 5, layer 6 + depthwise 7, pointwise 7).
    Removed in round 6 (BD_EINVAL): stem 2 (layers 1-2 + depthwise 3 only), stem 4 (the walk of stemroll.hip); separable 2
    (layer 4 as band tiles), 3 (a launch per layer for layers 8-11), 4 / 5 (layer 12 / 14 on the 8-wave kernel), 6 (one
-   exact-f32 kernel per separable layer, sepf32.hip), 8 (the on-chip run ending at layer 11), 9 / 12 (plain fused layers).
+   exact-f32 kernel per separable layer, sepf32.hip), 7 (layers 8-11 as the round-3 run through global memory, layers 12 and
+   14 on the 12-wave kernel: deleted with that kernel when layers 13 / 14 moved to septail.hip), 8 (the on-chip run ending at
+   layer 11), 9 / 12 (plain fused layers).
    With stem == 0 or during calibration / stage taps inside a fused group: one kernel per op.  Fused and unfused paths give
    bit-identical results. */
 BD_API int bd_set_fusion(bd_handle h, int32_t stem, int32_t separable);

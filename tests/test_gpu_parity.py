@@ -374,9 +374,7 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     engine.set_pointwise_mode("f16x3")
     try:
-        for variant in (1, 11, 7, 10):           # 1: the default launch set; 11: layers 13 / 14 on the round-5 kernels; 10: ... and layers 5-7
-                                                 # on the four kernels of round 4; 7: ... and layers 8-11 as the round-3 run, layer 12 +
-                                                 # depthwise 13 on the 12-wave kernel
+        for variant in (1, 10):                  # 1: the default launch set; 10: layers 5-7 on the four kernels of round 4
             engine.set_fusion(False, False)
             plain = {st: engine.stage_tap(x, HOP, STEP, st, windows).cpu().numpy() for st in (6, 10, 12, 14, 22, 24, 26)}
             plain_logits = engine.predict(x, 0.96).numpy()
@@ -393,8 +391,7 @@ def test_fused_separable_layers_bit_identical_to_unfused(engine, windows):
 def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, windows):
     """Default path: every workgroup takes its four windows through layers 8-12 AND the stride-2 depthwise of layer 13 in ONE
     launch with the tiles between the layers kept on the CU (sepchip.hip: accumulators -> depthwise in registers -> LDS ring);
-    hook 8: that launch ending at layer 11; hook 7: the round-3 form (each
-    layer's output written to the other buffer and read back by the same workgroup).  Against one kernel per op
+    hook 10: the same with layers 5-7 on their four kernels in front of it.  Against one kernel per op
     (bd_set_fusion 0, 0): the same bits, in both f16 modes, whole and partial tiles, first and last workgroup."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=800 + windows)
     try:
@@ -403,9 +400,7 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
             engine.set_fusion(False, False)
             ref_logits = engine.predict(x, 0.96).numpy()
             ref_emb = engine.embed(x, 0.96).numpy()
-            for hook in (7, 10, 11):             # 11: layers 13 / 14 on the round-5 kernels instead of septail.hip's; 10: ... and layers 5-7
-                                                 # on their four kernels instead of the on-chip launch (sepmid.hip); 7: ... and the
-                                                 # round-3 run of layers 8-11 through global memory
+            for hook in (10,):                   # 10: layers 5-7 on their four kernels instead of the on-chip launch (sepmid.hip)
                 engine.set_fusion(True, hook)
                 assert np.array_equal(engine.predict(x, 0.96).numpy(), ref_logits), (mode, hook)
                 assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), (mode, hook)
@@ -850,14 +845,14 @@ def test_fused_f32_mode_equals_one_kernel_per_op(engine, windows):
         # the default (round 5): layers 1-3 as stem3_f32_kernel, layer 4 + depthwise 5 as l4_f32_kernel, pointwise 5 + layers 6-7
         # and layers 8-12 + depthwise 13 as the two on-chip runs (sepmidf32.hip, sepchipf32.hip), layers 13 / 14 as 1x1 kernels
         # with the next depthwise / the pool in their epilogue; 10 = without the middle run (the chip run then takes the
-        # depthwise-8 output), 7 = without either (a 1x1 kernel per layer)
-        for code in (True, 10, 7):
+        # depthwise-8 output)
+        for code in (True, 10):
             engine.set_fusion(True, code)
             assert np.array_equal(engine.predict(x, 0.96).numpy(), ref), code
             assert np.array_equal(engine.embed(x, 0.96).numpy(), ref_emb), code
             assert np.array_equal(engine.predict(x[: HOP * 40], 0.48).numpy(), ref_half), code
         assert ref.shape == (windows, 13)
-        for gone in ((4, 1), (2, 1), (3, 6), (3, 2), (3, 3), (3, 4), (3, 5), (3, 8), (3, 9), (3, 12)):   # removed in round 6: refused
+        for gone in ((4, 1), (2, 1), (3, 6), (3, 2), (3, 3), (3, 4), (3, 5), (3, 7), (3, 8), (3, 9), (3, 11), (3, 12)):   # removed in round 6: refused
             with pytest.raises(Exception):
                 engine.set_fusion(*gone)
     finally:

@@ -15,8 +15,9 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SLOTS = [(-1, "whole path"), (0, "frontend"), (5, "stem(1-3)"), (7, "sep4+dw5"), (9, "pw5"), (11, "sep6+dw7"), (13, "pw7"),
-         (15, "sep8"), (17, "sep9"), (23, "sep12+dw13"), (25, "pw13"), (27, "sep14+pool"), (28, "head")]
+# the default launch set (bd_set_fusion 3 / 1): every launch reads one buffer and writes another, so a repeated launch sees the same input
+SLOTS = [(-1, "whole path"), (0, "frontend"), (5, "stem(1-3)"), (7, "sep4+dw5"), (13, "pw5-pw7"), (23, "sep8-12+dw13"),
+         (25, "pw13+dw14"), (27, "pw14+pool"), (28, "head")]
 REPEAT = 128
 
 
@@ -47,8 +48,9 @@ def child(seconds):
     from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
     hw = hwmon_of(0)
     eng = HipEngine(device=0)
-    eng.set_fusion(False, False)       # one kernel per op: a repeated launch must not consume its own output (the on-chip runs
-                                       # and the round-3 run write into the buffer they read)
+    if os.environ.get("BD_POWER_PROFILE_FUSION"):          # e.g. "3,11": another launch set
+        a, b = os.environ["BD_POWER_PROFILE_FUSION"].split(",")
+        eng.set_fusion(int(a), int(b))
     hop, step = hop_samples(0.96), patch_step(0.96)
     x = torch.randn(1024 * hop + 240, device="cuda") * 0.1
     out = torch.empty((1024, 13), device="cuda")

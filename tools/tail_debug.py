@@ -1,4 +1,4 @@
-"""Developer aid: embeddings of the default launch set against bd_set_fusion(·, 11) (layers 13 / 14 on the round-5 kernels)."""
+"""Developer aid: embeddings of the default launch set against one kernel per op (bd_set_fusion 0, 0)."""
 import os
 import sys
 
@@ -18,7 +18,7 @@ def main():
     eng = HipEngine(embeddername="yamnet_k2", modelname="model_general_v3")
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
     eng.set_pointwise_mode(mode)
-    eng.set_fusion(True, 11)
+    eng.set_fusion(False, False)
     ref = eng.embed(x, 0.96).numpy()
     eng.set_fusion(True, True)
     got = eng.embed(x, 0.96).numpy()
