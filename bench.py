@@ -211,10 +211,12 @@ def slot_plan_f32(launches, stem_kernel="stem_reg_f32_kernel"):
                           pw_fl(dims[3]) + dw_fl(dims[4]) + pw_fl(dims[4]) + dw_fl(dims[5]) + pw_fl(dims[5]))
             continue
         if layer == 14:
-            plan[slot] = ("pw14+pool", "pointwise_kernel", rows_in + d[5] * 4, pw_fl(d) + d[3] * d[4] * d[5])
+            plan[slot] = ("pw14+pool", "tail_gemm_f32_kernel" if chip else "pointwise_kernel", rows_in + d[5] * 4, pw_fl(d) + d[3] * d[4] * d[5])
         else:
             n = dims[layer - 1]
-            plan[slot] = (f"pw{layer}+dw{layer + 1}", "pointwise_kernel", rows_in + n[3] * n[4] * n[2] * 4, pw_fl(d) + dw_fl(n))
+            # (layer 13 behind the on-chip run: septail.hip's kernel, like layer 14 above)
+            plan[slot] = (f"pw{layer}+dw{layer + 1}", "tail_gemm_f32_kernel" if chip and layer == 13 else "pointwise_kernel",
+                          rows_in + n[3] * n[4] * n[2] * 4, pw_fl(d) + dw_fl(n))
     plan[28] = ("head", "pool_head_kernel", (1024 + 13) * 4, 2 * 1024 * 13)
     return {k: v for k, v in plan.items() if launches[k] > 0}
 

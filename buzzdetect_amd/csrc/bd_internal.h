@@ -154,6 +154,10 @@ bool launch_separable_chip(const float* in, float* out, int windows, const SepLa
 bool tail_supported(const SepLayer& L13, const SepLayer& L14);      // septail.hip: would the two launches below run?
 bool launch_tail_pw13_dw14(const void* in, void* out, int windows, const SepLayer& L13, const SepLayer& L14, hipStream_t stream);   // septail.hip
 bool launch_tail_pw14_pool(const void* in, float* pooled, int windows, const SepLayer& L14, hipStream_t stream);
+bool tail_f32_supported(const SepLayer& L13, const SepLayer& L14);
+// which = 0: pointwise 13 + depthwise 14 (in -> mid); 1: pointwise 14 + pool (mid -> pooled)
+bool launch_tail_f32(const float* in, float* mid, float* pooled, int windows, const SepLayer& L13, const SepLayer& L14, hipStream_t stream,
+                     int which);
 bool launch_separable_chip_f32(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
                                const SepLayer* next, bool dw0_done);
 bool launch_separable_mid_f32(const float* in, float* out, int windows, const SepLayer& L5, const SepLayer& L6, const SepLayer& L7,

@@ -469,7 +469,7 @@ int bd_create(bd_handle* out, int device, const bd_weights* w) {
         // the f32 kernel in the fragment order of v_mfma_f32_32x32x2_f32 as the exact-f32 on-chip run reads it (sepchipf32.hip):
         // for a 32-channel tile t and a super-step S of 8 k, lane l holds W[32 t + l % 32][8 S + 4 (l / 32) .. + 4]
         off_pw_ffrag[l] = 0;
-        if (cin >= 128 && cout <= 512) {                           // layers 5-12: what the exact-f32 on-chip runs cover (5.8 MB)
+        if (cin >= 128) {                                          // layers 5-14: what the exact-f32 on-chip runs and the tail kernel cover (12 MB)
             off_pw_ffrag[l] = reserve(nw);
             const float* wf = host.data() + off_pw_w[l];
             float* ff = host.data() + off_pw_ffrag[l];
@@ -1064,6 +1064,25 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
                     last_floats = (int64_t)gw * 3 * 2 * 512;
                     continue;
                 }
+            }
+            // exact-f32 mode: pointwise 13 + depthwise 14 and pointwise 14 + pool on septail.hip's kernel (depthwise 13 has been applied
+            // by the on-chip run: buf_b -> buf_a -> [windows][1024]), timed in the two layers' pointwise slots
+            if (f32_l4 && l == 11 && skip_dw_layer == 11 && stop_stage < 0 && bd::tail_f32_supported(sep[11], sep[12])) {
+                float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
+                (void)bd::launch_tail_f32(buf_b, buf_a, pooled, gw, sep[11], sep[12], stream, 0);
+                BD_REPEAT_EXTRA(25) (void)bd::launch_tail_f32(buf_b, buf_a, pooled, gw, sep[11], sep[12], stream, 0);
+                if (e->profiling) Scope::mark(e, stream, 25);
+                (void)bd::launch_tail_f32(buf_b, buf_a, pooled, gw, sep[11], sep[12], stream, 1);
+                BD_REPEAT_EXTRA(27) (void)bd::launch_tail_f32(buf_b, buf_a, pooled, gw, sep[11], sep[12], stream, 1);
+                if (e->profiling) Scope::mark(e, stream, 27);
+                if (logits) {
+                    Scope sc(e, stream, 28);
+                    bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
+                    BD_REPEAT_EXTRA(28)
+                        bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
+                }
+                pooled_done = true;
+                break;
             }
             // exact-f32 mode, behind the f32 stem: layer 4 and layer 5's stride-2 depthwise as one kernel (bit-identical to the
             // three it replaces); layer 5 then starts at its 1x1 convolution

@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace bd {
 
@@ -316,6 +317,210 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef TAIL_TS
 }
 
+// ---------------------------------------------------------------------------------------------------------------- exact-f32 mode
+// The same kernel on v_mfma_f32_32x32x2_f32 (bd_set_pointwise_mode 0).  What differs: the A operand is the f32 activation itself
+// ([rows][K], what sep_chip_f32_kernel and this kernel's own depthwise epilogue write), a stage is 64 k of it = 256-byte rows (the
+// same 24 KB), one ds_read_b128 per row tile and super-step of 8 k, B fragments from the weights in the f32 instruction's fragment
+// order (SepLayer::pw_ffrag, even / odd channel tiles by lane address as above), two super-steps ahead; a super-step is 24 matrix
+// instructions of 64 cycles.  Per accumulator the k pairs {8 s + e, 8 s + 4 + e}, e = 0..3, of super-step s in ascending order
+// (pointwise_kernel's operand map), then acc + shift, ReLU: the bits of pointwise_kernel with the next depthwise / the pool in its
+// epilogue, which these two launches replace (0.61 / 0.71 of the f32 matrix peak: a 96 x 128 tile per 4 waves, its A and B tiles
+// through LDS behind two barriers per 32 k).
+struct TailArgsF32 {
+    const float* a;                            // A [M][K]
+    const float* bfrag;                        // weights in fragment order [1024 / 32][K / 8][64][4]
+    const float* pb;                           // shift per output channel
+    const float* taps;                         // depthwise epilogue: [9][1024] taps; shift: the layer's dw_b
+    const float* tshift;
+    float* out;                                // depthwise epilogue: [M][1024]
+    float* pooled;                             // pool epilogue: [windows][1024]
+};
+
+template <int K, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tail_gemm_f32_kernel(const TailArgsF32 a, int M, int windows) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int N = kTailN, NST = K / 64, KS = K / 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    const int rt = 4 * (kx >> 1) + (xcd >> 1);
+    const int m0 = rt * 96;
+    if (m0 >= M) return;
+    const int n0 = (2 * (xcd & 1) + (kx & 1)) * 256;
+    const int x_cnt = M - m0 < 96 ? M - m0 : 96;
+    // ---- DMA: lane L = 64 c + lane of a stage's 1536 writes LDS bytes 16 L ..: row rho = L >> 4, slot L & 15 (XORed with rho & 7)
+    const __amdgpu_buffer_rsrc_t ar = TAIL_RSRC(a.a, (unsigned)M * K * 4);
+    unsigned dvo[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int L = (6 * wc + t) * 64 + lane;
+        const int rho = L >> 4, ls = (L & 15) ^ (rho & 7);
+        const int g = 48 * ((rho >> 2) & 1) + 16 * (rho >> 5) + 4 * ((rho >> 3) & 3) + (rho & 3);
+        int row = m0 + g;
+        row = row < M ? row : M - 1;
+        dvo[t] = (unsigned)row * (K * 4) + ls * 16;
+    }
+    auto dma1 = [&](int s, int t) {
+        char* const base = sm + (s % kTailRing) * kTailStage + (6 * wc + t) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (__attribute__((address_space(3))) void*)base, 16, dvo[t], s * 256, 0, 0);
+    };
+    auto dma = [&](int s) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) dma1(s, t);
+    };
+    // ---- A fragments: lane (frow, fh), row tile i, super-step s of a stage: row 32 i + frow, slot (2 s + fh) ^ (frow & 7)
+    unsigned aro[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) aro[s] = frow * 256 + (((2 * s + fh) ^ (frow & 7)) << 4);
+    const __amdgpu_buffer_rsrc_t br = TAIL_RSRC(a.bfrag, N * K * 4);
+    const int sb0 = (n0 / 32 + 2 * wc) * KS * 1024;
+    unsigned bvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bvo[j] = (frow >> 4) * (KS * 1024) + ((((2 * frow + j) & 31) + 32 * fh) << 4);
+    const int ch0 = n0 + 64 * wc + 2 * frow;
+    const v2f b2 = *reinterpret_cast<const v2f*>(a.pb + ch0);
+    v2f wt2[9], shift2;
+    if constexpr (EPI == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt2[t] = *reinterpret_cast<const v2f*>(a.taps + t * N + ch0);
+        shift2 = *reinterpret_cast<const v2f*>(a.tshift + ch0);
+    }
+    dma(0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 1; s < kTailRing - 1; ++s) dma(s);
+    v4f bf[4][2];
+#define TAIL_BLOAD32(S, J, Q) bf[S][J] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(br, bvo[J], sb0 + (Q) * 1024, 0));
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        TAIL_BLOAD32(s, 0, s)
+        TAIL_BLOAD32(s, 1, s)
+    }
+    f32x16 acc[3][2];
+    {
+        float zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = zero;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + (kTailRing - 2) * 6) : "memory");      // stage 0 has landed (this wave's part)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    v4f av[2][3];
+    // fragments of super-step S of the stage in ring slot SLOT (run time)
+#define TAIL_ALOAD32(BUF, SLOT, S, I) \
+    av[BUF][I] = *reinterpret_cast<const v4f*>(sm + aro[S] + (SLOT) * kTailStage + (I) * 8192);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) TAIL_ALOAD32(0, 0, 0, i)
+    __builtin_amdgcn_sched_barrier(0);
+    // A stage = eight super-steps, written out (a run-time loop over the stages: 3 072 matrix instructions do not unroll).  Super-
+    // step s: element e of every fragment in turn (an accumulator's instructions are six others apart); behind the first matrix
+    // instructions one memory instruction each: A of the next super-step, B of the third next (ring of four), and - in the super-
+    // step behind the stage's barrier - the six DMA instructions of stage t + 3.  LAST: the stage behind which nothing follows.
+    auto stage = [&](int t, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const int slot = t & (kTailRing - 1), slotn = (t + 1) & (kTailRing - 1);
+        const bool dm = t + kTailRing - 1 < NST;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1, bs = s & 3, brl = (s + 3) & 3;
+            const bool la = !LAST || s < 7, lb = !LAST || s < 5;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                const int e = k / 6, i = (k % 6) >> 1, j = k & 1;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][e], bf[bs][j][e], acc[i][j], 0, 0, 0);
+                if (k < 3) {
+                    if (la) {
+                        if (s < 7) { TAIL_ALOAD32(nxt, slot, s + 1, k) } else { TAIL_ALOAD32(nxt, slotn, 0, k) }
+                    }
+                } else if (k < 5) {
+                    if (lb) TAIL_BLOAD32(brl, k - 3, 8 * t + s + 3)
+                } else if (k < 11 && s == 4 && !LAST) {
+                    if (dm) dma1(t + kTailRing - 1, k - 5);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (s == 3 && !LAST) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                // this wave's part of the next stage has landed
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t + 1 < NST; ++t) stage(t, std::false_type{});
+    stage(NST - 1, std::true_type{});
+#undef TAIL_ALOAD32
+#undef TAIL_BLOAD32
+    // ---- epilogue (as above): positions 0 .. 5 of windows 8 fh .. 8 fh + 7, channels ch0, ch0 + 1
+    v2f yv[48];
+#pragma unroll
+    for (int n = 0; n < 48; ++n) {
+        const v2f y = v2f{acc[n >> 4][0][n & 15], acc[n >> 4][1][n & 15]} + b2;
+        yv[n] = v2f{fmaxf(y.x, 0.0f), fmaxf(y.y, 0.0f)};
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (EPI == 1) {
+        const __amdgpu_buffer_rsrc_t pr = TAIL_RSRC(a.pooled, (unsigned)windows * N * 4);
+        const unsigned po = (unsigned)((m0 / 6 + 8 * fh) * N + ch0) * 4;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            float sx = yv[6 * w].x, sy = yv[6 * w].y;
+#pragma unroll
+            for (int p = 1; p < 6; ++p) {
+                sx += yv[6 * w + p].x;
+                sy += yv[6 * w + p].y;
+            }
+            const float six = 6.0f;
+            sx /= six;
+            sy /= six;
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, sx), __builtin_bit_cast(unsigned, sy)}, pr, po, w * N * 4, 0);
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t orr = TAIL_RSRC(a.out + (size_t)m0 * N, (unsigned)x_cnt * N * 4);
+        const unsigned oo = (unsigned)(48 * fh * N + ch0) * 4;
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+            for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox) {
+                    v2f s2 = shift2;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int iy = oy + kh - 1, ix = ox + kw - 1;
+                            if (iy < 0 || iy >= 3 || ix < 0 || ix >= 2) continue;
+                            s2 = __builtin_elementwise_fma(yv[6 * w + 2 * iy + ix], wt2[kh * 3 + kw], s2);
+                        }
+                    const float ox_ = fmaxf(s2.x, 0.0f), oy_ = fmaxf(s2.y, 0.0f);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, ox_), __builtin_bit_cast(unsigned, oy_)}, orr, oo,
+                                                          (6 * w + 2 * oy + ox) * N * 4, 0);
+                }
+    }
+}
+
+template <int K, int EPI>
+void launch_tail_f32(const TailArgsF32& a, int windows, hipStream_t stream) {
+    static std::once_flag once[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 63], [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_gemm_f32_kernel<K, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds);
+    });
+    const int M = windows * 6;
+    const int nrt4 = ((M + 95) / 96 + 3) / 4 * 4;
+    hipLaunchKernelGGL((tail_gemm_f32_kernel<K, EPI>), dim3(4 * nrt4), dim3(256), kTailLds, stream, a, M, windows);
+}
+
 template <int K, int EPI, bool PLAIN>
 void launch_tail(const TailArgs& a, int windows, unsigned* range_flag, hipStream_t stream) {
     static std::once_flag once[64];
@@ -401,6 +606,34 @@ bool launch_tail_pw14_pool(const void* in, float* pooled, int windows, const Sep
     a.pooled = pooled;
     if (L14.pw_mode == 2) launch_tail<1024, 1, true>(a, windows, nullptr, stream);
     else launch_tail<1024, 1, false>(a, windows, nullptr, stream);
+    return true;
+}
+
+// The exact-f32 mode's two launches: in = depthwise-13 output [windows * 6][512] f32 (sep_chip_f32_kernel), mid = depthwise-14 output
+// [windows * 6][1024] f32, pooled = [windows][1024].  False (nothing launched) when a shape or the fragment-ordered weights are missing.
+bool tail_f32_supported(const SepLayer& L13, const SepLayer& L14) {
+    return L13.cin == 512 && L13.cout == 1024 && L13.h_out == 3 && L13.w_out == 2 && L14.cin == 1024 && L14.cout == 1024 && L14.stride == 1 &&
+           L14.h_out == 3 && L14.w_out == 2 && L13.pw_ffrag && L14.pw_ffrag;
+}
+bool launch_tail_f32(const float* in, float* mid, float* pooled, int windows, const SepLayer& L13, const SepLayer& L14, hipStream_t stream,
+                     int which) {
+    if (windows <= 0 || windows > (1 << 18) || !tail_f32_supported(L13, L14)) return false;
+    TailArgsF32 a{};
+    if (which == 0) {
+        a.a = in;
+        a.bfrag = L13.pw_ffrag;
+        a.pb = L13.pw_b;
+        a.taps = L14.dw_w;
+        a.tshift = L14.dw_b;
+        a.out = mid;
+        launch_tail_f32<512, 0>(a, windows, stream);
+    } else {
+        a.a = mid;
+        a.bfrag = L14.pw_ffrag;
+        a.pb = L14.pw_b;
+        a.pooled = pooled;
+        launch_tail_f32<1024, 1>(a, windows, stream);
+    }
     return true;
 }
 

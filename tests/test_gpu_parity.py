@@ -417,12 +417,12 @@ def test_layers_8_to_11_as_one_launch_bit_identical_to_a_launch_each(engine, win
 def test_tail_on_the_one_wave_per_simd_kernel_bit_identical_to_a_kernel_per_op(engine, windows):
     """Layers 13 / 14 + pool (septail.hip): pointwise 13 reads the depthwise-13 output as f16 hi / lo planes written by the on-chip
     run, applies depthwise 14 to its accumulators and writes planes again; pointwise 14 pools its accumulators.  Against one
-    kernel per op: the same logits and embeddings bit for bit, both f16 modes; row tiles of 16 windows whole and partial, grids
+    kernel per op: the same logits and embeddings bit for bit, both f16 modes and the exact-f32 mode; row tiles of 16 windows whole and partial, grids
     rounded up to four row tiles (workgroups that leave at once), a second pass of a 1024-window group, twice (the second
     call reads buffers the first left behind)."""
     x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=1300 + windows)
     try:
-        for mode in ("f16x3", "f16"):
+        for mode in ("f16x3", "f16", "f32"):     # f32: the same kernel on v_mfma_f32_32x32x2_f32, its A operand the f32 activation itself
             engine.set_pointwise_mode(mode)
             engine.set_fusion(False, False)
             ref_logits = engine.predict(x, 0.96).numpy()
