@@ -147,7 +147,6 @@ int launch_pointwise_f16x3_variant(const float* A, const void* Whi, const void* 
 void launch_scale_copy(const float* src, float* dst, int64_t n, float factor, hipStream_t stream);
 bool launch_pointwise_next_dw_f32(const float* in, float* out, int windows, const SepLayer& L, const SepLayer& Ln,
                                   hipStream_t stream);
-bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream);
 bool launch_l4_reg_f32(const float* in, float* out, int windows, const SepLayer& L4, const SepLayer& L5, hipStream_t stream);
 bool launch_separable_chip(const float* in, float* out, int windows, const SepLayer* L, int nl, hipStream_t stream,
                            const SepLayer* next = nullptr, bool planes = false);

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_ker
                                                                   const float* __restrict__ ndw_w,
                                                                   const float* __restrict__ ndw_b, int windows) {
     constexpr int NT = WGM * WGN * 64;
-    constexpr bool NDW = NH > 0;                 // NS == 0: the epilogue is the average pool over the NH x NW map instead
+    constexpr bool NDW = NH > 0;
     static_assert(!NDW || (BM % (NH * NW) == 0 && BN == 128 && NT % 32 == 0), "whole windows per tile");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -383,11 +383,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_ker
             const int c4 = tid & (BN / 4 - 1);                   // this thread's channel quad (NT is a multiple of 32)
             pw4 tw[9];
             pw4 tb = {0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (NS != 0) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) tw[k] = *(pw_gptr4)((pw_gptr)ndw_w + (size_t)k * N + n0 + c4 * 4);
-                tb = *(pw_gptr4)((pw_gptr)ndw_b + n0 + c4 * 4);
-            }
+            for (int k = 0; k < 9; ++k) tw[k] = *(pw_gptr4)((pw_gptr)ndw_w + (size_t)k * N + n0 + c4 * 4);
+            tb = *(pw_gptr4)((pw_gptr)ndw_b + n0 + c4 * 4);
             __syncthreads();                                     // every wave has read its last fragments
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -404,24 +402,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (NH > 0 ? 2 : 1)) void pointwise_ker
             __syncthreads();
             const long long win0 = m0 / PWN;
             const bool whole = win0 + WPT <= windows;            // (stores under a branch each wait for the one before)
-            if constexpr (NS == 0) {
-                // global average pool (pool_head_kernel<6>'s chain: the positions added in order, then one division):
-                // C = [windows][N], a thread sums a window's positions for a channel quad
-                constexpr int ITEMS = WPT * (BN / 4);
-                static_assert(ITEMS % NT == 0, "whole rounds of pool items");
-#pragma unroll
-                for (int u = 0; u < ITEMS / NT; ++u) {
-                    const int w = (tid + NT * u) / (BN / 4);
-                    pw4 a = *reinterpret_cast<const pw4*>(P + (w * PWN) * PS + c4 * 4);
-#pragma unroll
-                    for (int q = 1; q < PWN; ++q) a += *reinterpret_cast<const pw4*>(P + (w * PWN + q) * PS + c4 * 4);
-                    a.x /= (float)PWN;
-                    a.y /= (float)PWN;
-                    a.z /= (float)PWN;
-                    a.w /= (float)PWN;
-                    if (whole || win0 + w < windows) *reinterpret_cast<pw4*>(C + (size_t)(win0 + w) * N + n0 + c4 * 4) = a;
-                }
-            } else if constexpr (NS == 1) {
+            if constexpr (NS == 1) {
                 // stride 1: a thread owns a COLUMN of a window's map (and a channel quad) and walks the input rows once - each row
                 // is tap row 0 of the output below it, 1 of its own, 2 of the one above - so an output's chain still runs
                 // in (kh, kw) order, with 3 NH LDS reads per NH outputs instead of 9 NH
@@ -2251,18 +2232,8 @@ bool launch_pointwise_next_dw_f32(const float* in, float* out, int windows, cons
     BD_NDW_CASE(12, 8, 2)
     BD_NDW_CASE(6, 4, 1)
     BD_NDW_CASE(6, 4, 2)
-    BD_NDW_CASE(3, 2, 1)
 #undef BD_NDW_CASE
     return false;
-}
-
-// Exact-f32 1x1 convolution of the LAST layer with the global average pool in the kernel's epilogue: in = its depthwise output
-// [windows][3][2][cin], pooled = [windows][cout] (pool_head_kernel<6>'s chain).  false = shape not covered.
-bool launch_pointwise_pool_f32(const float* in, float* pooled, int windows, const SepLayer& L, hipStream_t stream) {
-    if (windows <= 0) return true;
-    if (L.cout % 128 != 0 || L.cin % kBK != 0 || L.h_out != 3 || L.w_out != 2) return false;
-    launch_pw<96, 128, 1, 4, 3, 2, 0>(in, L.pw_wt, L.pw_b, pooled, (long long)windows * 6, L.cout, L.cin, stream, nullptr, nullptr, windows);
-    return true;
 }
 
 // Tile choice for the split-f16 kernel, from tools/gemm_sweep.py on MI355X at 1024 windows; when the

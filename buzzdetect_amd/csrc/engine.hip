@@ -1109,23 +1109,6 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // exact-f32 mode behind the f32 stem: the 1x1 convolution with the NEXT layer's depthwise in its epilogue (whole
             // windows per 96-row tile; bit-identical to the two kernels): the 1x1 output never reaches HBM and the next
             // layer starts at its own 1x1 convolution.  Timed in this layer's pointwise slot.
-            // ... and the last layer average-pools in its epilogue: only [windows][1024] is written (into the caller's embedding
-            // buffer if there is one), the head reads that
-            if (f32_l4 && l == 12) {
-                float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_a;
-                if (bd::launch_pointwise_pool_f32(buf_b, pooled, gw, L, stream)) {
-                    BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_pointwise_pool_f32(buf_b, pooled, gw, L, stream);
-                    if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);
-                    if (logits) {
-                        Scope sc(e, stream, 28);
-                        bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
-                        BD_REPEAT_EXTRA(28)
-                            bd::launch_head(pooled, gw, e->head_wt, e->head_b, e->n_classes, logits + w0 * e->n_classes, stream);
-                    }
-                    pooled_done = true;
-                    break;
-                }
-            }
             if (f32_l4 && l + 1 < 13 && bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream)) {
                 BD_REPEAT_EXTRA(3 + 2 * l) (void)bd::launch_pointwise_next_dw_f32(buf_b, buf_a, gw, L, sep[l + 1], stream);
                 if (e->profiling) Scope::mark(e, stream, 3 + 2 * l);

@@ -207,11 +207,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (p == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[bs][j], acc[i][j], 0, 0, 0);
             else if (p == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[bs][j], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[bs][j], acc[i][j], 0, 0, 0);
-#ifndef BD_TAIL_ABLATE
-#define BD_TAIL_ABLATE 0
-#endif
             if (k < NAL) {
-                if (la && BD_TAIL_ABLATE != 4) {
+                if (la) {
                     if constexpr (PLAIN) {
                         TAIL_ALOAD(nxt, g + 1, k, 0)
                     } else {
@@ -220,8 +217,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
             } else if (k < NAL + 2) {
-                if (lb && BD_TAIL_ABLATE != 3) TAIL_BLOAD(br, k - NAL, g + 3)
-            } else if ((g & 3) == 2 && (g >> 2) + kTailRing - 1 < NST && BD_TAIL_ABLATE != 2) {
+                if (lb) TAIL_BLOAD(br, k - NAL, g + 3)
+            } else if ((g & 3) == 2 && (g >> 2) + kTailRing - 1 < NST) {
                 // the DMA of stage t + 3 (its slot is free since the barrier behind step 1), a piece behind each of the next matrix
                 // instructions: issued in one go behind the barrier by all four waves, they held the matrix pipe up
                 if constexpr (PLAIN) {
@@ -233,11 +230,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((g & 3) == 1 && (g >> 2) + 1 < NST) {
-            if (BD_TAIL_ABLATE != 1) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");   // this wave's part of the next stage has landed
-                __builtin_amdgcn_s_barrier();                                   // ... everybody's; and the stage before is read
-                asm volatile("" ::: "memory");
-            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");       // this wave's part of the next stage has landed
+            __builtin_amdgcn_s_barrier();                                       // ... everybody's; and the stage before is read
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (TRACE) {
