@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int L = (3 * wc + t) * 64 + lane;
-        const int rho = L >> 3, ls = (L & 7) ^ (rho & 7);
+        const int rho = L >> 3, ls = (L & 7) ^ ((rho >> 1) & 7);
         const int g = 48 * ((rho >> 2) & 1) + 16 * (rho >> 5) + 4 * ((rho >> 3) & 3) + (rho & 3);
         int row = m0 + g;
         row = row < M ? row : M - 1;           // rows past the tile's last: any valid row (their outputs are dropped)
@@ -119,12 +119,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (!PLAIN) dma1(s, t, true);
         }
     };
-    // ---- A fragments: lane (frow, fh), row tile i, k16 step s of a stage: row 32 i + frow, slot (2 s + fh) ^ (frow & 7);
+    // ---- A fragments: lane (frow, fh), row tile i, k16 step s of a stage: row 32 i + frow, slot (2 s + fh) ^ ((frow >> 1) & 7) - two
+    //      128-byte rows share the 64 banks, and a ds_read_b128 serves the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32):
+    //      with that key the sixteen rows of a group lie on sixteen different 16-byte slots (row & 7: eight, 2 x the LDS cycles);
     //      two bases per step (ring slots 0-1 / 2-3: a ds_read's immediate offset ends at 64 KB)
     unsigned aro[2][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        aro[0][s] = frow * 128 + (((2 * s + fh) ^ (frow & 7)) << 4);
+        aro[0][s] = frow * 128 + (((2 * s + fh) ^ ((frow >> 1) & 7)) << 4);
         aro[1][s] = aro[0][s] + 2 * kTailStage;
     }
     // ---- B fragments.  The wave's two column tiles are the EVEN (j = 0) and the ODD (j = 1) channels of its 64, so that a lane's
@@ -345,13 +347,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (m0 >= M) return;
     const int n0 = (2 * (xcd & 1) + (kx & 1)) * 256;
     const int x_cnt = M - m0 < 96 ? M - m0 : 96;
-    // ---- DMA: lane L = 64 c + lane of a stage's 1536 writes LDS bytes 16 L ..: row rho = L >> 4, slot L & 15 (XORed with rho & 7)
+    // ---- DMA: lane L = 64 c + lane of a stage's 1536 writes LDS bytes 16 L ..: row rho = L >> 4, slot L & 15 (XORed with rho & 15)
     const __amdgpu_buffer_rsrc_t ar = TAIL_RSRC(a.a, (unsigned)M * K * 4);
     unsigned dvo[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         const int L = (6 * wc + t) * 64 + lane;
-        const int rho = L >> 4, ls = (L & 15) ^ (rho & 7);
+        const int rho = L >> 4, ls = (L & 15) ^ (rho & 15);
         const int g = 48 * ((rho >> 2) & 1) + 16 * (rho >> 5) + 4 * ((rho >> 3) & 3) + (rho & 3);
         int row = m0 + g;
         row = row < M ? row : M - 1;
@@ -365,10 +367,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int t = 0; t < 6; ++t) dma1(s, t);
     };
-    // ---- A fragments: lane (frow, fh), row tile i, super-step s of a stage: row 32 i + frow, slot (2 s + fh) ^ (frow & 7)
+    // ---- A fragments: lane (frow, fh), row tile i, super-step s of a stage: row 32 i + frow, slot (2 s + fh) ^ (frow & 15)
     unsigned aro[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) aro[s] = frow * 256 + (((2 * s + fh) ^ (frow & 7)) << 4);
+    for (int s = 0; s < 8; ++s) aro[s] = frow * 256 + (((2 * s + fh) ^ (frow & 15)) << 4);
     const __amdgpu_buffer_rsrc_t br = TAIL_RSRC(a.bfrag, N * K * 4);
     const int sb0 = (n0 / 32 + 2 * wc) * KS * 1024;
     unsigned bvo[2];
