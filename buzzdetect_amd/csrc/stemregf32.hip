@@ -20,14 +20,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// ---- LDS map (bytes): 53 504, three workgroups per CU ----
+// ---- LDS map (bytes): 53 248, three workgroups per CU ----
 constexpr int OFF_C1 = 0;                        // conv1 band [6][34][32] f32
 constexpr int OFF_A2 = 6 * 34 * 32 * 4;          // 26112: A tile of layer 2 [128 rows][32 k] f32 (128-byte rows, chunk ^ ((row >> 1) & 7));
                                                  //        the log-mel band [13][68] f32 before it
 constexpr int OFF_A3 = OFF_A2 + 128 * 128;       // 42496: A tile of layer 3 [32 rows][64 k] f32 (256-byte rows, chunk ^ (row & 15))
-constexpr int OFF_HALO = OFF_A3 + 32 * 256;      // 50688: column 16 of the three input rows of a half, [column tile][half][3][32 channels] f32
-constexpr int OFF_D2W = OFF_HALO + 2 * 2 * 3 * 32 * 4;   // 52224: taps and shift of depthwise 2, [10][32] f32, for the whole run
-constexpr int kRegF32Lds = OFF_D2W + 10 * 32 * 4;        // 53504
+constexpr int OFF_HALO = OFF_C1 + (2 * 34 + 1) * 32 * 4;   // column 16 of the three input rows of a half, [column tile][half][3][32 channels] f32: in conv
+                                                 // band row 2 (from its column 0 on), dead from the third barrier of a tile to the next tile's phase B
+                                                 // (stemreg.hip)
+constexpr int OFF_D2W = OFF_A3 + 32 * 256;       // 50688: taps and shift of depthwise 2, [10][32] f32, for the whole run
+constexpr int OFF_C1W = OFF_D2W + 10 * 32 * 4;   // 51968: taps and shift of conv1, likewise (as global loads at the top of a tile they stood behind
+                                                 // the previous tile's output stores: vmcnt(0), the stores' whole round trip - stemreg.hip)
+constexpr int kRegF32Lds = OFF_C1W + 10 * 32 * 4;        // 53248
 
 __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __restrict__ logmel, int patch_step, const WindowMap map, int w0,
                                                               const float* __restrict__ c1_w, const float* __restrict__ c1_b,
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
     char* const s_a2 = smem + OFF_A2;
     float* const s_halo = reinterpret_cast<float*>(smem + OFF_HALO);
     const float* const s_d2 = reinterpret_cast<const float*>(smem + OFF_D2W);
+    const float* const s_c1w = reinterpret_cast<const float*>(smem + OFF_C1W);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, col = tid >> 3;               // vector phases: channel quad, map column
@@ -79,10 +84,6 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
     auto front = [&](auto rows_c, int r_first, int c1_new) {
         constexpr int ROWS = decltype(rows_c)::value;      // 4, or 1: only row r_first (what a run that starts inside a window needs)
         constexpr int C1R = ROWS + 2, LMR = 2 * C1R + 1;
-        v4f c1wt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) c1wt[t] = *(gptr4)(pc1w + t * 32 + c4 * 4);
-        const v4f c1bias = *(gptr4)(pc1b + c4 * 4);
         // ---- A: log-mel rows 2 (r_first - 1) .. + 12 (prefetched) ----
         if (tid < LMR * 16) {
             float4 v = lmv;
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
             *reinterpret_cast<float4*>(&s_lm[255 - tid][64]) = make_float4(z, z, z, z);
         }
         __syncthreads();                                   // (the halo columns of the conv1 band were zeroed once, before the run)
+        v4f c1wt[9];                                       // (behind the barrier: the run's first tile finds the taps written)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) c1wt[t] = *reinterpret_cast<const v4f*>(s_c1w + t * 32 + c4 * 4);
+        const v4f c1bias = *reinterpret_cast<const v4f*>(s_c1w + 9 * 32 + c4 * 4);
         // ---- B: conv1 rows r_first - 1 .. r_first + 4 (conv1_kernel's chain: taps in (kh, kw) order, a tap row past the patch
         //         skipped; a conv1 row outside the map is the depthwise's zero padding) ----
         {
@@ -213,9 +218,10 @@ __global__ __launch_bounds__(256, 3) void stem_reg_f32_kernel(const float* __res
 
     v2f carry[8];                                          // half 0: row 0 of the tile below (= row 4 of this one), in ev's pairs
     if (t_begin < t_end) {
-        if (tid >= 128 && tid < 128 + 80) {                // depthwise 2's taps [9][32] and shift [32] into LDS for the whole run
-            const int row = (tid - 128) >> 3, cc = tid & 7;
-            *reinterpret_cast<v4f*>(smem + OFF_D2W + (row * 32 + cc * 4) * 4) = row < 9 ? *(gptr4)(pd2w + row * 32 + cc * 4) : *(gptr4)(pd2b + cc * 4);
+        if (tid >= 96 && tid < 96 + 160) {                 // conv1's and depthwise 2's taps [9][32] and shift [32] into LDS for the whole run
+            const int which = (tid - 96) / 80, row = ((tid - 96) % 80) >> 3, cc = tid & 7;
+            gptr w = which ? pd2w : pc1w, bs = which ? pd2b : pc1b;
+            *reinterpret_cast<v4f*>(smem + (which ? OFF_D2W : OFF_C1W) + (row * 32 + cc * 4) * 4) = row < 9 ? *(gptr4)(w + row * 32 + cc * 4) : *(gptr4)(bs + cc * 4);
         }
         if (tid < 6 * 2 * 8) {                             // columns -1 and 32 of the conv1 band: zero for the whole run
             const int r = tid / 16, side = (tid >> 3) & 1, cc = tid & 7;
