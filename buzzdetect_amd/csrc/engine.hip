@@ -989,7 +989,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             // buf_a, writes only [windows][3][2][512] into buf_b; timed in layer 12's pointwise slot
             if (e->fuse_sep && mode != 0 && stop_stage < 0 && skip_dw_layer != l) {
                 // ... and with the tail behind it on septail.hip's kernel, that output leaves as f16 hi / lo planes
-                const bool planes = l == 6 && bd::tail_supported(sep[11], sep[12]);
+                const bool planes = l == 6 && gw <= (1 << 18) && bd::tail_supported(sep[11], sep[12]);   // (2^18 windows: the tail kernel's 32-bit offsets)
                 const int ran = bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream, planes);
                 if (ran > 0) {
                     BD_REPEAT_EXTRA(3 + 2 * (l + ran - 1)) (void)bd::launch_separable_run_next_dw(buf_a, buf_b, gw, &sep[l], 13 - l, stream, planes);
@@ -1067,7 +1067,7 @@ int run_chunks(bd_engine* e, const float* const* chunk_pcm, const int64_t* chunk
             }
             // exact-f32 mode: pointwise 13 + depthwise 14 and pointwise 14 + pool on septail.hip's kernel (depthwise 13 has been applied
             // by the on-chip run: buf_b -> buf_a -> [windows][1024]), timed in the two layers' pointwise slots
-            if (f32_l4 && l == 11 && skip_dw_layer == 11 && stop_stage < 0 && bd::tail_f32_supported(sep[11], sep[12])) {
+            if (f32_l4 && l == 11 && skip_dw_layer == 11 && stop_stage < 0 && gw <= (1 << 17) && bd::tail_f32_supported(sep[11], sep[12])) {
                 float* pooled = emb ? emb + w0 * BD_EMBEDDING_SIZE : buf_b;
                 (void)bd::launch_tail_f32(buf_b, buf_a, pooled, gw, sep[11], sep[12], stream, 0);
                 BD_REPEAT_EXTRA(25) (void)bd::launch_tail_f32(buf_b, buf_a, pooled, gw, sep[11], sep[12], stream, 0);

@@ -614,7 +614,7 @@ bool tail_f32_supported(const SepLayer& L13, const SepLayer& L14) {
 }
 bool launch_tail_f32(const float* in, float* mid, float* pooled, int windows, const SepLayer& L13, const SepLayer& L14, hipStream_t stream,
                      int which) {
-    if (windows <= 0 || windows > (1 << 18) || !tail_f32_supported(L13, L14)) return false;
+    if (windows <= 0 || windows > (1 << 17) || !tail_f32_supported(L13, L14)) return false;      // (32-bit byte offsets into [6 windows][1024] f32)
     TailArgsF32 a{};
     if (which == 0) {
         a.a = in;
