@@ -17,7 +17,7 @@ os.environ.setdefault("BUZZDETECT_SYNTHETIC_WEIGHTS", "1")      # developer tool
 from buzzdetect_amd.engine import HipEngine, hop_samples, patch_step
 
 a_code = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-b_code = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+b_code = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n_streams = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 
 dev = torch.device("cuda", 0)
