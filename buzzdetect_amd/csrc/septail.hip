@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float rmax = 0.0f;
         const __amdgpu_buffer_rsrc_t ohr = TAIL_RSRC(a.ohi + (size_t)m0 * N, (unsigned)x_cnt * N * 2);
         const __amdgpu_buffer_rsrc_t olr = TAIL_RSRC(a.olo + (size_t)m0 * N, (unsigned)x_cnt * N * 2);
-        const unsigned oo = (unsigned)(48 * fh * N + (ch0 - 0)) * 2;
+        const unsigned oo = (unsigned)(48 * fh * N + ch0) * 2;
 #pragma unroll
         for (int w = 0; w < 8; ++w)
 #pragma unroll
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // The same kernel on v_mfma_f32_32x32x2_f32 (bd_set_pointwise_mode 0).  What differs: the A operand is the f32 activation itself
 // ([rows][K], what sep_chip_f32_kernel and this kernel's own depthwise epilogue write), a stage is 64 k of it = 256-byte rows (the
 // same 24 KB), one ds_read_b128 per row tile and super-step of 8 k, B fragments from the weights in the f32 instruction's fragment
-// order (SepLayer::pw_ffrag, even / odd channel tiles by lane address as above), two super-steps ahead; a super-step is 24 matrix
+// order (SepLayer::pw_ffrag, even / odd channel tiles by lane address as above), three super-steps ahead; a super-step is 24 matrix
 // instructions of 64 cycles.  Per accumulator the k pairs {8 s + e, 8 s + 4 + e}, e = 0..3, of super-step s in ascending order
 // (pointwise_kernel's operand map), then acc + shift, ReLU: the bits of pointwise_kernel with the next depthwise / the pool in its
 // epilogue, which these two launches replace (0.61 / 0.71 of the f32 matrix peak: a 96 x 128 tile per 4 waves, its A and B tiles
