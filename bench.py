@@ -61,9 +61,11 @@ _DEF = ((2, 32), (1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 
         (1, 512), (1, 512), (2, 1024), (1, 1024))
 
 
-def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel", tail=True):
+def slot_plan(launches, stem_kernel="stem_reg_kernel", tail=True):
     """Map the 29 profile slots to (slot name, kernel family, per-window algorithmic bytes, per-window flops)
-    for the launches that actually happened (fused kernels are timed in the pointwise slot of their layer)."""
+    for the launches that actually happened (fused kernels are timed in the pointwise slot of their layer).  Launch sets the engine
+    has: the default (slots 0, 5, 7, 13, 23, 25, 27, 28), bd_set_fusion separable = 10 (+ 9, 11: layers 5-7 on their own kernels),
+    one kernel per op (every slot); `tail` = layers 13 / 14 run on septail.hip's kernel (always, behind the on-chip run)."""
     plan = {0: ("frontend", "logmel_kernel", FRONTEND_BYTES_PER_WINDOW, 0)}
     h, w, c = 48, 32, 32
     conv1 = (96 * 64 * 4 + h * w * c * 4, 2 * 9 * h * w * c)
@@ -79,7 +81,7 @@ def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel
         dw_slot, pw_slot = 2 * layer - 2, 2 * layer - 1
         dw = ((h * w * c + ho * wo * c) * 4, 2 * 9 * ho * wo * c)
         pw = ((ho * wo * c + ho * wo * cout) * 4, 2 * ho * wo * c * cout)
-        if tail and chip and layer in (13, 14) and launches[dw_slot] == 0 and launches[pw_slot] > 0:
+        if tail and layer in (13, 14) and launches[dw_slot] == 0 and launches[pw_slot] > 0:
             # septail.hip: pointwise 13 with depthwise 14 in its epilogue (f16 planes in, f16 planes out: 4 bytes per element), pointwise
             # 14 with the average pool; depthwise 13 has run in the on-chip launch in front
             if layer == 13:
@@ -102,8 +104,7 @@ def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel
             h, w, c = ho, wo, cout
             continue
         if stride == 1 and c == 512 and cout == 512 and launches[dw_slot] == 0 and launches[pw_slot] == 0 and launches[0] > 0:
-            # timed (and launched) with the last layer of its run (round-3 form, --sep-variant 7: every layer of the run still
-            # stores its output and reads it back as the next layer's slabs; default: sepchip.hip keeps them on the CU)
+            # timed (and launched) with the last layer of its run (sepchip.hip keeps the tiles between the layers on the CU)
             run = run or [layer, 0, 0]
             run[1] += (h * w * c + ho * wo * cout) * 4
             run[2] += dw[1] + pw[1]
@@ -134,33 +135,22 @@ def slot_plan(launches, pool_fused=True, chip=True, stem_kernel="stem_reg_kernel
                 if launches[dw_slot] == 0 and layer >= 5 and (pw_slot - 2) in plan:
                     nm, fam, nb, fl = plan[pw_slot - 2]
                     # the fused kernel of the previous layer wrote this layer's depthwise output instead of its own
-                    # (epilogue fusion exists only in the 8-wave kernel)
-                    # (layer 4 + depthwise 5 have their own kernel: a window per workgroup, no overlapping bands)
-                    # (512 output channels - layer 12 - run the 12-wave kernel, which then applies this depthwise to
-                    #  256 channels at a time: cnn.hip launch_separable_fused_next_dw)
-                    prev_fam = "l4_window_kernel" if layer == 5 else ("sep_w12_ndw_kernel" if pool_fused and c == 512 else "sep_ws_kernel")
-                    if fam == "sep_chip_kernel":       # the on-chip run took layer 12 and this depthwise along (sepchip.hip, NDW)
-                        prev_fam = fam
+                    # (layer 4 + depthwise 5 have their own kernel: a window per workgroup, no overlapping bands; layer 6 + depthwise 7:
+                    #  the 8-wave kernel; the on-chip run takes layer 12 and depthwise 13 along: sepchip.hip, NDW)
+                    prev_fam = "l4_window_kernel" if layer == 5 else fam if fam == "sep_chip_kernel" else "sep_ws_kernel"
                     plan[pw_slot - 2] = (nm + f"+dw{layer}", prev_fam, nb - h * w * c * 4 + ho * wo * c * 4, fl + dw[1])
-            else:                 # depthwise inside the GEMM: layer input in, layer output out
-                # fused stride-1 layers run the wave-specialised kernel; 512 -> 512 channels its 12-wave form (default path)
-                fam = "sep_w12_kernel" if (pool_fused and c == 512 and cout == 512) else "sep_ws_kernel"
-                if layer == 14 and pool_fused:    # the average pool rides in the epilogue: [1024] out per window
-                    # (12-wave kernel, two 512-column halves per row tile: cnn.hip launch_separable_fused_pool)
-                    plan[pw_slot] = ("sep14+pool", "sep_w12_ndw_kernel", (h * w * c + cout) * 4, dw[1] + pw[1] + ho * wo * cout)
-                elif run and fam == "sep_w12_kernel":
-                    if chip:       # sepchip.hip: the tiles between the run's layers stay on the CU - its input in, its output out
-                        plan[pw_slot] = (f"sep{run[0]}-{layer}", "sep_chip_kernel", (h * w * c + ho * wo * cout) * 4, run[2] + dw[1] + pw[1])
-                    else:
-                        plan[pw_slot] = (f"sep{run[0]}-{layer}", fam, run[1] + (h * w * c + ho * wo * cout) * 4, run[2] + dw[1] + pw[1])
+            else:                 # depthwise inside the product kernel: layer input in, layer output out
+                if run and c == 512 and cout == 512:
+                    # sepchip.hip: the tiles between the run's layers stay on the CU - the run's input in, its output out
+                    plan[pw_slot] = (f"sep{run[0]}-{layer}", "sep_chip_kernel", (h * w * c + ho * wo * cout) * 4, run[2] + dw[1] + pw[1])
                     run = None
-                else:
-                    plan[pw_slot] = (f"sep{layer}", fam, (h * w * c + ho * wo * cout) * 4, dw[1] + pw[1])
+                else:             # layer 4 (its own kernel, named when layer 5 is walked) and layer 6 on the 8-wave kernel
+                    plan[pw_slot] = (f"sep{layer}", "sep_ws_kernel", (h * w * c + ho * wo * cout) * 4, dw[1] + pw[1])
         h, w, c = ho, wo, cout
-    if pool_fused and 27 in plan and plan[27][0] in ("sep14+pool", "pw14+pool"):
+    if 27 in plan and plan[27][0] == "pw14+pool":
         plan[28] = ("head", "pool_head_kernel", (1024 + 13) * 4, 2 * 1024 * 13)
     else:
-        plan[28] = ("pool_head", "pool_head_kernel", (6 * 1024 + 13) * 4, 2 * 1024 * 13)
+        plan[28] = ("pool_head", "pool_head_kernel", (6 * 1024 + 13) * 4, 6 * 1024 + 2 * 1024 * 13)
     return plan
 
 
@@ -859,7 +849,7 @@ def main() -> int:
         stem_kernel = {None: "stem_reg_kernel", 3: "stem_reg_kernel"}.get(args.stem, "stem3_kernel")
         if events_on and launches.sum() > 0 and args.per_slot:
             plan = (slot_plan_f32(launches, "stem_reg_f32_kernel" if args.stem in (None, 3) else "stem3_f32_kernel") if args.pointwise_mode == "f32"
-                    else slot_plan(launches, pool_fused=True, chip=True, stem_kernel=stem_kernel, tail=True))
+                    else slot_plan(launches, stem_kernel=stem_kernel))
             for slot, (nm, fam, nb, fl) in sorted(plan.items()):
                 us = 1e3 * ms[slot] / max(int(launches[slot]), 1)
                 wl = windows_per_file * ev_steps / max(int(launches[slot]), 1)     # windows per launch on average
@@ -869,7 +859,7 @@ def main() -> int:
             out["ms_per_recording_with_kernel_events"] = round(1e3 * elapsed_events / ev_steps, 4)
             out["ms_per_recording"] = round(1e3 * elapsed / (args.steps * files_per_step), 4)
             fams = {}
-            for slot, (nm, fam, nb, fl) in slot_plan(launches, pool_fused=True, chip=True, stem_kernel=stem_kernel, tail=True).items():
+            for slot, (nm, fam, nb, fl) in slot_plan(launches, stem_kernel=stem_kernel).items():
                 f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0, "slots": []})
                 f["ms"] += ms[slot]
                 f["launches"] += int(launches[slot])
@@ -877,9 +867,7 @@ def main() -> int:
                 f["flops"] += fl * windows_per_file * ev_steps
                 f["slots"].append(nm)
             total_ms = float(ms.sum())
-            # (sep_w12_ndw_kernel: the instantiations of sep_w12_kernel with the next layer's depthwise (layer 12) or the
-            #  average pool (layer 14) in the epilogue)
-            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_w12_kernel", "sep_chip_kernel", "sep_mid_kernel", "sep_w12_ndw_kernel", "tail_gemm_kernel", "stem3_kernel", "stem_reg_kernel",
+            mfma_fams = ("pointwise_f16x3_kernel", "sep_ws_kernel", "sep_chip_kernel", "sep_mid_kernel", "tail_gemm_kernel", "stem3_kernel", "stem_reg_kernel",
                          "pw_res_kernel", "l4_window_kernel")
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]

@@ -10,16 +10,15 @@ import bench
 from oracle import yamnet_oracle as O
 
 # profile slots that see a launch per batch (engine.hip run_chunks): slot 2 l + 1 is layer l + 2's pointwise / fused kernel
-DEFAULT = [0, 5, 7, 13, 23, 25, 27, 28]                               # layers 5-7 one launch (slot 13), layers 8-12 + depthwise 13 one (slot 23)
+DEFAULT = [0, 5, 7, 13, 23, 25, 27, 28]                               # layers 5-7 one launch (slot 13), layers 8-12 + depthwise 13 one (slot 23), the tail (25, 27)
 NO_MID = [0, 5, 7, 9, 11, 13, 23, 25, 27, 28]                         # bd_set_fusion separable = 10: layers 5-7 on their four kernels
-RUN_TO_11 = [0, 5, 7, 9, 11, 13, 21, 23, 25, 27, 28]                  # bd_set_fusion separable = 7: the run ends at layer 11
-PER_LAYER = [0, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 28]      # a launch per layer (the bookkeeping must still add up)
+PER_OP = list(range(0, 29))                                           # bd_set_fusion 0 / 0: conv1, every depthwise, every 1x1, pool + head
 
 
-def _plan(slots, chip=True, tail=False):
+def _plan(slots):
     launches = np.zeros(29, dtype=np.int64)
     launches[slots] = 40
-    return bench.slot_plan(launches, chip=chip, tail=tail)
+    return bench.slot_plan(launches)
 
 
 def _network_flops():
@@ -33,46 +32,35 @@ def _network_flops():
     return total + h * w * c + 2 * 1024 * 13
 
 
-def test_slot_plan_adds_up_to_the_network_in_both_layouts():
-    for slots in (DEFAULT, NO_MID, RUN_TO_11, PER_LAYER):
-        for chip in (True, False):
-            if slots is DEFAULT and not chip:
-                continue
-            plan = _plan(slots, chip)
-            assert sorted(plan) == sorted(slots)
-            assert sum(v[3] for v in plan.values()) == _network_flops()
-    a, b = _plan(RUN_TO_11, chip=False), _plan(PER_LAYER)
-    assert sum(v[2] for v in a.values()) == sum(v[2] for v in b.values())       # round-3 form of the run: it still stores every layer
-    # the on-chip run (sepchip.hip): the same FLOP, and of the four layers' 8 x 49 152 B per window only the run's input and
-    # output are algorithmic traffic
-    c = _plan(RUN_TO_11)
-    assert c[21][:2] == ("sep8-11", "sep_chip_kernel") and c[21][2] == 2 * 24 * 512 * 4
-    assert sum(v[2] for v in a.values()) - sum(v[2] for v in c.values()) == 6 * 24 * 512 * 4
-    # ... and with layer 12 + depthwise 13 along (the default): [24][512] in, [6][512] out per window
+def test_slot_plan_adds_up_to_the_network_in_every_launch_set():
+    for slots in (DEFAULT, NO_MID, PER_OP):
+        plan = _plan(slots)
+        assert sorted(plan) == sorted(slots)
+        assert sum(v[3] for v in plan.values()) == _network_flops()
+    # the on-chip run (sepchip.hip) with layer 12 + depthwise 13 along: of the five layers' tiles only the run's input and output are
+    # algorithmic traffic - [24][512] in, [6][512] out per window
     d = _plan(NO_MID)
     assert d[23][:2] == ("sep8-12+dw13", "sep_chip_kernel") and d[23][2] == (24 + 6) * 512 * 4
-    assert d[23][3] == c[21][3] + c[23][3]
-    # ... and pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one launch: [96][128] in, [24][512] out per window
+    o = _plan(PER_OP)
+    assert d[23][3] == sum(o[s_][3] for s_ in range(14, 25))                      # depthwise 8 .. depthwise 13
+    # ... pointwise 5 -> layer 6 -> depthwise 7 -> pointwise 7 as one launch: [96][128] in, [24][512] out per window
     m = _plan(DEFAULT)
     assert m[13][:2] == ("pw5-pw7", "sep_mid_kernel") and m[13][2] == (96 * 128 + 24 * 512) * 4
     assert m[13][3] == d[9][3] + d[11][3] + d[13][3] and m[7] == d[7]
-    # ... and layers 13 / 14 on septail.hip's kernel (the default): depthwise 14 moves from layer 14's slot into pointwise 13's;
-    # [6][512] in and [6][1024] out per window (as f16 planes: 4 bytes per element), then [6][1024] in and [1024] out
-    t = _plan(DEFAULT, tail=True)
-    assert sorted(t) == sorted(DEFAULT) and sum(v[3] for v in t.values()) == _network_flops()
-    assert t[25][:2] == ("pw13+dw14", "tail_gemm_kernel") and t[25][2] == (6 * 512 + 6 * 1024) * 4
-    assert t[27][:2] == ("pw14+pool", "tail_gemm_kernel") and t[27][2] == (6 * 1024 + 1024) * 4 and t[28][0] == "head"
-    assert t[25][3] + t[27][3] == m[25][3] + m[27][3] and t[23] == m[23]
+    # ... layers 13 / 14 on septail.hip's kernel: depthwise 14 is pointwise 13's epilogue; [6][512] in and [6][1024] out per window
+    # (as f16 planes: 4 bytes per element), then [6][1024] in and [1024] out
+    assert m[25][:2] == ("pw13+dw14", "tail_gemm_kernel") and m[25][2] == (6 * 512 + 6 * 1024) * 4
+    assert m[27][:2] == ("pw14+pool", "tail_gemm_kernel") and m[27][2] == (6 * 1024 + 1024) * 4 and m[28][0] == "head"
+    assert m[25][3] + m[27][3] == o[25][3] + o[26][3] + o[27][3] + 6 * 1024 and m[23] == d[23]
 
 
-def test_the_run_and_the_next_depthwise_forms_are_families_of_their_own():
-    plan = _plan(RUN_TO_11, chip=False)
-    assert plan[21][:2] == ("sep8-11", "sep_w12_kernel")
-    assert plan[21][3] == 4 * _plan(PER_LAYER)[15][3]
-    assert plan[23][:2] == ("sep12+dw13", "sep_w12_ndw_kernel")                 # 512 -> 512 with layer 13's depthwise: 12-wave kernel
-    assert plan[11][:2] == ("sep6+dw7", "sep_ws_kernel")                        # 256 -> 256: one column tile, 8-wave kernel
-    assert plan[27][:2] == ("sep14+pool", "sep_w12_ndw_kernel") and plan[28][0] == "head"     # two 512-column halves + pool
-    assert plan[25][:2] == ("pw13", "sep_ws_kernel")
+def test_the_kernels_of_the_other_launch_sets_are_named():
+    d = _plan(NO_MID)
+    assert d[7][:2] == ("sep4+dw5", "l4_window_kernel") and d[9][:2] == ("pw5", "pw_res_kernel")
+    assert d[11][:2] == ("sep6+dw7", "sep_ws_kernel") and d[13][:2] == ("pw7", "pw_res_kernel")
+    o = _plan(PER_OP)
+    assert o[1][1] == "conv1_kernel" and o[2][1] == "depthwise_kernel" and o[28][0] == "pool_head"
+    assert o[3][1] == "pointwise_f16x3_kernel" and o[25][1] == "sep_ws_kernel"      # 32 -> 64 on the tile kernel, 512 -> 1024 wave-specialised
 
 
 def test_strict_f32_is_measured_like_the_headline():

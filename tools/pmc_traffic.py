@@ -16,10 +16,6 @@ def family(name):
     if not m:
         return None
     fam = m.group(1)
-    if fam == "sep_w12_kernel":      # <XPMAX, TRACE, PLAIN, KT, NDW>: the NDW = 1 / 2 instantiations (layers 12, 14) are bench.py's sep_w12_ndw_kernel
-        args = re.findall(r"Li(\d+)E", name) if name.startswith("_ZN2bd") else re.findall(r"(\d+)", name.split("<", 1)[-1])
-        if len(args) >= 3 and args[2] in ("1", "2"):
-            fam = "sep_w12_ndw_kernel"
     return fam
 
 
