@@ -61,6 +61,30 @@ __global__ __launch_bounds__(512) void mfma_kernel(float* sink, int iters) {
     if (s == 12345.678f) sink[0] = s;
 }
 
+// the same FLOP per iteration on v_mfma_f32_16x16x32_f16 (sixteen accumulators of four registers)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void mfma16_kernel(float* sink, int iters) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) {
+        a[i] = (_Float16)(0.001f * (threadIdx.x + i));
+        b[i] = (_Float16)(0.002f * (threadIdx.x ^ i));
+    }
+    f32x4 acc[16];
+    for (int j = 0; j < 16; ++j)
+        for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j], 0, 0, 0);
+        }
+    }
+    float s = 0;
+    for (int j = 0; j < 16; ++j)
+        for (int r = 0; r < 4; ++r) s += acc[j][r];
+    if (s == 12345.678f) sink[0] = s;
+}
+
 template <bool PACKED>
 __global__ __launch_bounds__(512) void valu_kernel(float* sink, int iters) {
     v2f x[8], m = {1.0001f, 0.9999f}, c = {1e-6f, -1e-6f};
@@ -232,6 +256,14 @@ int main(int argc, char** argv) {
     {
         auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(mfma_kernel<0>, dim3(cus), dim3(512), 0, 0, sink, it_m); });
         report("mfma f16 32x32x16, 2 waves/SIMD, back to back", r, (double)cus * 8 * it_m * 16 * flop_mfma, "TFLOP/s", 1e-12);
+    }
+    {       // 32 instructions of 2 * 16 * 16 * 32 FLOP per iteration = the 16 of 2 * 32 * 32 * 16 above
+        auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(mfma16_kernel, dim3(cus), dim3(256), 0, 0, sink, it_m); });
+        report("mfma f16 16x16x32, 1 wave/SIMD, back to back", r, (double)cus * 4 * it_m * 16 * flop_mfma, "TFLOP/s", 1e-12);
+    }
+    {
+        auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(mfma16_kernel, dim3(cus), dim3(512), 0, 0, sink, it_m); });
+        report("mfma f16 16x16x32, 2 waves/SIMD, back to back", r, (double)cus * 8 * it_m * 16 * flop_mfma, "TFLOP/s", 1e-12);
     }
     {
         auto r = hold(hw, seconds, [&] { hipLaunchKernelGGL(mfma_kernel<2>, dim3(cus), dim3(256), 0, 0, sink, it_m / 2); });
