@@ -33,5 +33,26 @@ def main():
         print(" w", w, "c", c, "got", got[w, c], "ref", ref[w, c])
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "pattern"):
     main()
+
+
+def pattern():
+    """(window, channel mod 64) of every wrong embedding value, as a small table."""
+    windows = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    eng = HipEngine(embeddername="yamnet_k2", modelname="model_general_v3")
+    x = O.synthetic_audio(HOP * (windows - 1) + 15600, seed=windows)
+    if len(sys.argv) > 3:
+        eng.set_pointwise_mode(sys.argv[3])
+    eng.set_fusion(False, False)
+    ref = eng.embed(x, 0.96).numpy()
+    eng.set_fusion(True, True)
+    got = eng.embed(x, 0.96).numpy()
+    bad = got != ref
+    for w in range(windows):
+        cs = sorted(set(int(c) % 64 for c in np.nonzero(bad[w])[0]))
+        print("window", w, "wrong channels mod 64:", cs, " count", int(bad[w].sum()))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pattern":
+    pattern()
